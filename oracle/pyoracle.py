@@ -1,0 +1,229 @@
+"""ctypes binding of the CPU oracle (oracle/tscm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (tscm_calib_amd/) must never import
+this module.  Parity is unpinned against real Ceres -- see oracle/tscm_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "tscm_oracle.c")
+    hdr = os.path.join(_HERE, "tscm_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"])
+    return _LIB_PATH
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [
+        ("n_cameras", C.c_int), ("n_boards", C.c_int), ("n_points", C.c_int), ("n_views", C.c_int),
+        ("board_xy", C.c_void_p), ("view_camera", C.c_void_p), ("view_board", C.c_void_p),
+        ("view_offset", C.c_void_p), ("view_count", C.c_void_p), ("obs_u", C.c_void_p), ("obs_v", C.c_void_p),
+        ("cam_rt", C.c_void_p), ("intr", C.c_void_p), ("board_rt", C.c_void_p),
+        ("cam_pose_constant", C.c_void_p), ("mono", C.c_int),
+    ]
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("max_num_consecutive_invalid_steps", C.c_int), ("jacobi_scaling", C.c_int),
+    ]
+
+
+class OrcIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int), ("step_is_valid", C.c_int), ("step_is_successful", C.c_int),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+        ("gradient_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+    ]
+
+
+class OrcSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int), ("num_iterations", C.c_int), ("num_successful_steps", C.c_int),
+        ("num_unsuccessful_steps", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("n_residual_blocks", C.c_int), ("iterations", OrcIteration * 256), ("message", C.c_char * 128),
+        ("seconds_total", C.c_double), ("seconds_jacobian", C.c_double), ("seconds_linear", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.orc_default_options.argtypes = [C.POINTER(OrcOptions), C.c_int]
+        L.orc_project.argtypes = [dp, dp, dp]
+        L.orc_unproject.argtypes = [dp, dp, dp]
+        L.orc_angle_axis_rotate_point.argtypes = [dp, dp, dp]
+        L.orc_rodrigues.argtypes = [dp, dp]
+        L.orc_mono_residual.argtypes = [dp] * 5
+        L.orc_multi_residual.argtypes = [dp] * 6
+        L.orc_mono_autodiff.argtypes = [dp] * 7
+        L.orc_multi_autodiff.argtypes = [dp] * 9
+        L.orc_evaluate.argtypes = [C.POINTER(OrcProblem), C.c_int, dp, dp, dp, dp]
+        L.orc_evaluate.restype = C.c_double
+        L.orc_solve.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcOptions), C.POINTER(OrcSummary)]
+        L.orc_solve.restype = C.c_int
+        L.orc_mean_reprojection_error.argtypes = [C.POINTER(OrcProblem), dp]
+        L.orc_mean_reprojection_error.restype = C.c_double
+        L.orc_rmse.argtypes = [C.POINTER(OrcProblem)]
+        L.orc_rmse.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def c_problem(p) -> OrcProblem:
+    """Wrap a tscm_calib_amd.problem.Problem (arrays are referenced, not copied: keep `p` alive)."""
+    q = OrcProblem()
+    q.n_cameras, q.n_boards, q.n_points, q.n_views = p.n_cameras, p.n_boards, p.n_points, p.n_views
+    for name in ("board_xy", "view_camera", "view_board", "view_offset", "view_count", "obs_u", "obs_v",
+                 "cam_rt", "intr", "board_rt", "cam_pose_constant"):
+        arr = getattr(p, name)
+        assert arr.flags["C_CONTIGUOUS"]
+        setattr(q, name, arr.ctypes.data)
+    q.mono = 1 if p.mono else 0
+    return q
+
+
+def default_options(mono: bool, **over) -> OrcOptions:
+    o = OrcOptions()
+    lib().orc_default_options(C.byref(o), 1 if mono else 0)
+    for k, v in over.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def summary_dict(s: OrcSummary) -> dict:
+    its = []
+    for i in range(min(s.num_iterations, 256)):
+        it = s.iterations[i]
+        its.append({k: getattr(it, k) for k, _ in OrcIteration._fields_})
+    return dict(termination_type=s.termination_type, num_iterations=s.num_iterations,
+                num_successful_steps=s.num_successful_steps, num_unsuccessful_steps=s.num_unsuccessful_steps,
+                initial_cost=s.initial_cost, final_cost=s.final_cost, n_residual_blocks=s.n_residual_blocks,
+                iterations=its, message=s.message.decode(), seconds_total=s.seconds_total,
+                seconds_jacobian=s.seconds_jacobian, seconds_linear=s.seconds_linear)
+
+
+def solve(p, **option_overrides) -> dict:
+    """Run the oracle LM in place on `p` (a normalised Problem)."""
+    q = c_problem(p)
+    o = default_options(p.mono, **option_overrides)
+    s = OrcSummary()
+    rc = lib().orc_solve(C.byref(q), C.byref(o), C.byref(s))
+    d = summary_dict(s)
+    d["rc"] = rc
+    return d
+
+
+def evaluate(p, jets: bool = True):
+    """-> cost, residuals [N,2], J_cam [N,2,6], J_board [N,2,6], J_intr [N,2,9] (jets only)."""
+    q = c_problem(p)
+    N = p.n_corners
+    res = np.zeros((N, 2))
+    if jets:
+        Jc, Jb, Ji = np.zeros((N, 2, 6)), np.zeros((N, 2, 6)), np.zeros((N, 2, 9))
+        cost = lib().orc_evaluate(C.byref(q), 1, _dp(res), _dp(Jc), _dp(Jb), _dp(Ji))
+        return cost, res, Jc, Jb, Ji
+    cost = lib().orc_evaluate(C.byref(q), 0, _dp(res), None, None, None)
+    return cost, res
+
+
+def project(intr, P) -> np.ndarray:
+    intr, P = _f(intr), _f(P)
+    out = np.zeros(2)
+    lib().orc_project(_dp(intr), _dp(P), _dp(out))
+    return out
+
+
+def unproject(intr, uv) -> np.ndarray:
+    intr, uv = _f(intr), _f(uv)
+    out = np.zeros(3)
+    lib().orc_unproject(_dp(intr), _dp(uv), _dp(out))
+    return out
+
+
+def rotate(aa, pt) -> np.ndarray:
+    aa, pt = _f(aa), _f(pt)
+    out = np.zeros(3)
+    lib().orc_angle_axis_rotate_point(_dp(aa), _dp(pt), _dp(out))
+    return out
+
+
+def rodrigues(aa) -> np.ndarray:
+    aa = _f(aa)
+    out = np.zeros(9)
+    lib().orc_rodrigues(_dp(aa), _dp(out))
+    return out.reshape(3, 3)
+
+
+def mono_residual(intr, rt, obs, board_pt) -> np.ndarray:
+    a = [_f(x) for x in (intr, rt, obs, board_pt)]
+    out = np.zeros(2)
+    lib().orc_mono_residual(*[_dp(x) for x in a], _dp(out))
+    return out
+
+
+def multi_residual(cam_rt, board_rt, intr, obs, board_pt) -> np.ndarray:
+    a = [_f(x) for x in (cam_rt, board_rt, intr, obs, board_pt)]
+    out = np.zeros(2)
+    lib().orc_multi_residual(*[_dp(x) for x in a], _dp(out))
+    return out
+
+
+def mono_autodiff(intr, rt, obs, board_pt):
+    a = [_f(x) for x in (intr, rt, obs, board_pt)]
+    res, Ji, Jr = np.zeros(2), np.zeros((2, 9)), np.zeros((2, 6))
+    lib().orc_mono_autodiff(*[_dp(x) for x in a], _dp(res), _dp(Ji), _dp(Jr))
+    return res, Ji, Jr
+
+
+def multi_autodiff(cam_rt, board_rt, intr, obs, board_pt):
+    a = [_f(x) for x in (cam_rt, board_rt, intr, obs, board_pt)]
+    res, Jc, Jb, Ji = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 6)), np.zeros((2, 9))
+    lib().orc_multi_autodiff(*[_dp(x) for x in a], _dp(res), _dp(Jc), _dp(Jb), _dp(Ji))
+    return res, Jc, Jb, Ji
+
+
+def mean_reprojection_error(p):
+    q = c_problem(p)
+    per = np.zeros(p.n_cameras)
+    g = lib().orc_mean_reprojection_error(C.byref(q), _dp(per))
+    return g, per
+
+
+def rmse(p) -> float:
+    q = c_problem(p)
+    return lib().orc_rmse(C.byref(q))

@@ -1,0 +1,150 @@
+/*
+ * tscm_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE)
+ *
+ * Plain-C restatement of the reference's Triple-Sphere reprojection-error
+ * Levenberg-Marquardt hot path (imuncle/TSCM_Calib):
+ *   - cost functors            TS.h:100-131, multi_calib.h:146-195
+ *   - problem build + options  TS.cpp:247-282, multi_calib.cpp:155-218
+ *   - plain projection family  TS.cpp:332-344, TS.cpp:205-245, TS.h:58-69,
+ *                              multi_calib.cpp:233-283
+ *   - unprojection             TS.h:39-57
+ * plus the behaviour of the un-vendored dependency that holds all of the
+ * solver arithmetic: Ceres Solver (find_package(Ceres), CMakeLists.txt:7;
+ * version unpinned, most likely 1.14.x): Jet forward-mode autodiff,
+ * AngleAxisRotatePoint, TrustRegionMinimizer + LevenbergMarquardtStrategy with
+ * default options and the DENSE_SCHUR linear solver. Those parts are restated
+ * from Ceres' published algorithm (ceres/jet.h, ceres/rotation.h,
+ * internal/ceres/trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
+ * schur_eliminator_impl.h) -- none of that source is under /root/reference.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path
+ * and Ceres/Eigen/OpenCV are not installed in the build container, so this
+ * oracle cannot be checked against outputs of the real reference. It is pinned
+ * only by (i) 50-digit mpmath known-answer values of the cited formulas
+ * (tests/golden/kat_ts.json), (ii) project/unproject round trips, (iii)
+ * dual-number vs central-difference Jacobians, and (iv) SciPy least_squares
+ * reaching the same optimum cost on config-1-size problems.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this library.  The product (tscm_calib_amd/) never does.
+ */
+#ifndef TSCM_ORACLE_H
+#define TSCM_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Problem description shared by the mono and the multi-camera solve.
+ * A "view" is one (camera, board/frame) pair with `count` detected corners;
+ * corner j of a view observes board point j (multi_calib.cpp:169-176:
+ * `for j < pixels[i].size()` pairs pixels[i][j] with worlds_[j]).           */
+typedef struct {
+    int n_cameras;             /* C                                            */
+    int n_boards;              /* B (mono: number of views/images)             */
+    int n_points;              /* corners on the board (e.g. 54 = 9x6)         */
+    int n_views;               /* number of (camera, board) pairs with corners */
+    const double *board_xy;    /* [n_points*2] x,y ; z is forced to 0          */
+                               /*   (TS.h:107-109, multi_calib.h:154-156)      */
+    const int *view_camera;    /* [n_views]                                    */
+    const int *view_board;     /* [n_views]                                    */
+    const int *view_offset;    /* [n_views] first corner of the view in obs_*  */
+    const int *view_count;     /* [n_views] corners in the view (<= n_points)  */
+    const double *obs_u;       /* [N] observed pixel x                          */
+    const double *obs_v;       /* [N] observed pixel y                          */
+    double *cam_rt;            /* [C*6] angle-axis + t, in/out (multi only)     */
+    double *intr;              /* [C*9] fx fy cx cy xi lambda alpha b c, in/out */
+    double *board_rt;          /* [B*6] angle-axis + t, in/out                  */
+    const unsigned char *cam_pose_constant; /* [C] 1 = SetParameterBlockConstant
+                                               (multi_calib.cpp:186); may be NULL */
+    int mono;                  /* 1: TS.h functor (no camera pose), C must be 1 */
+} orc_problem;
+
+typedef struct {
+    int max_num_iterations;           /* 100 mono (TS.cpp:274), 50 multi (Ceres default) */
+    double function_tolerance;        /* 1e-6  */
+    double gradient_tolerance;        /* 1e-10 */
+    double parameter_tolerance;       /* 1e-8  */
+    double initial_trust_region_radius; /* 1e4 */
+    double max_trust_region_radius;   /* 1e16  */
+    double min_trust_region_radius;   /* 1e-32 */
+    double min_relative_decrease;     /* 1e-3  */
+    double min_lm_diagonal;           /* 1e-6  */
+    double max_lm_diagonal;           /* 1e32  */
+    int max_num_consecutive_invalid_steps; /* 5 */
+    int jacobi_scaling;               /* 1     */
+} orc_options;
+
+enum { ORC_CONVERGENCE = 0, ORC_NO_CONVERGENCE = 1, ORC_FAILURE = 2 };
+
+typedef struct {
+    int iteration;
+    int step_is_valid, step_is_successful;
+    double cost, cost_change, gradient_max_norm, gradient_norm, step_norm;
+    double relative_decrease, trust_region_radius;
+} orc_iteration;
+
+typedef struct {
+    int termination_type;
+    int num_iterations;            /* entries in `iterations` (incl. iteration 0) */
+    int num_successful_steps, num_unsuccessful_steps;
+    double initial_cost, final_cost;
+    int n_residual_blocks;         /* N corners in the program */
+    orc_iteration iterations[256];
+    char message[128];
+    double seconds_total;          /* wall time of the minimiser loop */
+    double seconds_jacobian;       /* time inside residual+Jacobian evaluation */
+    double seconds_linear;         /* time inside Schur eliminate/solve/back-substitute */
+} orc_summary;
+
+void orc_default_options(orc_options *o, int mono);
+
+/* ---- camera model -------------------------------------------------------*/
+/* TS.cpp:332-344 (project, with the skew terms b,c). intr = 9 doubles.      */
+void orc_project(const double *intr, const double *P, double *uv);
+/* TS.h:39-57 (get_unit_sphere_coordinate with transform = identity).        */
+void orc_unproject(const double *intr, const double *uv, double *ray);
+/* ceres::AngleAxisRotatePoint (external), double instantiation.             */
+void orc_angle_axis_rotate_point(const double *aa, const double *pt, double *out);
+/* cv::Rodrigues(r -> R) as used by update_param (multi_calib.h:42-57,104-108),
+ * row-major 3x3. */
+void orc_rodrigues(const double *aa, double *R);
+
+/* ---- functors -----------------------------------------------------------*/
+/* T = double instantiation of TS.h:100-131.  board_pt = (x,y[,ignored z]).  */
+void orc_mono_residual(const double *intr, const double *rt, const double *obs,
+                       const double *board_pt, double *res);
+/* T = double instantiation of multi_calib.h:146-195.                        */
+void orc_multi_residual(const double *cam_rt, const double *board_rt, const double *intr,
+                        const double *obs, const double *board_pt, double *res);
+/* T = Jet instantiation (what ceres::AutoDiffCostFunction evaluates).  Jacobians are
+ * row-major [2 x block] like CostFunction::Evaluate; any pointer may be NULL. */
+void orc_mono_autodiff(const double *intr, const double *rt, const double *obs,
+                       const double *board_pt, double *res, double *J_intr /*2x9*/,
+                       double *J_rt /*2x6*/);
+void orc_multi_autodiff(const double *cam_rt, const double *board_rt, const double *intr,
+                        const double *obs, const double *board_pt, double *res,
+                        double *J_cam /*2x6*/, double *J_board /*2x6*/, double *J_intr /*2x9*/);
+
+/* ---- batched evaluation of a whole problem ------------------------------*/
+/* residuals [2N] interleaved (u,v per corner); J_* may be NULL; layout per corner:
+ * J_cam[2*6], J_board[2*6], J_intr[2*9] row-major.  Returns cost = 0.5*sum r^2.
+ * use_jets=0 evaluates the double functor (cost-only path of Ceres).           */
+double orc_evaluate(const orc_problem *p, int use_jets, double *residuals,
+                    double *J_cam, double *J_board, double *J_intr);
+
+/* ---- the solve (TS.cpp:247-282 / multi_calib.cpp:155-218 + Ceres) -------*/
+int orc_solve(const orc_problem *p, const orc_options *opt, orc_summary *summary);
+
+/* ---- error reports ------------------------------------------------------*/
+/* multi_calib.cpp:233-283: per-camera mean Euclidean pixel error (projection
+ * with skew terms, poses through Rodrigues matrices) and the global mean.
+ * per_camera may be NULL. Returns global mean. */
+double orc_mean_reprojection_error(const orc_problem *p, double *per_camera);
+/* sqrt(sum r^2 / N) over all corners with the double functor. */
+double orc_rmse(const orc_problem *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
