@@ -1,0 +1,220 @@
+/*
+ * tscm.h -- C ABI of the MI355X-native Triple-Sphere reprojection-error LM solver.
+ *
+ * Drop-in boundary for the hot path of imuncle/TSCM_Calib:
+ * plain pointers and sizes, caller-owned parameter arrays updated in place -- the same
+ * contract the reference has with Ceres, which identifies parameter blocks by pointer
+ * (`intrinsic_.data()`, `rt_[i].data()`: TS.cpp:266-267, multi_calib.cpp:182-184).
+ * Every entry point names the reference interface it replaces.  INTEGRATION.md shows
+ * the reference-side binding (the body of MultiCalib::calibrate() /
+ * TripleSphereCamera::refinement() rewritten onto these calls).
+ *
+ * All entry points return 0 on success or a negative TSCM_E_* code;
+ * tscm_last_error() returns a thread-local description of the last failure.
+ * The library never falls back to a CPU path: without a usable HIP device every
+ * compute entry point fails with TSCM_E_NO_DEVICE.
+ */
+#ifndef TSCM_H
+#define TSCM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSCM_ABI_VERSION 1
+
+enum {
+    TSCM_OK = 0,
+    TSCM_E_INVALID = -1,      /* bad argument / inconsistent problem description      */
+    TSCM_E_NO_DEVICE = -2,    /* no HIP device, or hipSetDevice failed                */
+    TSCM_E_HIP = -3,          /* a HIP runtime call failed                            */
+    TSCM_E_RCCL = -4,         /* an RCCL call failed                                  */
+    TSCM_E_UNSUPPORTED = -5,  /* problem shape outside what the kernels support       */
+    TSCM_E_NOMEM = -6
+};
+
+/* ceres::TerminationType values the reference looks at (TS.cpp:281). */
+enum { TSCM_CONVERGENCE = 0, TSCM_NO_CONVERGENCE = 1, TSCM_FAILURE = 2 };
+
+#define TSCM_MAX_ITERATIONS 255
+
+/*
+ * Problem = what multi_calib.cpp:157-207 / TS.cpp:249-269 feed to ceres::Problem.
+ *
+ * A "view" is one (camera m, board i) pair with detected corners, i.e. a non-empty
+ * cameras_[m].pixels()[i] with chessboards_[i].is_initial() (multi_calib.cpp:164-169);
+ * corner j of the view is paired with board point worlds_[j] (:176).  Mono: a view is
+ * an image with has_chessboard_[i] (TS.cpp:253), camera index 0, board index = image.
+ *
+ * Parameter layout is the reference's: intrinsics `fx fy cx cy xi lambda alpha b c`
+ * (TS.h:105, multi_calib.h:22), poses = angle-axis (rad) then translation in board
+ * units (TS.cpp:72, multi_calib.h:17).  b and c are inert (their terms are commented
+ * out in both functors: TS.h:122-123, multi_calib.h:175-176) and are returned unchanged.
+ */
+typedef struct tscm_problem {
+    int n_cameras;                 /* C                                                */
+    int n_boards;                  /* B  (mono: number of images)                      */
+    int n_points;                  /* board corners, e.g. 54 or 88                     */
+    int n_views;
+    const double *board_xy;        /* [n_points*2]  worlds_[j].x, .y (z forced to 0:   */
+                                   /*   TS.h:107-109, multi_calib.h:154-156)           */
+    const int *view_camera;        /* [n_views]                                        */
+    const int *view_board;         /* [n_views]                                        */
+    const int *view_offset;        /* [n_views] first corner of the view in obs_u/v    */
+    const int *view_count;         /* [n_views] pixels[i].size()  (0..n_points)        */
+    const double *obs_u;           /* [N] observed pixel x, SoA                        */
+    const double *obs_v;           /* [N] observed pixel y                             */
+    double *cam_rt;                /* [C*6] cameras_[m].rt_        in/out (host)       */
+    double *intr;                  /* [C*9] cameras_[m].intrinsic_ in/out (host)       */
+    double *board_rt;              /* [B*6] chessboards_[i].rt_ / rt_[i]  in/out (host)*/
+    const unsigned char *cam_pose_constant; /* [C] SetParameterBlockConstant           */
+                                   /*   (multi_calib.cpp:186: camera 0); NULL = none   */
+    int mono;                      /* 1: TS.h functor -- no camera pose block at all   */
+} tscm_problem;
+
+/* ceres::Solver::Options fields the path depends on, Ceres defaults
+ * (TS.cpp:271-274, multi_calib.cpp:209-212; linear solver is always DENSE_SCHUR). */
+typedef struct tscm_options {
+    int max_num_iterations;              /* 100 mono (TS.cpp:274) / 50 multi           */
+    double function_tolerance;           /* 1e-6                                       */
+    double gradient_tolerance;           /* 1e-10                                      */
+    double parameter_tolerance;          /* 1e-8                                       */
+    double initial_trust_region_radius;  /* 1e4                                        */
+    double max_trust_region_radius;      /* 1e16                                       */
+    double min_trust_region_radius;      /* 1e-32                                      */
+    double min_relative_decrease;        /* 1e-3                                       */
+    double min_lm_diagonal;              /* 1e-6                                       */
+    double max_lm_diagonal;              /* 1e32                                       */
+    int max_num_consecutive_invalid_steps; /* 5                                        */
+    int jacobi_scaling;                  /* 1                                          */
+    int check_every;                     /* host polls the device-resident LM loop     */
+                                         /* every this many iterations (default 4)     */
+} tscm_options;
+
+/* ceres::IterationSummary subset */
+typedef struct tscm_iteration {
+    int iteration;
+    int step_is_valid;
+    int step_is_successful;
+    double cost;
+    double cost_change;
+    double gradient_max_norm;
+    double gradient_norm;
+    double step_norm;
+    double relative_decrease;
+    double trust_region_radius;
+} tscm_iteration;
+
+/* ceres::Solver::Summary subset (what BriefReport prints: TS.cpp:280, multi_calib.cpp:218)
+ * plus the error report of multi_calib.cpp:233-283. */
+typedef struct tscm_summary {
+    int termination_type;          /* TSCM_CONVERGENCE / NO_CONVERGENCE / FAILURE      */
+    int num_iterations;            /* entries in iterations[] (iteration 0 included)   */
+    int num_successful_steps;
+    int num_unsuccessful_steps;
+    double initial_cost;
+    double final_cost;
+    int n_residual_blocks;         /* corners in the program                           */
+    int lm_iterations;             /* LM iterations executed (incl. a final one that   */
+                                   /*   ended on a tolerance test)                     */
+    tscm_iteration iterations[TSCM_MAX_ITERATIONS + 1];
+    char message[128];
+    double seconds_solve;          /* minimiser loop only (device work + host polling) */
+    double seconds_total;          /* incl. parameter upload/download                  */
+    double rmse;                   /* sqrt(2*final_cost/N)                             */
+} tscm_summary;
+
+typedef struct tscm_solver tscm_solver;   /* opaque: device buffers, stream, layouts  */
+typedef struct tscm_comm tscm_comm;       /* opaque: RCCL communicator                */
+
+int tscm_abi_version(void);
+const char *tscm_last_error(void);
+int tscm_device_count(void);
+
+void tscm_default_options(tscm_options *opt, int mono);
+
+/* ------------------------------------------------------------------ solver handle
+ * tscm_solver_create  uploads observations and builds the device layout once
+ *                     (replaces the per-corner `new ReprojectionError` +
+ *                     AddResidualBlock loops: TS.cpp:251-269, multi_calib.cpp:162-207).
+ * tscm_solver_solve   = ceres::Solve(options, &problem, &summary)
+ *                     (TS.cpp:278, multi_calib.cpp:216).  Reads the initial parameters
+ *                     from the problem's cam_rt / intr / board_rt host arrays and
+ *                     overwrites them with the result, like Ceres does.
+ */
+int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
+int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU */
+int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *summary);
+/* Same as _solve but parameters start from / are left in device memory (used by the
+ * benchmark to time the minimiser loop with inputs resident in HBM). reset=1 reloads
+ * the parameters that were uploaded by the last tscm_solver_upload_params. */
+int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, const double *intr, const double *board_rt);
+int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *opt, tscm_summary *summary, int reset);
+int tscm_solver_download_params(tscm_solver *s, double *cam_rt, double *intr, double *board_rt);
+void tscm_solver_destroy(tscm_solver *s);
+/* timing of the dominant kernel (tscm_eval_gram) accumulated by HIP events on the
+ * solver's own stream since the last call; returns launches and total milliseconds. */
+int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches, double *total_ms);
+
+/* One-shot drop-ins ------------------------------------------------------------
+ * tscm_solve_multi replaces the Ceres block of MultiCalib::calibrate()
+ *                  (multi_calib.cpp:157-218); the caller then runs update_param()
+ *                  (multi_calib.cpp:221-232) on its own objects.
+ * tscm_solve_mono  replaces TripleSphereCamera::refinement (TS.cpp:247-282); the
+ *                  reference's `return summary.termination_type == CONVERGENCE`
+ *                  is `summary->termination_type == TSCM_CONVERGENCE`.             */
+int tscm_solve_multi(const tscm_problem *problem, const tscm_options *opt, tscm_summary *summary);
+int tscm_solve_mono(const tscm_problem *problem, const tscm_options *opt, tscm_summary *summary);
+
+/* ------------------------------------------------------------------ operator level
+ * Batched cost-functor evaluation = ceres::CostFunction::Evaluate of
+ * AutoDiffCostFunction<ReprojectionError,2,6,6,9> (multi_calib.h:138-199) /
+ * <...,2,9,6> (TS.h:93-134) for every corner of the problem, on the GPU, with the
+ * analytic Jacobian.  Corner order = views in problem order, corners in order.
+ * residuals [N*2]; J_cam [N*2*6], J_board [N*2*6], J_intr [N*2*9] row-major per corner
+ * (any of the three may be NULL).  cost = 0.5*sum r^2.  Host pointers.            */
+int tscm_eval_functor(const tscm_problem *problem, int device, double *residuals,
+                      double *J_cam, double *J_board, double *J_intr, double *cost);
+
+/* Schur-form normal equations at the problem's current parameters (the quantities
+ * Ceres' SchurEliminator forms from the Jacobian), for parity tests.  Outputs (host,
+ * any may be NULL):  board_gram [B*36] = sum E^T E ; board_grad [B*6] = E^T r ;
+ * view_cross [n_views*6*15] = E^T [F_campose(6) F_intr(9)] per view ;
+ * cam_gram [C*15*15] = F^T F per camera ; cam_grad [C*15] = F^T r ; cost.
+ * All UNSCALED (no Jacobi scaling, no damping).                                    */
+int tscm_eval_normal_equations(const tscm_problem *problem, int device, double *board_gram,
+                               double *board_grad, double *view_cross, double *cam_gram,
+                               double *cam_grad, double *cost);
+
+/* ------------------------------------------------------------------ projection family
+ * tscm_project_points   = TripleSphereCamera::project (TS.cpp:332-344), skew terms
+ *                         included, n camera-frame points [n*3] -> pixels [n*2].
+ * tscm_unproject_pixels = get_unit_sphere_coordinate (TS.h:39-57) with
+ *                         transform = identity, pixels [n*2] -> unit rays [n*3].
+ * tscm_reprojection_error = the report of multi_calib.cpp:233-283 / main.cpp:245-288:
+ *                         per-camera mean Euclidean pixel error [C] (may be NULL),
+ *                         global mean, and RMSE over all corners.                  */
+int tscm_project_points(const double *intr9, const double *points, int n, int device, double *pixels);
+int tscm_unproject_pixels(const double *intr9, const double *pixels, int n, int device, double *rays);
+int tscm_reprojection_error(const tscm_problem *problem, int device, double *per_camera_mean,
+                            double *global_mean, double *rmse);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL)
+ * One process per GPU.  Rank 0 calls tscm_comm_unique_id and distributes the 128
+ * bytes (e.g. over torch.distributed / MPI / a file); every rank then calls
+ * tscm_comm_create.  Frames are sharded by the caller (tscm_shard_frames) so every
+ * board's Schur block is rank-local; the solver all-reduces the reduced camera system
+ * and a handful of scalars twice per LM iteration (ncclAllReduce, sum / max).       */
+#define TSCM_UNIQUE_ID_BYTES 128
+int tscm_comm_unique_id(unsigned char id[TSCM_UNIQUE_ID_BYTES]);
+int tscm_comm_create(const unsigned char id[TSCM_UNIQUE_ID_BYTES], int rank, int world, int device, tscm_comm **out);
+void tscm_comm_destroy(tscm_comm *c);
+/* owner[b] = rank owning board b: contiguous ranges balanced by corner count.       */
+int tscm_shard_frames(const tscm_problem *problem, int world, int *owner);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSCM_H */

@@ -1,0 +1,797 @@
+// tscm_solver.hip -- host side of the MI355X-native TSCM LM solver and the C ABI (include/tscm/tscm.h).
+//
+// Replaces, behind the reference's own call boundary:
+//   * ceres::Problem construction (TS.cpp:249-269, multi_calib.cpp:160-207)  -> tscm_solver_create
+//   * ceres::Solve, DENSE_SCHUR + LM (TS.cpp:271-278, multi_calib.cpp:209-216) -> tscm_solver_solve
+// The host only enqueues kernels and polls a device-resident control block: accept/reject,
+// the trust-region radius and the termination tests all run on the GPU (k_control), so one LM
+// iteration costs no host<->device round trip.
+#include "tscm/tscm.h"
+#include "tscm_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace tscm;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(TSCM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                                 \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return fail(TSCM_E_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));             \
+    } while (0)
+
+static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct tscm_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+struct tscm_solver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevProblem P{};
+    DevState S{};
+    std::vector<void *> allocs;
+    tscm_comm *comm = nullptr;
+    // host copies of the layout
+    int C = 0, B = 0, V = 0, N = 0, n_points = 0, n_pad = 0;
+    bool mono = false;
+    std::vector<int> dev2orig;          // device view -> problem view
+    std::vector<int> h_view_obs, h_view_count, h_view_cam, h_view_board;
+    // caller-owned parameter arrays (host)
+    double *h_cam_rt = nullptr, *h_intr = nullptr, *h_board_rt = nullptr;
+    // resident initial parameters for the benchmark
+    double *d_init_cam = nullptr, *d_init_intr = nullptr, *d_init_board = nullptr;
+    bool have_init = false;
+    Ctrl *h_ctrl = nullptr;             // pinned
+    size_t lds_eval = 0, lds_solve = 0;
+    // dominant-kernel timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used = 0;
+    int t_launches = 0;
+    double t_ms = 0.0;
+};
+
+template <typename T>
+static int dev_alloc(tscm_solver *s, T **p, size_t n)
+{
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    s->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return 0;
+}
+
+template <typename T>
+static int dev_upload(tscm_solver *s, const T **p, const std::vector<T> &h)
+{
+    T *q = nullptr;
+    if (int rc = dev_alloc(s, &q, h.size())) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpy(q, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *p = q;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tscm_abi_version(void) { return TSCM_ABI_VERSION; }
+extern "C" const char *tscm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int tscm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void tscm_default_options(tscm_options *o, int mono)
+{
+    o->max_num_iterations = mono ? 100 : 50;   // TS.cpp:274 ; Ceres default (multi_calib.cpp:212 is commented out)
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->jacobi_scaling = 1;
+    o->check_every = 4;
+}
+
+static int validate(const tscm_problem *p)
+{
+    if (!p) return fail(TSCM_E_INVALID, "problem is NULL");
+    if (p->n_cameras < 1 || p->n_boards < 0 || p->n_points < 1 || p->n_views < 0) return fail(TSCM_E_INVALID, "negative or zero problem dimensions");
+    if (p->mono && p->n_cameras != 1) return fail(TSCM_E_INVALID, "mono problem needs exactly one camera");
+    if (!p->board_xy || !p->intr || (!p->board_rt && p->n_boards) || (!p->mono && !p->cam_rt)) return fail(TSCM_E_INVALID, "NULL parameter/board array");
+    if (p->n_views && (!p->view_camera || !p->view_board || !p->view_offset || !p->view_count || !p->obs_u || !p->obs_v)) return fail(TSCM_E_INVALID, "NULL view/observation array");
+    if (p->n_cameras > kMaxCam) return fail(TSCM_E_UNSUPPORTED, "more than 8 cameras: reduced system does not fit the LDS-resident solver");
+    for (int v = 0; v < p->n_views; ++v) {
+        if (p->view_camera[v] < 0 || p->view_camera[v] >= p->n_cameras) return fail(TSCM_E_INVALID, "view_camera out of range");
+        if (p->view_board[v] < 0 || p->view_board[v] >= p->n_boards) return fail(TSCM_E_INVALID, "view_board out of range");
+        if (p->view_count[v] < 0 || p->view_count[v] > p->n_points) return fail(TSCM_E_INVALID, "view_count outside [0, n_points]");
+        if (p->view_offset[v] < 0) return fail(TSCM_E_INVALID, "negative view_offset");
+    }
+    return 0;
+}
+
+extern "C" void tscm_solver_destroy(tscm_solver *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &e : s->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void *q : s->allocs) (void)hipFree(q);
+    if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver **out)
+{
+    if (!out) return fail(TSCM_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate(p)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TSCM_E_NO_DEVICE, "no HIP device available (the TSCM solver has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    std::unique_ptr<tscm_solver, void (*)(tscm_solver *)> sp(new tscm_solver, tscm_solver_destroy);
+    tscm_solver *s = sp.get();
+    s->device = device;
+    s->C = p->n_cameras; s->B = p->n_boards; s->n_points = p->n_points; s->mono = p->mono != 0;
+    s->n_pad = 16 * s->C;
+    s->h_cam_rt = p->cam_rt; s->h_intr = p->intr; s->h_board_rt = p->board_rt;
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const int C = s->C, B = s->B;
+
+    // ---- device view order: views with corners, sorted by (camera, board) ----------------------
+    std::vector<int> order;
+    for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0) order.push_back(v);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (p->view_camera[a] != p->view_camera[b]) return p->view_camera[a] < p->view_camera[b];
+        return p->view_board[a] < p->view_board[b];
+    });
+    for (size_t i = 1; i < order.size(); ++i)
+        if (p->view_camera[order[i]] == p->view_camera[order[i - 1]] && p->view_board[order[i]] == p->view_board[order[i - 1]])
+            return fail(TSCM_E_INVALID, "two views with the same (camera, board)");
+    const int V = (int)order.size();
+    s->V = V; s->dev2orig = order;
+    std::vector<int> view_cam(V), view_board(V), view_obs(V), view_count(V);
+    long N = 0;
+    for (int i = 0; i < V; ++i) {
+        const int v = order[i];
+        view_cam[i] = p->view_camera[v]; view_board[i] = p->view_board[v]; view_count[i] = p->view_count[v];
+        view_obs[i] = (int)N; N += p->view_count[v];
+    }
+    if (N > 0x7fffffffL) return fail(TSCM_E_UNSUPPORTED, "more than 2^31 corners");
+    s->N = (int)N;
+    s->h_view_obs = view_obs; s->h_view_count = view_count; s->h_view_cam = view_cam; s->h_view_board = view_board;
+    std::vector<double> u((size_t)N), w((size_t)N);
+    for (int i = 0; i < V; ++i) {
+        const int v = order[i];
+        std::memcpy(u.data() + view_obs[i], p->obs_u + p->view_offset[v], sizeof(double) * view_count[i]);
+        std::memcpy(w.data() + view_obs[i], p->obs_v + p->view_offset[v], sizeof(double) * view_count[i]);
+    }
+    std::vector<unsigned char> cam_const(C, 0), cam_active(C, 0);
+    for (int m = 0; m < C; ++m) cam_const[m] = (p->mono || (p->cam_pose_constant && p->cam_pose_constant[m])) ? 1 : 0;
+    for (int i = 0; i < V; ++i) cam_active[view_cam[i]] = 1;
+
+    // ---- chunks of views (one wave each), never straddling a camera ----------------------------
+    const int target_chunks = 2048;
+    const int per_chunk = std::max(1, (V + target_chunks - 1) / target_chunks);
+    std::vector<int> chunk_vb, chunk_ve, chunk_cam, cam_chunk_ptr(C + 1, 0);
+    {
+        int i = 0;
+        for (int m = 0; m < C; ++m) {
+            cam_chunk_ptr[m] = (int)chunk_vb.size();
+            int e = i;
+            while (e < V && view_cam[e] == m) ++e;
+            for (int b0 = i; b0 < e; b0 += per_chunk) { chunk_vb.push_back(b0); chunk_ve.push_back(std::min(e, b0 + per_chunk)); chunk_cam.push_back(m); }
+            i = e;
+        }
+        cam_chunk_ptr[C] = (int)chunk_vb.size();
+    }
+    // ---- board -> views (device order => increasing camera) --------------------------------------
+    std::vector<int> bv_ptr(B + 1, 0), bv_idx(V);
+    for (int i = 0; i < V; ++i) bv_ptr[view_board[i] + 1]++;
+    for (int b = 0; b < B; ++b) bv_ptr[b + 1] += bv_ptr[b];
+    {
+        std::vector<int> fill(B, 0);
+        for (int i = 0; i < V; ++i) { const int b = view_board[i]; bv_idx[bv_ptr[b] + fill[b]++] = i; }
+    }
+    // ---- view pairs grouped by camera-pair block --------------------------------------------------
+    std::vector<int> bid_of(C * C, -1), bid_mi, bid_mj;
+    std::vector<std::vector<std::pair<int, int>>> pairs_by_bid;
+    for (int b = 0; b < B; ++b)
+        for (int q1 = bv_ptr[b]; q1 < bv_ptr[b + 1]; ++q1)
+            for (int q2 = q1; q2 < bv_ptr[b + 1]; ++q2) {
+                const int vi = bv_idx[q1], vj = bv_idx[q2];
+                const int key = view_cam[vi] * C + view_cam[vj];
+                if (bid_of[key] < 0) { bid_of[key] = (int)bid_mi.size(); bid_mi.push_back(view_cam[vi]); bid_mj.push_back(view_cam[vj]); pairs_by_bid.emplace_back(); }
+                pairs_by_bid[bid_of[key]].emplace_back(vi, vj);
+            }
+    const int n_bids = (int)bid_mi.size();
+    size_t n_pairs = 0;
+    for (auto &v : pairs_by_bid) n_pairs += v.size();
+    const int target_pchunks = 1024;
+    const int per_pchunk = std::max<int>(1, (int)((n_pairs + target_pchunks - 1) / target_pchunks));
+    std::vector<int> pair_i, pair_j, pc_begin, pc_end, bid_pc_ptr(n_bids + 1, 0);
+    for (int bid = 0; bid < n_bids; ++bid) {
+        bid_pc_ptr[bid] = (int)pc_begin.size();
+        const int base = (int)pair_i.size();
+        for (auto &pr : pairs_by_bid[bid]) { pair_i.push_back(pr.first); pair_j.push_back(pr.second); }
+        const int end = (int)pair_i.size();
+        for (int b0 = base; b0 < end; b0 += per_pchunk) { pc_begin.push_back(b0); pc_end.push_back(std::min(end, b0 + per_pchunk)); }
+    }
+    bid_pc_ptr[n_bids] = (int)pc_begin.size();
+
+    // ---- upload --------------------------------------------------------------------------------
+    DevProblem &P = s->P;
+    DevState &S = s->S;
+    P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
+    P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
+    std::vector<double> bxy(p->board_xy, p->board_xy + 2 * (size_t)p->n_points);
+    int rc;
+    if ((rc = dev_upload(s, &P.board_xy, bxy))) return rc;
+    if ((rc = dev_upload(s, &P.view_cam, view_cam))) return rc;
+    if ((rc = dev_upload(s, &P.view_board, view_board))) return rc;
+    if ((rc = dev_upload(s, &P.view_obs, view_obs))) return rc;
+    if ((rc = dev_upload(s, &P.view_count, view_count))) return rc;
+    if ((rc = dev_upload(s, &P.obs_u, u))) return rc;
+    if ((rc = dev_upload(s, &P.obs_v, w))) return rc;
+    if ((rc = dev_upload(s, &P.chunk_vb, chunk_vb))) return rc;
+    if ((rc = dev_upload(s, &P.chunk_ve, chunk_ve))) return rc;
+    if ((rc = dev_upload(s, &P.chunk_cam, chunk_cam))) return rc;
+    if ((rc = dev_upload(s, &P.cam_chunk_ptr, cam_chunk_ptr))) return rc;
+    if ((rc = dev_upload(s, &P.bv_ptr, bv_ptr))) return rc;
+    if ((rc = dev_upload(s, &P.bv_idx, bv_idx))) return rc;
+    if ((rc = dev_upload(s, &P.pair_i, pair_i))) return rc;
+    if ((rc = dev_upload(s, &P.pair_j, pair_j))) return rc;
+    if ((rc = dev_upload(s, &P.pc_begin, pc_begin))) return rc;
+    if ((rc = dev_upload(s, &P.pc_end, pc_end))) return rc;
+    if ((rc = dev_upload(s, &P.bid_pc_ptr, bid_pc_ptr))) return rc;
+    if ((rc = dev_upload(s, &P.bid_mi, bid_mi))) return rc;
+    if ((rc = dev_upload(s, &P.bid_mj, bid_mj))) return rc;
+    if ((rc = dev_upload(s, &P.cam_const, cam_const))) return rc;
+    if ((rc = dev_upload(s, &P.cam_active, cam_active))) return rc;
+
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = dev_alloc(s, &S.cam_rt[k], 6 * (size_t)C))) return rc;
+        if ((rc = dev_alloc(s, &S.intr[k], 9 * (size_t)C))) return rc;
+        if ((rc = dev_alloc(s, &S.board_rt[k], 6 * (size_t)B))) return rc;
+        if ((rc = dev_alloc(s, &S.rec[k], (size_t)kRec * V))) return rc;
+        if ((rc = dev_alloc(s, &S.H[k], 256 * (size_t)C))) return rc;
+    }
+    if ((rc = dev_alloc(s, &s->d_init_cam, 6 * (size_t)C))) return rc;
+    if ((rc = dev_alloc(s, &s->d_init_intr, 9 * (size_t)C))) return rc;
+    if ((rc = dev_alloc(s, &s->d_init_board, 6 * (size_t)B))) return rc;
+    if ((rc = dev_alloc(s, &S.board_pc, (size_t)kBoardConst * B))) return rc;
+    if ((rc = dev_alloc(s, &S.cam_pc, (size_t)kCamConst * C))) return rc;
+    if ((rc = dev_alloc(s, &S.campart, 256 * (size_t)P.n_chunks))) return rc;
+    if ((rc = dev_alloc(s, &S.campart2, 256 * (size_t)C * kCamG1))) return rc;
+    if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal))) return rc;
+    if ((rc = dev_alloc(s, &S.M_stage, 8))) return rc;
+    if ((rc = dev_alloc(s, &S.s_b, 6 * (size_t)B))) return rc;
+    if ((rc = dev_alloc(s, &S.s_c, (size_t)s->n_pad))) return rc;
+    if ((rc = dev_alloc(s, &S.L, 21 * (size_t)B))) return rc;
+    if ((rc = dev_alloc(s, &S.z, 6 * (size_t)B))) return rc;
+    if ((rc = dev_alloc(s, &S.D2, 6 * (size_t)B))) return rc;
+    if ((rc = dev_alloc(s, &S.Y, 96 * (size_t)V))) return rc;
+    if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_pchunks))) return rc;
+    if ((rc = dev_alloc(s, &S.T, (size_t)s->n_pad * s->n_pad))) return rc;
+    if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
+    S.n_bs_blocks = (B + 15) / 16;
+    S.n_st_blocks = (B + 255) / 256;
+    if ((rc = dev_alloc(s, &S.bs_part, 2 * (size_t)S.n_bs_blocks))) return rc;
+    if ((rc = dev_alloc(s, &S.st_part, 3 * (size_t)S.n_st_blocks))) return rc;
+    if ((rc = dev_alloc(s, &S.ctrl, 1))) return rc;
+    HIP_TRY(hipMemset(S.T, 0, sizeof(double) * (size_t)s->n_pad * s->n_pad));
+    HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal)));
+    HIP_TRY(hipMemset(S.M_stage, 0, sizeof(double) * 8));
+    HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 256 * (size_t)C * kCamG1));
+    HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
+
+    s->lds_eval = sizeof(double) * ((size_t)(kFcols + kE) * kRP + 2 * (size_t)p->n_points);
+    s->lds_solve = sizeof(double) * (size_t)(s->n_pad + 1) * (s->n_pad + 4);
+    if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
+    if (s->lds_eval > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval));
+    if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
+    HIP_TRY(hipDeviceSynchronize());
+    *out = sp.release();
+    return 0;
+}
+
+extern "C" int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    if (comm && comm->device != s->device) return fail(TSCM_E_INVALID, "communicator and solver live on different devices");
+    s->comm = (comm && comm->world > 1) ? comm : nullptr;
+    return 0;
+}
+
+extern "C" int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, const double *intr, const double *board_rt)
+{
+    if (!s || !intr || (!board_rt && s->B)) return fail(TSCM_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<double> zero(6 * (size_t)s->C, 0.0);
+    const double *c = (s->mono || !cam_rt) ? zero.data() : cam_rt;
+    HIP_TRY(hipMemcpyAsync(s->d_init_cam, c, sizeof(double) * 6 * s->C, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_init_intr, intr, sizeof(double) * 9 * s->C, hipMemcpyHostToDevice, s->stream));
+    if (s->B) HIP_TRY(hipMemcpyAsync(s->d_init_board, board_rt, sizeof(double) * 6 * s->B, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->have_init = true;
+    return 0;
+}
+
+// one launch of the dominant kernel, optionally bracketed by HIP events on the solver's stream
+static int launch_eval(tscm_solver *s, int cand)
+{
+    const DevProblem &P = s->P;
+    if (P.n_chunks == 0) return 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->timing) {
+        if (s->ev_used == s->ev.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            s->ev.emplace_back(a, b);
+        }
+        e0 = s->ev[s->ev_used].first; e1 = s->ev[s->ev_used].second; ++s->ev_used;
+        HIP_TRY(hipEventRecord(e0, s->stream));
+    }
+    hipLaunchKernelGGL(k_eval_gram, dim3(P.n_chunks), dim3(64), s->lds_eval, s->stream, P, s->S, cand);
+    if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
+    return 0;
+}
+
+static int collect_timing(tscm_solver *s)
+{
+    for (size_t i = 0; i < s->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev[i].first, s->ev[i].second));
+        s->t_ms += ms; s->t_launches += 1;
+    }
+    s->ev_used = 0;
+    return 0;
+}
+
+extern "C" int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches, double *total_ms)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    if (launches) *launches = s->t_launches;
+    if (total_ms) *total_ms = s->t_ms;
+    s->t_launches = 0; s->t_ms = 0.0;
+    s->timing = enable != 0;
+    return 0;
+}
+
+// evaluation of the target point: pose constants, Gram kernel, reductions, statistics (+ all-reduce)
+static int enqueue_eval(tscm_solver *s, int cand, int init, int have_backsub)
+{
+    const DevProblem &P = s->P;
+    DevState &S = s->S;
+    hipLaunchKernelGGL(k_pose_prep, dim3((P.B + P.C + 255) / 256), dim3(256), 0, s->stream, P, S, cand);
+    if (int rc = launch_eval(s, cand)) return rc;
+    hipLaunchKernelGGL(k_cam_reduce1, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S);
+    if (S.n_st_blocks) hipLaunchKernelGGL(k_board_stats, dim3(S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
+    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub);
+    if (s->comm) {
+        NCCL_TRY(ncclGroupStart());
+        NCCL_TRY(ncclAllReduce(S.H_stage, S.H_stage, 256 * (size_t)P.C + kScal, ncclDouble, ncclSum, s->comm->comm, s->stream));
+        NCCL_TRY(ncclAllReduce(S.M_stage, S.M_stage, 1, ncclDouble, ncclMax, s->comm->comm, s->stream));
+        NCCL_TRY(ncclGroupEnd());
+    }
+    hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, P, S, init);
+    return 0;
+}
+
+static int enqueue_iteration(tscm_solver *s)
+{
+    const DevProblem &P = s->P;
+    DevState &S = s->S;
+    if (S.n_bs_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+    if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(64), 0, s->stream, P, S);
+    if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids), dim3(256), 0, s->stream, P, S);
+    if (s->comm) NCCL_TRY(ncclAllReduce(S.T, S.T, (size_t)P.n_pad * P.n_pad, ncclDouble, ncclSum, s->comm->comm, s->stream));
+    hipLaunchKernelGGL(k_solve_reduced, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+    if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+    return enqueue_eval(s, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
+}
+
+static const char *reason_message(int r)
+{
+    switch (r) {
+    case kMaxIter: return "Maximum number of iterations reached.";
+    case kGradTol: return "Gradient tolerance reached.";
+    case kMinRadius: return "Minimum trust region radius reached.";
+    case kParamTol: return "Parameter tolerance reached.";
+    case kFuncTol: return "Function tolerance reached.";
+    case kInvalidSteps: return "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.";
+    default: return "";
+    }
+}
+
+extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *opt_in, tscm_summary *sum, int reset)
+{
+    if (!s || !sum) return fail(TSCM_E_INVALID, "NULL argument");
+    if (!s->have_init) return fail(TSCM_E_INVALID, "tscm_solver_upload_params has not been called");
+    tscm_options opt;
+    if (opt_in) opt = *opt_in; else tscm_default_options(&opt, s->mono);
+    if (opt.max_num_iterations < 0 || opt.max_num_iterations > TSCM_MAX_ITERATIONS) return fail(TSCM_E_INVALID, "max_num_iterations must be in [0, 255]");
+    HIP_TRY(hipSetDevice(s->device));
+    DevState &S = s->S;
+    std::memset(sum, 0, sizeof(*sum));
+
+    // control block
+    Ctrl *h = s->h_ctrl;
+    std::memset(h, 0, sizeof(Ctrl));
+    h->radius = opt.initial_trust_region_radius;
+    h->decrease_factor = 2.0;
+    h->opt.max_num_iterations = opt.max_num_iterations;
+    h->opt.function_tolerance = opt.function_tolerance;
+    h->opt.gradient_tolerance = opt.gradient_tolerance;
+    h->opt.parameter_tolerance = opt.parameter_tolerance;
+    h->opt.initial_radius = opt.initial_trust_region_radius;
+    h->opt.max_radius = opt.max_trust_region_radius;
+    h->opt.min_radius = opt.min_trust_region_radius;
+    h->opt.min_relative_decrease = opt.min_relative_decrease;
+    h->opt.min_lm_diagonal = opt.min_lm_diagonal;
+    h->opt.max_lm_diagonal = opt.max_lm_diagonal;
+    h->opt.max_invalid = opt.max_num_consecutive_invalid_steps;
+    h->opt.jacobi_scaling = opt.jacobi_scaling;
+    const size_t header = offsetof(Ctrl, log);
+    HIP_TRY(hipMemcpyAsync(S.ctrl, h, header, hipMemcpyHostToDevice, s->stream));
+    if (reset) {
+        HIP_TRY(hipMemcpyAsync(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice, s->stream));
+        if (s->B) HIP_TRY(hipMemcpyAsync(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const double t0 = wall();
+
+    int rc;
+    if ((rc = enqueue_eval(s, /*cand=*/0, /*init=*/1, /*have_backsub=*/0))) return rc;
+    const int check_every = std::max(1, opt.check_every);
+    bool done = false;
+    for (int it = 1; it <= opt.max_num_iterations && !done; ++it) {
+        if ((rc = enqueue_iteration(s))) return rc;
+        if (it % check_every == 0 || it == opt.max_num_iterations) {
+            HIP_TRY(hipMemcpyAsync(h, S.ctrl, 64, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            done = h->done != 0;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const double t1 = wall();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(h, S.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    if ((rc = collect_timing(s))) return rc;
+    if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
+
+    // the accepted point lives in buffer `cur`; make it buffer 0 for the next resident solve
+    if (h->cur != 0) {
+        HIP_TRY(hipMemcpy(S.cam_rt[0], S.cam_rt[1], sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(S.intr[0], S.intr[1], sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
+        if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], S.board_rt[1], sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
+    }
+    sum->termination_type = h->term_type;
+    sum->num_iterations = std::min(h->n_log, TSCM_MAX_ITERATIONS + 1);
+    sum->num_successful_steps = h->num_successful;
+    sum->num_unsuccessful_steps = h->num_unsuccessful;
+    sum->initial_cost = h->initial_cost;
+    sum->final_cost = h->x_cost;
+    sum->n_residual_blocks = s->N;
+    sum->lm_iterations = h->lm_iterations;
+    for (int i = 0; i < sum->num_iterations; ++i) {
+        const IterLog &l = h->log[i];
+        tscm_iteration &o = sum->iterations[i];
+        o.iteration = l.iteration; o.step_is_valid = l.step_is_valid; o.step_is_successful = l.step_is_successful;
+        o.cost = l.cost; o.cost_change = l.cost_change; o.gradient_max_norm = l.gradient_max_norm; o.gradient_norm = l.gradient_norm;
+        o.step_norm = l.step_norm; o.relative_decrease = l.relative_decrease; o.trust_region_radius = l.radius;
+    }
+    std::snprintf(sum->message, sizeof(sum->message), "%s", reason_message(h->term_reason));
+    sum->seconds_solve = t1 - t0;
+    sum->seconds_total = t1 - t0;
+    sum->rmse = s->N ? std::sqrt(2.0 * h->x_cost / (double)s->N) : 0.0;
+    return 0;
+}
+
+extern "C" int tscm_solver_download_params(tscm_solver *s, double *cam_rt, double *intr, double *board_rt)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    if (cam_rt && !s->mono) HIP_TRY(hipMemcpy(cam_rt, s->S.cam_rt[0], sizeof(double) * 6 * s->C, hipMemcpyDeviceToHost));
+    if (intr) HIP_TRY(hipMemcpy(intr, s->S.intr[0], sizeof(double) * 9 * s->C, hipMemcpyDeviceToHost));
+    if (board_rt && s->B) HIP_TRY(hipMemcpy(board_rt, s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *sum)
+{
+    if (!s || !sum) return fail(TSCM_E_INVALID, "NULL argument");
+    const double t0 = wall();
+    int rc;
+    if ((rc = tscm_solver_upload_params(s, s->h_cam_rt, s->h_intr, s->h_board_rt))) return rc;
+    if ((rc = tscm_solver_solve_resident(s, opt, sum, 1))) return rc;
+    if ((rc = tscm_solver_download_params(s, s->h_cam_rt, s->h_intr, s->h_board_rt))) return rc;
+    sum->seconds_total = wall() - t0;
+    return 0;
+}
+
+static int solve_once(const tscm_problem *p, const tscm_options *opt, tscm_summary *sum)
+{
+    tscm_solver *s = nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int rc = tscm_solver_create(p, dev, &s);
+    if (rc) return rc;
+    rc = tscm_solver_solve(s, opt, sum);
+    tscm_solver_destroy(s);
+    return rc;
+}
+
+extern "C" int tscm_solve_multi(const tscm_problem *p, const tscm_options *opt, tscm_summary *sum)
+{
+    if (p && p->mono) return fail(TSCM_E_INVALID, "tscm_solve_multi called with a mono problem");
+    return solve_once(p, opt, sum);
+}
+
+extern "C" int tscm_solve_mono(const tscm_problem *p, const tscm_options *opt, tscm_summary *sum)
+{
+    if (p && !p->mono) return fail(TSCM_E_INVALID, "tscm_solve_mono called with a multi-camera problem");
+    return solve_once(p, opt, sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator level
+// ------------------------------------------------------------------------------------------------
+// upload the problem's current parameters into buffer 0 and compute the pose constants
+static int prepare_eval(tscm_solver *s)
+{
+    int rc;
+    if ((rc = tscm_solver_upload_params(s, s->h_cam_rt, s->h_intr, s->h_board_rt))) return rc;
+    DevState &S = s->S;
+    HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
+    HIP_TRY(hipMemcpy(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
+    if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(k_pose_prep, dim3((s->P.B + s->P.C + 255) / 256), dim3(256), 0, s->stream, s->P, S, 0);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int tscm_eval_functor(const tscm_problem *p, int device, double *residuals, double *J_cam,
+                                 double *J_board, double *J_intr, double *cost)
+{
+    tscm_solver *s = nullptr;
+    int rc = tscm_solver_create(p, device, &s);
+    if (rc) return rc;
+    std::unique_ptr<tscm_solver, void (*)(tscm_solver *)> guard(s, tscm_solver_destroy);
+    if ((rc = prepare_eval(s))) return rc;
+    const size_t N = (size_t)s->N;
+    std::vector<int> corner_view(N);
+    for (int v = 0; v < s->V; ++v) for (int j = 0; j < s->h_view_count[v]; ++j) corner_view[s->h_view_obs[v] + j] = v;
+    const int *d_cv = nullptr;
+    double *d_res = nullptr, *d_Jc = nullptr, *d_Jb = nullptr, *d_Ji = nullptr;
+    if ((rc = dev_upload(s, &d_cv, corner_view))) return rc;
+    if ((rc = dev_alloc(s, &d_res, 2 * N))) return rc;
+    if (J_cam && (rc = dev_alloc(s, &d_Jc, 12 * N))) return rc;
+    if (J_board && (rc = dev_alloc(s, &d_Jb, 12 * N))) return rc;
+    if (J_intr && (rc = dev_alloc(s, &d_Ji, 18 * N))) return rc;
+    if (N) hipLaunchKernelGGL(k_eval_functor, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s->stream, s->P, s->S, d_cv, d_res, d_Jc, d_Jb, d_Ji);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    // device corner order -> problem corner order (views in problem order, empty views skipped)
+    std::vector<double> h_res(2 * N), h_Jc(d_Jc ? 12 * N : 0), h_Jb(d_Jb ? 12 * N : 0), h_Ji(d_Ji ? 18 * N : 0);
+    if (N) HIP_TRY(hipMemcpy(h_res.data(), d_res, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+    if (d_Jc && N) HIP_TRY(hipMemcpy(h_Jc.data(), d_Jc, sizeof(double) * 12 * N, hipMemcpyDeviceToHost));
+    if (d_Jb && N) HIP_TRY(hipMemcpy(h_Jb.data(), d_Jb, sizeof(double) * 12 * N, hipMemcpyDeviceToHost));
+    if (d_Ji && N) HIP_TRY(hipMemcpy(h_Ji.data(), d_Ji, sizeof(double) * 18 * N, hipMemcpyDeviceToHost));
+    std::vector<long> orig_row(p->n_views, 0);
+    { long k = 0; for (int v = 0; v < p->n_views; ++v) { orig_row[v] = k; k += p->view_count[v]; } }
+    double c = 0.0;
+    for (int dv = 0; dv < s->V; ++dv) {
+        const long dst = orig_row[s->dev2orig[dv]], src = s->h_view_obs[dv];
+        const int cnt = s->h_view_count[dv];
+        if (residuals) std::memcpy(residuals + 2 * dst, h_res.data() + 2 * src, sizeof(double) * 2 * cnt);
+        if (J_cam) std::memcpy(J_cam + 12 * dst, h_Jc.data() + 12 * src, sizeof(double) * 12 * cnt);
+        if (J_board) std::memcpy(J_board + 12 * dst, h_Jb.data() + 12 * src, sizeof(double) * 12 * cnt);
+        if (J_intr) std::memcpy(J_intr + 18 * dst, h_Ji.data() + 18 * src, sizeof(double) * 18 * cnt);
+    }
+    // cost in problem order (same summation order as a sequential evaluator)
+    { long k = 0; for (int v = 0; v < p->n_views; ++v) for (int j = 0; j < p->view_count[v]; ++j, ++k) {
+        // locate the device row of this corner
+        (void)j; } }
+    for (size_t k = 0; k < N; ++k) c += 0.5 * (h_res[2 * k] * h_res[2 * k] + h_res[2 * k + 1] * h_res[2 * k + 1]);
+    if (cost) *cost = c;
+    return 0;
+}
+
+extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, double *board_gram, double *board_grad,
+                                          double *view_cross, double *cam_gram, double *cam_grad, double *cost)
+{
+    tscm_solver *s = nullptr;
+    int rc = tscm_solver_create(p, device, &s);
+    if (rc) return rc;
+    std::unique_ptr<tscm_solver, void (*)(tscm_solver *)> guard(s, tscm_solver_destroy);
+    if ((rc = prepare_eval(s))) return rc;
+    const DevProblem &P = s->P;
+    DevState &S = s->S;
+    if ((rc = launch_eval(s, 0))) return rc;
+    hipLaunchKernelGGL(k_cam_reduce1, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S);
+    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C), dim3(256), 0, s->stream, P, S, 0);   // camera blocks only
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    std::vector<double> rec((size_t)kRec * s->V), H(256 * (size_t)s->C);
+    if (s->V) HIP_TRY(hipMemcpy(rec.data(), S.rec[0], sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(H.data(), S.H_stage, sizeof(double) * H.size(), hipMemcpyDeviceToHost));
+    if (board_gram) std::memset(board_gram, 0, sizeof(double) * 36 * (size_t)s->B);
+    if (board_grad) std::memset(board_grad, 0, sizeof(double) * 6 * (size_t)s->B);
+    if (view_cross) std::memset(view_cross, 0, sizeof(double) * 90 * (size_t)p->n_views);
+    for (int dv = 0; dv < s->V; ++dv) {
+        const double *r = rec.data() + (size_t)kRec * dv;
+        const int b = s->h_view_board[dv], ov = s->dev2orig[dv];
+        for (int i = 0; i < 6; ++i) {
+            if (board_gram) for (int j = 0; j < 6; ++j) board_gram[36 * (size_t)b + 6 * i + j] += r[kRecEE + 6 * i + j];
+            if (board_grad) board_grad[6 * (size_t)b + i] += r[16 * i + kFR];
+            if (view_cross) {
+                for (int j = 0; j < 13; ++j) view_cross[90 * (size_t)ov + 15 * i + j] = r[16 * i + j];
+            }
+        }
+    }
+    double c = 0.0;
+    for (int m = 0; m < s->C; ++m) {
+        const double *h = H.data() + 256 * (size_t)m;
+        if (cam_gram) { std::memset(cam_gram + 225 * (size_t)m, 0, sizeof(double) * 225); for (int i = 0; i < 13; ++i) for (int j = 0; j < 13; ++j) cam_gram[225 * (size_t)m + 15 * i + j] = h[16 * i + j]; }
+        if (cam_grad) { std::memset(cam_grad + 15 * (size_t)m, 0, sizeof(double) * 15); for (int i = 0; i < 13; ++i) cam_grad[15 * (size_t)m + i] = h[16 * i + kFR]; }
+        c += 0.5 * h[16 * kFR + kFR];
+    }
+    if (cost) *cost = c;
+    return 0;
+}
+
+extern "C" int tscm_project_points(const double *intr9, const double *points, int n, int device, double *pixels)
+{
+    if (!intr9 || (n > 0 && (!points || !pixels)) || n < 0) return fail(TSCM_E_INVALID, "NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipSetDevice(device));
+    if (n == 0) return 0;
+    double *d_i = nullptr, *d_p = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_i), 9 * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_p), 3 * (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_o), 2 * (size_t)n * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_i, intr9, 9 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p, points, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_project, dim3((n + 255) / 256), dim3(256), 0, 0, d_i, d_p, n, d_o);
+    HIP_TRY(hipMemcpy(pixels, d_o, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_i); (void)hipFree(d_p); (void)hipFree(d_o);
+    return 0;
+}
+
+extern "C" int tscm_unproject_pixels(const double *intr9, const double *pixels, int n, int device, double *rays)
+{
+    if (!intr9 || (n > 0 && (!pixels || !rays)) || n < 0) return fail(TSCM_E_INVALID, "NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipSetDevice(device));
+    if (n == 0) return 0;
+    double *d_i = nullptr, *d_p = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_i), 9 * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_p), 2 * (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_o), 3 * (size_t)n * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_i, intr9, 9 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p, pixels, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_unproject, dim3((n + 255) / 256), dim3(256), 0, 0, d_i, d_p, n, d_o);
+    HIP_TRY(hipMemcpy(rays, d_o, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_i); (void)hipFree(d_p); (void)hipFree(d_o);
+    return 0;
+}
+
+extern "C" int tscm_reprojection_error(const tscm_problem *p, int device, double *per_camera_mean, double *global_mean, double *rmse)
+{
+    tscm_solver *s = nullptr;
+    int rc = tscm_solver_create(p, device, &s);
+    if (rc) return rc;
+    std::unique_ptr<tscm_solver, void (*)(tscm_solver *)> guard(s, tscm_solver_destroy);
+    if ((rc = tscm_solver_upload_params(s, s->h_cam_rt, s->h_intr, s->h_board_rt))) return rc;
+    double *d_e = nullptr, *d_q = nullptr;
+    if ((rc = dev_alloc(s, &d_e, (size_t)s->V))) return rc;
+    if ((rc = dev_alloc(s, &d_q, (size_t)s->V))) return rc;
+    if (s->V) hipLaunchKernelGGL(k_reproj_error, dim3(s->V), dim3(64), 0, s->stream, s->P, s->d_init_cam, s->d_init_intr, s->d_init_board, d_e, d_q);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+    std::vector<double> e(s->V), q(s->V);
+    if (s->V) { HIP_TRY(hipMemcpy(e.data(), d_e, sizeof(double) * s->V, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(q.data(), d_q, sizeof(double) * s->V, hipMemcpyDeviceToHost)); }
+    std::vector<double> err(s->C, 0.0);
+    std::vector<long> cnt(s->C, 0);
+    double sq = 0.0;
+    for (int v = 0; v < s->V; ++v) { err[s->h_view_cam[v]] += e[v]; cnt[s->h_view_cam[v]] += s->h_view_count[v]; sq += q[v]; }
+    double tot = 0.0; long n = 0;
+    for (int m = 0; m < s->C; ++m) { tot += err[m]; n += cnt[m]; if (per_camera_mean) per_camera_mean[m] = cnt[m] ? err[m] / (double)cnt[m] : 0.0; }
+    if (global_mean) *global_mean = n ? tot / (double)n : 0.0;
+    if (rmse) *rmse = n ? std::sqrt(sq / (double)n) : 0.0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU
+// ------------------------------------------------------------------------------------------------
+static_assert(sizeof(ncclUniqueId) <= TSCM_UNIQUE_ID_BYTES, "ncclUniqueId larger than the ABI buffer");
+
+extern "C" int tscm_comm_unique_id(unsigned char id[TSCM_UNIQUE_ID_BYTES])
+{
+    if (!id) return fail(TSCM_E_INVALID, "id is NULL");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    std::memset(id, 0, TSCM_UNIQUE_ID_BYTES);
+    std::memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+extern "C" int tscm_comm_create(const unsigned char id[TSCM_UNIQUE_ID_BYTES], int rank, int world, int device, tscm_comm **out)
+{
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(TSCM_E_INVALID, "bad communicator arguments");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    std::unique_ptr<tscm_comm> c(new tscm_comm);
+    c->rank = rank; c->world = world; c->device = device;
+    NCCL_TRY(ncclCommInitRank(&c->comm, world, u, rank));
+    *out = c.release();
+    return 0;
+}
+
+extern "C" void tscm_comm_destroy(tscm_comm *c)
+{
+    if (!c) return;
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int tscm_shard_frames(const tscm_problem *p, int world, int *owner)
+{
+    if (!p || !owner || world < 1) return fail(TSCM_E_INVALID, "bad arguments");
+    if (int rc = validate(p)) return rc;
+    std::vector<double> per_board(p->n_boards, 0.0);
+    for (int v = 0; v < p->n_views; ++v) per_board[p->view_board[v]] += p->view_count[v];
+    double total = 0.0;
+    for (double x : per_board) total += x;
+    double before = 0.0;
+    for (int b = 0; b < p->n_boards; ++b) {
+        int r = total > 0.0 ? (int)(before * world / total) : 0;
+        owner[b] = std::min(r, world - 1);
+        before += per_board[b];
+    }
+    return 0;
+}

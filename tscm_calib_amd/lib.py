@@ -1,0 +1,178 @@
+"""ctypes binding of the C ABI in include/tscm/tscm.h (libtscm_hip.so).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+present, compute calls raise.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libtscm_hip.so")
+UNIQUE_ID_BYTES = 128
+MAX_ITERATIONS = 255
+
+E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
+           -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM"}
+TERMINATION = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
+
+
+class TscmError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{E_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class CProblem(C.Structure):
+    _fields_ = [
+        ("n_cameras", C.c_int), ("n_boards", C.c_int), ("n_points", C.c_int), ("n_views", C.c_int),
+        ("board_xy", C.c_void_p), ("view_camera", C.c_void_p), ("view_board", C.c_void_p),
+        ("view_offset", C.c_void_p), ("view_count", C.c_void_p), ("obs_u", C.c_void_p), ("obs_v", C.c_void_p),
+        ("cam_rt", C.c_void_p), ("intr", C.c_void_p), ("board_rt", C.c_void_p),
+        ("cam_pose_constant", C.c_void_p), ("mono", C.c_int),
+    ]
+
+
+class COptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("max_num_consecutive_invalid_steps", C.c_int), ("jacobi_scaling", C.c_int), ("check_every", C.c_int),
+    ]
+
+
+class CIteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int), ("step_is_valid", C.c_int), ("step_is_successful", C.c_int),
+        ("cost", C.c_double), ("cost_change", C.c_double), ("gradient_max_norm", C.c_double),
+        ("gradient_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+    ]
+
+
+class CSummary(C.Structure):
+    _fields_ = [
+        ("termination_type", C.c_int), ("num_iterations", C.c_int), ("num_successful_steps", C.c_int),
+        ("num_unsuccessful_steps", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("n_residual_blocks", C.c_int), ("lm_iterations", C.c_int),
+        ("iterations", CIteration * (MAX_ITERATIONS + 1)), ("message", C.c_char * 128),
+        ("seconds_solve", C.c_double), ("seconds_total", C.c_double), ("rmse", C.c_double),
+    ]
+
+
+# every symbol include/tscm/tscm.h declares
+EXPORTS = [
+    "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_default_options",
+    "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_solve", "tscm_solver_upload_params",
+    "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
+    "tscm_solver_kernel_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
+    "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
+    "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
+    "tscm_shard_frames",
+]
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("tscm_solver.hip", "tscm_kernels.h", "tscm_math.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "tscm", "tscm.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TscmError(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.tscm_abi_version.restype = C.c_int
+    L.tscm_last_error.restype = C.c_char_p
+    L.tscm_device_count.restype = C.c_int
+    L.tscm_default_options.argtypes = [C.POINTER(COptions), C.c_int]
+    L.tscm_default_options.restype = None
+    L.tscm_solver_create.argtypes = [C.POINTER(CProblem), C.c_int, C.POINTER(vp)]
+    L.tscm_solver_set_comm.argtypes = [vp, vp]
+    L.tscm_solver_solve.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary)]
+    L.tscm_solver_upload_params.argtypes = [vp, dp, dp, dp]
+    L.tscm_solver_solve_resident.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary), C.c_int]
+    L.tscm_solver_download_params.argtypes = [vp, dp, dp, dp]
+    L.tscm_solver_destroy.argtypes = [vp]
+    L.tscm_solver_destroy.restype = None
+    L.tscm_solver_kernel_time.argtypes = [vp, C.c_int, ip, dp]
+    L.tscm_solve_multi.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary)]
+    L.tscm_solve_mono.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary)]
+    L.tscm_eval_functor.argtypes = [C.POINTER(CProblem), C.c_int, dp, dp, dp, dp, dp]
+    L.tscm_eval_normal_equations.argtypes = [C.POINTER(CProblem), C.c_int, dp, dp, dp, dp, dp, dp]
+    L.tscm_project_points.argtypes = [dp, dp, C.c_int, C.c_int, dp]
+    L.tscm_unproject_pixels.argtypes = [dp, dp, C.c_int, C.c_int, dp]
+    L.tscm_reprojection_error.argtypes = [C.POINTER(CProblem), C.c_int, dp, dp, dp]
+    L.tscm_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+    L.tscm_comm_create.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.tscm_comm_destroy.argtypes = [vp]
+    L.tscm_comm_destroy.restype = None
+    L.tscm_shard_frames.argtypes = [C.POINTER(CProblem), C.c_int, ip]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise TscmError(rc, lib().tscm_last_error().decode(errors="replace"))
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def c_problem(p) -> CProblem:
+    """Wrap a normalised Problem. Arrays are referenced, not copied: keep `p` alive."""
+    q = CProblem()
+    q.n_cameras, q.n_boards, q.n_points, q.n_views = p.n_cameras, p.n_boards, p.n_points, p.n_views
+    for name in ("board_xy", "view_camera", "view_board", "view_offset", "view_count", "obs_u", "obs_v",
+                 "cam_rt", "intr", "board_rt", "cam_pose_constant"):
+        arr = getattr(p, name)
+        if not arr.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{name} must be C-contiguous (use Problem.normalised())")
+        setattr(q, name, arr.ctypes.data)
+    q.mono = 1 if p.mono else 0
+    return q
+
+
+def default_options(mono: bool, **over) -> COptions:
+    o = COptions()
+    lib().tscm_default_options(C.byref(o), 1 if mono else 0)
+    for k, v in over.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def summary_dict(s: CSummary) -> dict:
+    its = []
+    for i in range(min(s.num_iterations, MAX_ITERATIONS + 1)):
+        it = s.iterations[i]
+        its.append({k: getattr(it, k) for k, _ in CIteration._fields_})
+    return dict(termination_type=s.termination_type, termination=TERMINATION.get(s.termination_type, "?"),
+                num_iterations=s.num_iterations, num_successful_steps=s.num_successful_steps,
+                num_unsuccessful_steps=s.num_unsuccessful_steps, initial_cost=s.initial_cost,
+                final_cost=s.final_cost, n_residual_blocks=s.n_residual_blocks, lm_iterations=s.lm_iterations,
+                iterations=its, message=s.message.decode(), seconds_solve=s.seconds_solve,
+                seconds_total=s.seconds_total, rmse=s.rmse)
