@@ -6,6 +6,7 @@
 //   rec[2][V][132]   per-view Schur pieces written by the Gram kernel:
 //                      [0..95]   E^T [F | r]   6 x 16  (cols 0-12 = W, col 13 = E^T r)
 //                      [96..131] E^T E         6 x 6
+//                      [132..143] compact copy of E^T r and diag(E^T E) for the per-board statistics
 //                    double buffered: index ctrl->cur = system at x, cur^1 = candidate.
 //   H_stage          per camera a 16x16 tile [F | r]^T [F | r]  (13x13 Gram, col 13 =
 //                    F^T r, [13][13] = r^T r) + 8 scalars; fixed address so that RCCL can
@@ -20,15 +21,51 @@
 
 namespace tscm {
 
-constexpr int kRec = 132;          // doubles per view record
+constexpr int kRec = 144;          // doubles per view record
+constexpr int kRecG = 132;         // offset of the compact copy: E^T r (6), diag(E^T E) (6)
 constexpr int kRecEE = 96;         // offset of E^T E inside a record
-constexpr int kRP = 130;           // LDS row pitch (doubles) of the column-major Jacobian tile:
-                                   // 2*kRP = 260 = 4 (mod 64) dwords -> conflict-free ds_read_b64
-constexpr int kFcols = 14;         // Jacobian columns staged for F (13 params + residual)
+constexpr int kTcols = 15;         // columns of the single MFMA Gram tile (see k_eval_gram)
+constexpr int kVConst = 27;        // per-view constants: r1, r2, t_b, R_c dR_b/dw_k [:,0:2]
+constexpr int kCConst = 48;        // per-camera constants: R_c, t_c, dR_c/dw_k, fx fy cx cy xi lambda beta 1/(1-alpha)^2
+constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
 constexpr int kCamG1 = 16;         // first-level fan-in of the per-camera tile reduction
 constexpr int kMaxCam = 8;         // n_pad = 16*C <= 128 (reduced system kept in LDS)
 constexpr int kMaxLog = 256;
+
+// LDS hand-off inside ONE wave (64-thread workgroups): DS operations of a wave are serviced in
+// issue order, so no s_barrier / vmcnt(0) drain is needed -- only the compiler must keep the
+// program order of the LDS accesses.  (__syncthreads() would also drain the global prefetches.)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 1/sqrt(x) and 1/x to full fp64 accuracy from the hardware seeds (v_rsq_f64 / v_rcp_f64) plus
+// Newton steps: ~3x fewer instructions than the IEEE sqrt + divide expansions.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+    r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+// sqrt(x) with one correction step, and its reciprocal
+__device__ __forceinline__ void sqrt_and_inverse(double x, double &s, double &is)
+{
+    is = fast_rsqrt(x);
+    s = x * is;
+    s = __builtin_fma(0.5 * is, __builtin_fma(-s, s, x), s);
+}
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -66,6 +103,7 @@ struct Ctrl {
 struct DevProblem {
     int C, B, n_points, V, N, n_pad;
     int n_chunks, n_pairs, n_pchunks, n_bids;
+    int rp, half;                      // LDS pitch (doubles) and v-row offset of the Jacobian tile
     const double *board_xy;
     const int *view_cam, *view_board, *view_obs, *view_count;
     const double *obs_u, *obs_v;
@@ -74,11 +112,13 @@ struct DevProblem {
     const int *pair_i, *pair_j;
     const int *pc_begin, *pc_end, *bid_pc_ptr, *bid_mi, *bid_mj;
     const unsigned char *cam_const, *cam_active;
+    const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
 };
 
 struct DevState {
     double *cam_rt[2], *intr[2], *board_rt[2];
     double *board_pc, *cam_pc;
+    double *vconst, *cconst;
     double *rec[2];
     double *campart, *campart2;
     double *H[2], *H_stage, *M_stage;
@@ -128,84 +168,252 @@ __device__ __forceinline__ void load_view_const(const DevProblem &P, const DevSt
 }
 
 // ---------------------------------------------------------------------------------------------
-// THE HOT KERNEL: per-corner TSCM projection + analytic 2x19 Jacobian + residual, then the
-// Gram contractions  [F|r]^T[F|r] (per camera),  E^T[F|r] and E^T E (per view)  on the f64
-// matrix cores (v_mfma_f64_16x16x4_f64).
-//   one wave (= one 64-thread workgroup) per chunk of consecutive views of ONE camera;
-//   lane = corner: coalesced SoA loads of u[], v[]; board points staged in LDS;
-//   the 2 x 20 Jacobian rows of 64 corners are transposed through LDS (column-major,
-//   conflict-free pitch) into MFMA operand layout: lane (c, k) feeds J[row 4t+k][col c];
-//   the 16x16 camera tile stays in the accumulator across all views of the chunk.
-// dynamic LDS: (14 + 6) * kRP + 2 * n_points doubles.
+// per-view / per-camera constants of the evaluation target in the form the hot kernel consumes.
+// grid ceil((V + C)/256) x 256.
+//   vconst[k][view]: r1(3) r2(3) t_b(3), then for k=0..2: R_c dR_b/dw_k[:,0] (3), R_c dR_b/dw_k[:,1] (3)
+//   cconst[cam] : R_c(9) t_c(3) dR_c/dw_k (27) fx fy cx cy xi lambda beta=alpha/(1-alpha) 1/(1-alpha)^2
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_eval_gram(DevProblem P, DevState S, int cand)
+__global__ void k_view_prep(DevProblem P, DevState S, int cand)
+{
+    if (S.ctrl->done) return;
+    const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.V) {
+        // self-contained (rotations recomputed per view: cheaper than a second launch + round trip);
+        // stored SoA ([k][view]) so that the 27 stores of a wave are coalesced
+        const int b = P.view_board[i], m = P.view_cam[i];
+        double rt[6], bc[kBoardConst], Rc[9], dRc[27];
+        for (int k = 0; k < 6; ++k) rt[k] = S.board_rt[tgt][6 * b + k];
+        board_constants(rt, bc);
+        double crt[3];
+        for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
+        rotation_and_derivatives(crt, Rc, dRc);
+        double *o = S.vconst + i;
+        const size_t st = (size_t)P.V;
+        for (int k = 0; k < 6; ++k) o[k * st] = bc[k];
+        for (int k = 0; k < 3; ++k) o[(6 + k) * st] = rt[3 + k];
+        for (int k = 0; k < 6; ++k) {           // six 3-vectors d -> R_c d
+            const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
+            for (int r = 0; r < 3; ++r) o[(9 + 3 * k + r) * st] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
+        }
+    } else if (i < P.V + P.C) {
+        const int m = i - P.V;
+        double crt[3], Rc[9], dRc[27];
+        for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
+        rotation_and_derivatives(crt, Rc, dRc);
+        double *o = S.cconst + kCConst * m;
+        for (int k = 0; k < 9; ++k) o[k] = Rc[k];
+        for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
+        for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
+        const double *I = S.intr[tgt] + 9 * m;
+        for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
+        const double oma = 1.0 - I[6];
+        o[45] = I[6] / oma;
+        o[46] = 1.0 / (oma * oma);
+        o[47] = 0.0;
+    }
+}
+
+// tile column -> (parity mask) bookkeeping shared by the hot kernel's epilogue and k_finalize_eval.
+// Tile columns: 0-2 w_b | 3-5 w_c | 6-8 t_c | 9 f* | 10 one* | 11 xi | 12 lambda | 13 alpha | 14 r.
+//   f*   = -X/k on u-rows, -Y/k on v-rows : fx is its u-half, fy its v-half
+//   one* = -1 on every row                 : cx is its u-half, cy its v-half
+// so with separate Gram tiles for the u-rows (GU) and the v-rows (GV) the true products are
+//   <a, b> = sum over parities in mask(a) & mask(b) of G_par[tile(a)][tile(b)].
+// F index (record / H layout): 0-2 w_c, 3-5 t_c, 6 fx, 7 fy, 8 cx, 9 cy, 10 xi, 11 lambda, 12 alpha, 13 r.
+__device__ __forceinline__ int f_tile(int f) { return f < 6 ? f + 3 : (f < 10 ? 9 + ((f - 6) >> 1) : f + 1); }
+__device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 << ((f - 6) & 1)) : 3; }
+
+// ---------------------------------------------------------------------------------------------
+// THE HOT KERNEL: per-corner TSCM projection + analytic Jacobian + residual, then ALL Gram
+// products of the 2 x 20 Jacobian block [E | F | r] from ONE 16x16 f64 MFMA tile per 4 rows:
+//   * t_b columns are constant combinations of the t_c columns (J_tb = J_tc R_c): dropped from
+//     the tile, recovered per view by a 3x3 multiply in the epilogue;
+//   * (fx, fy) and (cx, cy) have disjoint row support: merged into f* and one*, separated again
+//     by keeping the u-rows and the v-rows of the Jacobian in two accumulators.
+//   -> 15 tile columns, v_mfma_f64_16x16x4_f64 count per view = 2*ceil(n/4) (28 for 54 corners)
+//      instead of 3*ceil(2n/4) = 81 for the naive [E|F|r] padding.
+// One wave (= one 64-thread workgroup) per chunk of consecutive views of ONE camera;
+// lane = corner (coalesced SoA loads of u[], v[]), board points and all wave-uniform constants in
+// LDS, Jacobian columns transposed through LDS (column-major, pitch 130: conflict-free
+// ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
+// dynamic LDS: kTcols*rp + kCst + 2*n_points doubles.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
 {
     if (S.ctrl->done) return;
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Fl = lds;
-    double *El = lds + kFcols * kRP;
-    double *bxy = El + kE * kRP;
+    const int RP = P.rp, HV = P.half;          // pitch = 2*odd >= 2*HV: conflict-free ds_read_b64
+    double *Fl = lds;                          // [kTcols][RP]: rows 0..HV-1 u, HV..2HV-1 v
+    double *TU = Fl;                           // [16][16] staged u tile  } epilogue scratch, aliases the
+    double *TV = TU + 256;                     // [16][16] staged v tile  } Jacobian tile (dead after the
+    double *MU = TV + 256;                     // [6][16]                 } MFMA loop of the view)
+    double *MV = MU + 96;                      // [6][16]
+    double *cst = Fl + max(kTcols * RP, 704);  // [kCst]  (704 = epilogue scratch, for tiny boards)
+    double *bxy = cst + kCst;
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x;
-    for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
     const int cam = P.chunk_cam[chunk];
+    for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
+    if (lane < kCConst) cst[kVConst + lane] = S.cconst[kCConst * cam + lane];
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
-    d4 accFF = { 0.0, 0.0, 0.0, 0.0 };
-    __syncthreads();
+    d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
+    const double *cc = cst + kVConst;          // camera constants
+    // software prefetch: the next view's constants and first 64 observations are loaded while
+    // the current view computes (one wave per SIMD-slot cannot hide HBM latency otherwise)
+    double pf_c = 0.0, pf_u = 0.0, pf_v = 0.0;
+    if (vb < ve) {
+        if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + vb];
+        if (lane < P.view_count[vb]) { pf_u = P.obs_u[P.view_obs[vb] + lane]; pf_v = P.obs_v[P.view_obs[vb] + lane]; }
+    }
     for (int view = vb; view < ve; ++view) {
-        const int board = P.view_board[view];
         const int cnt = P.view_count[view];
         const int off = P.view_obs[view];
-        ViewConst vc;
-        load_view_const(P, S, tgt, cam, board, vc);
-        d4 accEF = { 0.0, 0.0, 0.0, 0.0 };
-        d4 accEE = { 0.0, 0.0, 0.0, 0.0 };
+        wave_lds_fence();                       // previous view's epilogue has finished with LDS
+        if (lane < kVConst) cst[lane] = pf_c;
+        const double ou0 = pf_u, ov0 = pf_v;
+        if (view + 1 < ve) {
+            if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + view + 1];
+            if (lane < P.view_count[view + 1]) { pf_u = P.obs_u[P.view_obs[view + 1] + lane]; pf_v = P.obs_v[P.view_obs[view + 1] + lane]; }
+        }
+        wave_lds_fence();
+        d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             const bool valid = j < cnt;
-            double r[2] = { 0.0, 0.0 }, JE[2][kE], JF[2][kFA];
-            if (valid) {
-                corner_residual_jacobian(vc, bxy[2 * j], bxy[2 * j + 1], P.obs_u[off + j], P.obs_v[off + j], r, JE, JF);
-            } else {
-                for (int c = 0; c < kE; ++c) { JE[0][c] = 0.0; JE[1][c] = 0.0; }
-                for (int c = 0; c < kFA; ++c) { JF[0][c] = 0.0; JF[1][c] = 0.0; }
+            double *fu = Fl + lane, *fv = Fl + HV + lane;
+            if (valid && !(ablate & 4)) {
+                const double x = bxy[2 * j], y = bxy[2 * j + 1];
+                const double ou = c0 ? P.obs_u[off + j] : ou0, ov = c0 ? P.obs_v[off + j] : ov0;
+                // board -> world -> camera (multi_calib.h:158-167)
+                const double Pw0 = x * cst[0] + y * cst[3] + cst[6];
+                const double Pw1 = x * cst[1] + y * cst[4] + cst[7];
+                const double Pw2 = x * cst[2] + y * cst[5] + cst[8];
+                const double X = cc[0] * Pw0 + cc[1] * Pw1 + cc[2] * Pw2 + cc[9];
+                const double Y = cc[3] * Pw0 + cc[4] * Pw1 + cc[5] * Pw2 + cc[10];
+                const double Z = cc[6] * Pw0 + cc[7] * Pw1 + cc[8] * Pw2 + cc[11];
+                const double fx = cc[39], fy = cc[40], xi = cc[43], lam = cc[44], beta = cc[45];
+                // triple sphere (multi_calib.h:170-178)
+                const double rho2 = X * X + Y * Y;
+                double d1, id1, d2, id2, d3, id3;
+                sqrt_and_inverse(rho2 + Z * Z, d1, id1);
+                const double z1 = Z + xi * d1;
+                sqrt_and_inverse(rho2 + z1 * z1, d2, id2);
+                const double z2 = z1 + lam * d2;
+                sqrt_and_inverse(rho2 + z2 * z2, d3, id3);
+                const double k = z2 + beta * d3;
+                const double ik = fast_rcp(k);
+                const double mx = X * ik, my = Y * ik;
+                const double c1 = 1.0 + xi * Z * id1;
+                const double c2 = 1.0 + lam * z1 * id2;
+                const double c3 = 1.0 + beta * z2 * id3;
+                const double q = beta * id3 + c3 * (lam * id2 + c2 * xi * id1);
+                const double kz = c1 * c2 * c3;
+                const double fxk = fx * ik, fyk = fy * ik;
+                // -A = -d(u,v)/dPc  (the t_c columns)
+                const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
+                const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
+                fu[6 * RP] = n00; fv[6 * RP] = n10;
+                fu[7 * RP] = n01; fv[7 * RP] = n11;
+                fu[8 * RP] = n02; fv[8 * RP] = n12;
+                // w_b: -A (x e_k0 + y e_k1)
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double h0 = x * cst[9 + 6 * kk] + y * cst[12 + 6 * kk];
+                    const double h1 = x * cst[10 + 6 * kk] + y * cst[13 + 6 * kk];
+                    const double h2 = x * cst[11 + 6 * kk] + y * cst[14 + 6 * kk];
+                    fu[kk * RP] = n00 * h0 + n01 * h1 + n02 * h2;
+                    fv[kk * RP] = n10 * h0 + n11 * h1 + n12 * h2;
+                }
+                // w_c: -A (dR_c/dw_k Pw)
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double *D = cc + 12 + 9 * kk;
+                    const double g0 = D[0] * Pw0 + D[1] * Pw1 + D[2] * Pw2;
+                    const double g1 = D[3] * Pw0 + D[4] * Pw1 + D[5] * Pw2;
+                    const double g2 = D[6] * Pw0 + D[7] * Pw1 + D[8] * Pw2;
+                    fu[(3 + kk) * RP] = n00 * g0 + n01 * g1 + n02 * g2;
+                    fv[(3 + kk) * RP] = n10 * g0 + n11 * g1 + n12 * g2;
+                }
+                // f* and one*
+                fu[9 * RP] = -mx;   fv[9 * RP] = -my;
+                fu[10 * RP] = -1.0; fv[10 * RP] = -1.0;
+                // xi, lambda, alpha: -du/dk * dk/dparam
+                const double hu = fxk * mx, hv = fyk * my;
+                const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * cc[46];
+                fu[11 * RP] = hu * kxi;  fv[11 * RP] = hv * kxi;
+                fu[12 * RP] = hu * klam; fv[12 * RP] = hv * klam;
+                fu[13 * RP] = hu * kal;  fv[13 * RP] = hv * kal;
+                // residual = observed - projected (multi_calib.h:192-193)
+                fu[14 * RP] = ou - (fx * mx + cc[41]);
+                fv[14 * RP] = ov - (fy * my + cc[42]);
+            } else if (lane < HV) {
+#pragma unroll
+                for (int c = 0; c < kTcols; ++c) { fu[c * RP] = 0.0; fv[c * RP] = 0.0; }
             }
-#pragma unroll
-            for (int c = 0; c < kFA; ++c) *reinterpret_cast<d2 *>(Fl + c * kRP + 2 * lane) = d2{ JF[0][c], JF[1][c] };
-            *reinterpret_cast<d2 *>(Fl + kFR * kRP + 2 * lane) = d2{ r[0], r[1] };
-#pragma unroll
-            for (int c = 0; c < kE; ++c) *reinterpret_cast<d2 *>(El + c * kRP + 2 * lane) = d2{ JE[0][c], JE[1][c] };
-            __syncthreads();
+            wave_lds_fence();
             const int nv = min(64, cnt - c0);
-            const int ksteps = (2 * nv + 3) >> 2;
-            const double *fp = Fl + (col < kFcols ? col : 0) * kRP + kq;
-            const double *ep = El + (col < kE ? col : 0) * kRP + kq;
-            for (int t = 0; t < ksteps; ++t) {
-                const double af = col < kFcols ? fp[4 * t] : 0.0;
-                const double ae = col < kE ? ep[4 * t] : 0.0;
-                accFF = __builtin_amdgcn_mfma_f64_16x16x4f64(af, af, accFF, 0, 0, 0);
-                accEF = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, af, accEF, 0, 0, 0);
-                accEE = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ae, accEE, 0, 0, 0);
+            const int ksteps = (nv + 3) >> 2;
+            // rows past the last corner are zero (every lane wrote its rows), so the loop may run in
+            // pairs of k-steps; operands of the next pair are fetched while the current MFMAs issue
+            const double *fp = Fl + (col < kTcols ? col : 0) * RP + kq;
+            const bool live = col < kTcols;
+            double au0 = live ? fp[0] : 0.0, au1 = live ? fp[4] : 0.0;
+            double av0 = live ? fp[HV] : 0.0, av1 = live ? fp[HV + 4] : 0.0;
+            for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
+                const int tn = min(t + 2, (HV >> 2) - 2);   // stay inside the HV-row half
+                const double nu0 = live ? fp[4 * tn] : 0.0, nu1 = live ? fp[4 * tn + 4] : 0.0;
+                const double nv0 = live ? fp[HV + 4 * tn] : 0.0, nv1 = live ? fp[HV + 4 * tn + 4] : 0.0;
+                accU = __builtin_amdgcn_mfma_f64_16x16x4f64(au0, au0, accU, 0, 0, 0);
+                accV = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, av0, accV, 0, 0, 0);
+                accU = __builtin_amdgcn_mfma_f64_16x16x4f64(au1, au1, accU, 0, 0, 0);
+                accV = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, av1, accV, 0, 0, 0);
+                au0 = nu0; au1 = nu1; av0 = nv0; av1 = nv1;
             }
-            __syncthreads();
+            wave_lds_fence();
         }
-        // D[row = kq + 4*reg][col]: rows 0..5 of E^T[F|r] and E^T E
+        camU += accU; camV += accV;
+        if (ablate & 2) continue;
+        // ---- epilogue: tile -> record  (E rows: w_b directly, t_b = R_c^T t_c rows) -------------
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) { TU[(kq + 4 * rg) * 16 + col] = accU[rg]; TV[(kq + 4 * rg) * 16 + col] = accV[rg]; }
+        wave_lds_fence();
+        for (int idx = lane; idx < 192; idx += 64) {
+            const int par = idx >= 96, e = (idx % 96) >> 4, c = idx & 15;
+            const double *T = par ? TV : TU;
+            double v;
+            if (e < 3) v = T[e * 16 + c];
+            else { const int l = e - 3; v = cc[l] * T[6 * 16 + c] + cc[3 + l] * T[7 * 16 + c] + cc[6 + l] * T[8 * 16 + c]; }
+            (par ? MV : MU)[e * 16 + c] = v;
+        }
+        wave_lds_fence();
         double *rec = S.rec[tgt] + (size_t)kRec * view;
-        rec[kq * 16 + col] = accEF[0];
-        if (kq < 2) rec[(kq + 4) * 16 + col] = accEF[1];
-        if (col < kE) {
-            rec[kRecEE + kq * 6 + col] = accEE[0];
-            if (kq < 2) rec[kRecEE + (kq + 4) * 6 + col] = accEE[1];
+        for (int idx = lane; idx < kRec; idx += 64) {
+            double v;
+            if (idx < kRecEE) {
+                const int e = idx >> 4, f = idx & 15;
+                if (f >= 14) v = 0.0;
+                else { const int t = f_tile(f), m = f_mask(f); v = ((m & 1) ? MU[e * 16 + t] : 0.0) + ((m & 2) ? MV[e * 16 + t] : 0.0); }
+            } else if (idx >= kRecG && idx < kRecG + 6) {
+                const int e = idx - kRecG;
+                v = MU[e * 16 + 14] + MV[e * 16 + 14];
+            } else {
+                const int k = idx < kRecG ? idx - kRecEE : (idx - kRecG - 6) * 7;     // diagonal entry for the compact copy
+                const int e = k / 6, jj = k % 6;
+                if (jj < 3) v = MU[e * 16 + jj] + MV[e * 16 + jj];
+                else { const int l = jj - 3; v = cc[l] * (MU[e * 16 + 6] + MV[e * 16 + 6]) + cc[3 + l] * (MU[e * 16 + 7] + MV[e * 16 + 7]) + cc[6 + l] * (MU[e * 16 + 8] + MV[e * 16 + 8]); }
+            }
+            rec[idx] = v;
         }
     }
-    double *part = S.campart + (size_t)256 * chunk;
+    double *part = S.campart + (size_t)512 * chunk;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) part[(kq + 4 * rg) * 16 + col] = accFF[rg];
+    for (int rg = 0; rg < 4; ++rg) { part[(kq + 4 * rg) * 16 + col] = camU[rg]; part[256 + (kq + 4 * rg) * 16 + col] = camV[rg]; }
 }
 
-// per-camera tile reduction, level 1: grid (C * kCamG1) x 256
+// per-camera raw tile (GU | GV) reduction, level 1: grid (C * kCamG1) x 256
 __global__ void k_cam_reduce1(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
@@ -215,16 +423,19 @@ __global__ void k_cam_reduce1(DevProblem P, DevState S)
     const int per = (n + kCamG1 - 1) / kCamG1;
     const int b = cb + g * per, e = min(ce, b + per);
     const int t = threadIdx.x;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int c = b;
-    for (; c + 3 < e; c += 4) {
-        a0 += S.campart[(size_t)256 * c + t];
-        a1 += S.campart[(size_t)256 * (c + 1) + t];
-        a2 += S.campart[(size_t)256 * (c + 2) + t];
-        a3 += S.campart[(size_t)256 * (c + 3) + t];
+    for (int half = 0; half < 2; ++half) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double *src = S.campart + 256 * half + t;
+        int c = b;
+        for (; c + 3 < e; c += 4) {
+            a0 += src[(size_t)512 * c];
+            a1 += src[(size_t)512 * (c + 1)];
+            a2 += src[(size_t)512 * (c + 2)];
+            a3 += src[(size_t)512 * (c + 3)];
+        }
+        for (; c < e; ++c) a0 += src[(size_t)512 * c];
+        S.campart2[(size_t)512 * blockIdx.x + 256 * half + t] = (a0 + a1) + (a2 + a3);
     }
-    for (; c < e; ++c) a0 += S.campart[(size_t)256 * c + t];
-    S.campart2[(size_t)256 * blockIdx.x + t] = (a0 + a1) + (a2 + a3);
 }
 
 // deterministic block reductions (256 threads)
@@ -264,7 +475,7 @@ __global__ void k_board_stats(DevProblem P, DevState S, int cand, int init)
             double g[6] = { 0, 0, 0, 0, 0, 0 }, dg[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
                 const double *rec = S.rec[tgt] + (size_t)kRec * P.bv_idx[q];
-                for (int i = 0; i < 6; ++i) { g[i] += rec[i * 16 + kFR]; dg[i] += rec[kRecEE + i * 7]; }
+                for (int i = 0; i < 6; ++i) { g[i] += rec[kRecG + i]; dg[i] += rec[kRecG + 6 + i]; }
             }
             for (int i = 0; i < 6; ++i) {
                 const double x = S.board_rt[tgt][6 * b + i];
@@ -282,7 +493,7 @@ __global__ void k_board_stats(DevProblem P, DevState S, int cand, int init)
     if (threadIdx.x == 0) { S.st_part[3 * blockIdx.x] = m; S.st_part[3 * blockIdx.x + 1] = s1; S.st_part[3 * blockIdx.x + 2] = s2; }
 }
 
-// level-2 camera reduction into H_stage + reduction of the per-block scalar partials.
+// level-2 camera reduction (raw u/v tiles -> [F|r]^T[F|r]) into H_stage + reduction of the per-block scalar partials.
 // grid (C + 1) x 256.  H_stage scal: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b ; M_stage[0] gmax_b
 __global__ void k_finalize_eval(DevProblem P, DevState S, int have_backsub)
 {
@@ -290,10 +501,23 @@ __global__ void k_finalize_eval(DevProblem P, DevState S, int have_backsub)
     __shared__ double sm[256];
     const int t = threadIdx.x;
     if ((int)blockIdx.x < P.C) {
+        __shared__ double G[512];
         const int cam = blockIdx.x;
-        double a = 0.0;
-        for (int g = 0; g < kCamG1; ++g) a += S.campart2[(size_t)256 * (cam * kCamG1 + g) + t];
-        S.H_stage[256 * cam + t] = a;
+        for (int half = 0; half < 2; ++half) {
+            double a = 0.0;
+            for (int g = 0; g < kCamG1; ++g) a += S.campart2[(size_t)512 * (cam * kCamG1 + g) + 256 * half + t];
+            G[256 * half + t] = a;
+        }
+        __syncthreads();
+        // raw (GU | GV) tile -> H layout: 14x14 [F | r]^T [F | r] in a 16x16 slot
+        const int a = t >> 4, b = t & 15;
+        double v = 0.0;
+        if (a < 14 && b < 14) {
+            const int ta = f_tile(a), tb = f_tile(b), m = f_mask(a) & f_mask(b);
+            if (m & 1) v += G[ta * 16 + tb];
+            if (m & 2) v += G[256 + ta * 16 + tb];
+        }
+        S.H_stage[256 * cam + t] = v;
         return;
     }
     double mb = 0.0, ss = 0.0;
@@ -360,7 +584,7 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
             for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += rec[kRecEE + i * 6 + j];
-            g[i] += rec[i * 16 + kFR];
+            g[i] += rec[kRecG + i];
         }
     }
     double D2[6];
@@ -398,159 +622,286 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
 }
 
 // Schur complement contributions  T(mi, mj) += Y'_i^T Y'_j  over pairs of views of one board.
-// Pairs are pre-sorted by camera-pair block; one wave per chunk of pairs of a single block keeps
-// its 16x16 tile in registers (4 entries per lane).  grid n_pchunks x 64
-__global__ __launch_bounds__(64) void k_pair_gram(DevProblem P, DevState S)
+// Pairs are pre-sorted by camera-pair block; one 4-wave workgroup per chunk of pairs of a single
+// block, each wave keeps a 16x16 tile in registers (4 entries per lane, two pairs in flight),
+// the four tiles are summed in a fixed order through LDS.   grid n_pchunks x 256
+__global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
+    __shared__ double red[4][256];
     const int pc = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane & 15, bg = lane >> 4;
-    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-    for (int p = P.pc_begin[pc]; p < P.pc_end[pc]; ++p) {
-        const double *Yi = S.Y + (size_t)96 * P.pair_i[p];
-        const double *Yj = S.Y + (size_t)96 * P.pair_j[p];
+    const int pb = P.pc_begin[pc], pe = P.pc_end[pc];
+    const int q = (pe - pb + 3) >> 2;
+    const int wb = pb + wave * q, we = min(pe, wb + q);
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 }, bcc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (int p = wb; p < we; p += 2) {
+        const bool two = p + 1 < we;
+        const double *Yi0 = S.Y + (size_t)96 * P.pair_i[p];
+        const double *Yj0 = S.Y + (size_t)96 * P.pair_j[p];
+        const double *Yi1 = S.Y + (size_t)96 * P.pair_i[two ? p + 1 : p];
+        const double *Yj1 = S.Y + (size_t)96 * P.pair_j[two ? p + 1 : p];
+        double ya0[6], ya1[6];
+        d4 yb0[6], yb1[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const double ya = Yi[k * 16 + a];
-            const d4 yb = *reinterpret_cast<const d4 *>(Yj + k * 16 + 4 * bg);
-            acc[0] += ya * yb[0]; acc[1] += ya * yb[1]; acc[2] += ya * yb[2]; acc[3] += ya * yb[3];
+            ya0[k] = Yi0[k * 16 + a]; yb0[k] = *reinterpret_cast<const d4 *>(Yj0 + k * 16 + 4 * bg);
+            ya1[k] = Yi1[k * 16 + a]; yb1[k] = *reinterpret_cast<const d4 *>(Yj1 + k * 16 + 4 * bg);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            acc[0] += ya0[k] * yb0[k][0]; acc[1] += ya0[k] * yb0[k][1]; acc[2] += ya0[k] * yb0[k][2]; acc[3] += ya0[k] * yb0[k][3];
+        }
+        if (two) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                bcc[0] += ya1[k] * yb1[k][0]; bcc[1] += ya1[k] * yb1[k][1]; bcc[2] += ya1[k] * yb1[k][2]; bcc[3] += ya1[k] * yb1[k][3];
+            }
         }
     }
-    double *out = S.pairpart + (size_t)256 * pc + a * 16 + 4 * bg;
-    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = acc[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][a * 16 + 4 * bg + e] = acc[e] + bcc[e];
+    __syncthreads();
+    const int t = threadIdx.x;
+    S.pairpart[(size_t)256 * pc + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-// grid n_bids x 256: sum the pair-chunk tiles of one camera-pair block into T
-__global__ void k_T_reduce(DevProblem P, DevState S)
+// grid (n_bids * 4) x 256: block (bid, quarter) sums 64 tile entries over the pair-chunk tiles of
+// one camera-pair block, the chunk list split four ways across the threads of an entry
+__global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
-    const int bid = blockIdx.x, t = threadIdx.x;
+    __shared__ double red[4][64];
+    const int bid = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    const int e = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int entry = quarter * 64 + e;
+    const int cb = P.bid_pc_ptr[bid], ce = P.bid_pc_ptr[bid + 1];
+    const int per = (ce - cb + 3) >> 2;
+    const int b0 = cb + slice * per, b1 = min(ce, b0 + per);
     double a0 = 0.0, a1 = 0.0;
-    int c = P.bid_pc_ptr[bid];
-    const int e = P.bid_pc_ptr[bid + 1];
-    for (; c + 1 < e; c += 2) { a0 += S.pairpart[(size_t)256 * c + t]; a1 += S.pairpart[(size_t)256 * (c + 1) + t]; }
-    if (c < e) a0 += S.pairpart[(size_t)256 * c + t];
-    const int mi = P.bid_mi[bid], mj = P.bid_mj[bid];
-    S.T[(size_t)(mi * 16 + (t >> 4)) * P.n_pad + mj * 16 + (t & 15)] = a0 + a1;
+    int c = b0;
+    for (; c + 1 < b1; c += 2) { a0 += S.pairpart[(size_t)256 * c + entry]; a1 += S.pairpart[(size_t)256 * (c + 1) + entry]; }
+    if (c < b1) a0 += S.pairpart[(size_t)256 * c + entry];
+    red[slice][e] = a0 + a1;
+    __syncthreads();
+    if (slice == 0) {
+        const int mi = P.bid_mi[bid], mj = P.bid_mj[bid];
+        S.T[(size_t)(mi * 16 + (entry >> 4)) * P.n_pad + mj * 16 + (entry & 15)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Reduced camera system (DenseSchurComplementSolver): one workgroup, matrix in LDS.
-//   A = S_c (H_cc - T) S_c + D_c^2, rhs = S_c (g_c - t_r); inactive columns (padding, constant
-//   camera pose, cameras without views) are replaced by identity rows.  Left-looking Cholesky
-//   on the matrix augmented with the rhs row (forward substitution for free), then a
-//   single-wave back-substitution.  Writes yhat = S_c y (the camera step is -yhat) and the
-//   candidate camera parameters.   grid 1 x 256, dynamic LDS (n+1)*(n+4) doubles
+// Reduced camera system (DenseSchurComplementSolver): one 256-thread workgroup.
+//   A = S_c (H_cc - T) S_c + D_c^2, rhs = S_c (g_c - t_r); inactive columns (tile padding,
+//   constant camera pose, cameras without views) become identity rows.
+// Blocked right-looking Cholesky with the matrix held in REGISTERS: thread (ti, tj) owns the
+// TS x TS tile (TS = N/16).  Per panel: (1) the diagonal thread factors its tile and forward-
+// substitutes its slice of the rhs, (2) the threads below it solve their tile against L_kk^T,
+// (3) everybody applies the rank-TS update -- two barriers per panel, 32 in total.
+// Back-substitution: one wave, w in registers, rows of L streamed from LDS.  Writes
+// yhat = S_c y (camera step = -yhat) and the candidate camera parameters.
+// grid 1 x 256, dynamic LDS N*(N+1) + N*TS + TS*TS + 4*N doubles.
 // ---------------------------------------------------------------------------------------------
+template <int TS>
 __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
+    constexpr int N = 16 * TS;
+    constexpr int LD = N + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Lm = lds;                 // [N][LD] lower factor (for the back-substitution)
+    double *Xb = Lm + N * LD;         // [N][TS] panel column  L[:, panel]
+    double *Ld = Xb + N * TS;         // [TS][TS] factor of the diagonal tile
+    double *wp = Ld + TS * TS;        // [N] forward-substituted rhs  w = L^{-1} b
+    double *yv = wp + N;              // [N]
+    double *s_sc = yv + N;            // [N]
+    double *s_yh = s_sc + N;          // [N]
     __shared__ int s_fail;
+    __shared__ unsigned char s_act[N];
     __shared__ double sred[256];
-    const int n = P.n_pad, ld = n + 4;
-    double *A = lds;                 // (n+1) rows x ld
+    const int n = P.n_pad;            // <= N
     const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     const double *H = S.H[cur];
     if (tid == 0) s_fail = S.ctrl->lin_fail;
-    auto active = [&](int i) -> bool {
-        const int m = i >> 4, a = i & 15;
-        return a < kFA && P.cam_active[m] && !(a < 6 && P.cam_const[m]);
-    };
-    for (int idx = tid; idx < (n + 1) * n; idx += 256) {
-        const int i = idx / n, j = idx % n;
-        double v;
-        if (i < n) {
-            if (j > i) continue;                 // lower triangle only
-            const bool ai = active(i), aj = active(j);
-            if (ai && aj) {
-                const int mi = i >> 4, a = i & 15, mj = j >> 4, b = j & 15;
-                const double h = (mi == mj) ? H[256 * mi + a * 16 + b] : 0.0;
-                // T holds upper blocks (mj <= mi here -> block (mj, mi), transposed)
-                const double tt = (mi == mj) ? S.T[(size_t)i * n + j] : S.T[(size_t)j * n + i];
-                v = S.s_c[i] * S.s_c[j] * (h - tt);
-                if (i == j) v += fmin(fmax(S.s_c[i] * S.s_c[i] * h, dmin), dmax) / radius;
-            } else {
-                v = (i == j) ? 1.0 : 0.0;
-            }
-        } else {
-            // rhs row
-            if (active(j)) { const int mj = j >> 4, b = j & 15; v = S.s_c[j] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)j * n + mj * 16 + kFR]); }
-            else v = 0.0;
-        }
-        A[i * ld + j] = v;
-    }
+    for (int i = tid; i < N; i += 256) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; }
     __syncthreads();
-    // left-looking Cholesky, 4 threads per row, rows in passes of 64
-    const int seg = tid & 3, r0 = tid >> 2;
-    for (int j = 0; j < n; ++j) {
-        double sj = 0.0;
-        for (int k = seg; k < j; k += 4) sj += A[j * ld + k] * A[j * ld + k];
-        sj += __shfl_xor(sj, 1, 4); sj += __shfl_xor(sj, 2, 4);
-        double pj = A[j * ld + j] - sj;
-        if (!(pj > 0.0)) { if (tid == 0) s_fail = 1; pj = 1.0; }
-        const double invp = 1.0 / sqrt(pj);
-        for (int r = r0; r <= n; r += 64) {
-            if (r <= j) continue;
-            double s = 0.0;
-            for (int k = seg; k < j; k += 4) s += A[r * ld + k] * A[j * ld + k];
-            s += __shfl_xor(s, 1, 4); s += __shfl_xor(s, 2, 4);
-            if (seg == 0) A[r * ld + j] = (A[r * ld + j] - s) * invp;
+    // ---- build my tile (lower tiles only); the diagonal thread also owns its slice of the rhs ----
+    double a[TS][TS], bd[TS];
+    if (tj <= ti) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r) {
+#pragma unroll
+            for (int c = 0; c < TS; ++c) {
+                const int i = ti * TS + r, j = tj * TS + c;
+                double v = (i == j) ? 1.0 : 0.0;
+                if (s_act[i] && s_act[j]) {
+                    const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
+                    const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
+                    // T holds the upper camera-pair blocks; (i, j) with mi > mj is block (mj, mi) transposed
+                    const double t = (mi > mj) ? S.T[(size_t)j * n + i] : S.T[(size_t)i * n + j];
+                    v = s_sc[i] * s_sc[j] * (h - t);
+                    if (i == j) v += fmin(fmax(s_sc[i] * s_sc[i] * h, dmin), dmax) / radius;
+                }
+                a[r][c] = v;
+            }
+        }
+    }
+    if (ti == tj) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r) {
+            const int i = ti * TS + r;
+            bd[r] = 0.0;
+            if (s_act[i]) { const int mj = i >> 4, b = i & 15; bd[r] = s_sc[i] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)i * n + mj * 16 + kFR]); }
+        }
+    }
+    // ---- factorisation ------------------------------------------------------------------------
+    for (int tk = 0; tk < 16; ++tk) {
+        if (ti == tk && tj == tk) {
+            // (1) Cholesky of the diagonal tile + forward substitution of its rhs slice
+            double il[TS];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) {
+                double d = a[c][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) d -= a[c][q] * a[c][q];
+                if (!(d > 0.0)) { s_fail = 1; d = 1.0; }
+                double sd, isd;
+                sqrt_and_inverse(d, sd, isd);
+                a[c][c] = sd; il[c] = isd;
+#pragma unroll
+                for (int r = c + 1; r < TS; ++r) {
+                    double v = a[r][c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) v -= a[r][q] * a[c][q];
+                    a[r][c] = v * isd;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < TS; ++c) {
+                double w = bd[c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) w -= a[c][q] * bd[q];
+                bd[c] = w * il[c];
+                wp[tk * TS + c] = bd[c];
+            }
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c) Ld[r * TS + c] = (c < r) ? a[r][c] : (c == r ? il[r] : 0.0);   // diag slot holds 1/L_rr
         }
         __syncthreads();
-        if (tid == 0) A[j * ld + j] = pj * invp;
-        // (diagonal is only read again in the back-substitution; the barrier of the next
-        //  column orders this store before that)
-    }
-    __syncthreads();
-    // back-substitution L^T y = w (w = row n), single wave, lane i owns y[i], y[i+64]
-    double *yv = A + (size_t)n * ld;     // w in place
-    if (tid < 64) {
-        for (int k = n - 1; k >= 0; --k) {
-            const double yk = yv[k] / A[k * ld + k];
-            __builtin_amdgcn_wave_barrier();
-            if (tid == 0) yv[k] = yk;
-            for (int i = tid; i < k; i += 64) yv[i] -= A[k * ld + i] * yk;
-            __builtin_amdgcn_wave_barrier();
+        if (tj == tk && ti > tk) {
+            // (2) X = A_tile L_kk^{-T}
+#pragma unroll
+            for (int r = 0; r < TS; ++r) {
+#pragma unroll
+                for (int c = 0; c < TS; ++c) {
+                    double v = a[r][c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) v -= a[r][q] * Ld[c * TS + q];
+                    a[r][c] = v * Ld[c * TS + c];
+                    Xb[(ti * TS + r) * TS + c] = a[r][c];
+                }
+            }
         }
+        __syncthreads();
+        if (ti > tk && tj > tk && tj <= ti) {
+            // (3) trailing update  A_ij -= X_i X_j^T ;  rhs slice  b_i -= X_i w_k
+            double xi[TS][TS], xj[TS][TS];
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int q = 0; q < TS; ++q) { xi[r][q] = Xb[(ti * TS + r) * TS + q]; xj[r][q] = Xb[(tj * TS + r) * TS + q]; }
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c) {
+                    double v = a[r][c];
+#pragma unroll
+                    for (int q = 0; q < TS; ++q) v -= xi[r][q] * xj[c][q];
+                    a[r][c] = v;
+                }
+            if (ti == tj) {
+#pragma unroll
+                for (int r = 0; r < TS; ++r) {
+                    double v = bd[r];
+#pragma unroll
+                    for (int q = 0; q < TS; ++q) v -= xi[r][q] * wp[tk * TS + q];
+                    bd[r] = v;
+                }
+            }
+        }
+        // no barrier needed here: the next panel's diagonal thread only touches its own registers
+        // before the next barrier, and Xb / Ld / wp are rewritten only after it.
+    }
+    // ---- publish L, back-substitute L^T y = w with one wave -----------------------------------------
+    if (tj <= ti) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int c = 0; c < TS; ++c) Lm[(ti * TS + r) * LD + tj * TS + c] = a[r][c];
     }
     __syncthreads();
-    // yhat, candidate camera parameters, camera part of the model cost change / step norm
+    if (tid < 64) {
+        constexpr int R = N / 64;
+        double w[R], idg[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { w[q] = wp[tid + 64 * q]; idg[q] = 1.0 / Lm[(tid + 64 * q) * LD + tid + 64 * q]; }
+        for (int k = N - 1; k >= 0; --k) {
+            const int q = k >> 6, src = k & 63;
+            double wk = 0.0, ik = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) if (qq == q) { wk = w[qq]; ik = idg[qq]; }
+            const double yk = __shfl(wk * ik, src);
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) {
+                const int i = tid + 64 * qq;
+                if (i < k) w[qq] -= Lm[k * LD + i] * yk;
+                else if (i == k) w[qq] = yk;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) yv[tid + 64 * q] = w[q];
+    }
+    __syncthreads();
+    // ---- yhat, candidate camera parameters, camera part of model cost change / step norm --------
     double model = 0.0, stepsq = 0.0;
     const int fail = s_fail;
     for (int i = tid; i < n; i += 256) {
-        const int m = i >> 4, a = i & 15;
-        const bool act = active(i) && !fail;
-        const double yh = act ? S.s_c[i] * yv[i] : 0.0;
+        const int m = i >> 4, ai = i & 15;
+        const bool act = s_act[i] && !fail;
+        const double yh = act ? s_sc[i] * yv[i] : 0.0;
         S.yhat[i] = yh;
-        if (a < 6) {
-            const double x = S.cam_rt[cur][6 * m + a];
+        s_yh[i] = yh;
+        if (ai < 6) {
+            const double x = S.cam_rt[cur][6 * m + ai];
             const double xn = x + (-yh);
-            S.cam_rt[cur ^ 1][6 * m + a] = xn;
+            S.cam_rt[cur ^ 1][6 * m + ai] = xn;
             const double d = x - xn; stepsq += d * d;
-        } else if (a < kFA) {
-            const double x = S.intr[cur][9 * m + (a - 6)];
+        } else if (ai < kFA) {
+            const double x = S.intr[cur][9 * m + (ai - 6)];
             const double xn = x + (-yh);
-            S.intr[cur ^ 1][9 * m + (a - 6)] = xn;
+            S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
             const double d = x - xn; stepsq += d * d;
-        } else if (a < 15) {
-            S.intr[cur ^ 1][9 * m + (a - 6)] = S.intr[cur][9 * m + (a - 6)];   // b, c are inert
+        } else if (ai < 15) {
+            S.intr[cur ^ 1][9 * m + (ai - 6)] = S.intr[cur][9 * m + (ai - 6)];   // b, c are inert
         }
     }
     __syncthreads();
     // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
     for (int i = tid; i < n; i += 256) {
-        const int m = i >> 4, a = i & 15;
-        if (a >= kFA) continue;
-        const double yi = S.yhat[i];
+        const int m = i >> 4, ai = i & 15;
+        if (ai >= kFA) continue;
+        const double yi = s_yh[i];
         if (yi == 0.0) continue;
         double hy = 0.0;
-        for (int b = 0; b < kFA; ++b) hy += H[256 * m + a * 16 + b] * S.yhat[m * 16 + b];
-        model += yi * (H[256 * m + a * 16 + kFR] - 0.5 * hy);
+        for (int b = 0; b < kFA; ++b) hy += H[256 * m + ai * 16 + b] * s_yh[m * 16 + b];
+        model += yi * (H[256 * m + ai * 16 + kFR] - 0.5 * hy);
     }
     model = block_sum256(model, sred);
     stepsq = block_sum256(stepsq, sred);
@@ -626,38 +977,40 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
 // one thread.  `init` = IterationZero; otherwise the tail of one loop iteration followed by
 // FinalizeIterationAndCheckIfMinimizerCanContinue.
 // ---------------------------------------------------------------------------------------------
-__device__ void camera_norms(const DevProblem &P, const DevState &S, int idx, const double *H,
-                             double &gmax, double &gsq, double &xsq)
-{
-    gmax = 0.0; gsq = 0.0; xsq = 0.0;
-    for (int m = 0; m < P.C; ++m) {
-        if (!P.cam_active[m]) continue;
-        for (int a = 0; a < 15; ++a) {
-            if (a < 6 && P.cam_const[m]) continue;
-            const double x = a < 6 ? S.cam_rt[idx][6 * m + a] : S.intr[idx][9 * m + (a - 6)];
-            const double g = a < kFA ? H[256 * m + a * 16 + kFR] : 0.0;   // b, c: zero gradient
-            const double d = x - (x + (-g));
-            gmax = fmax(gmax, fabs(d)); gsq += d * d; xsq += x * x;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int init)
 {
     Ctrl &c = *S.ctrl;
     if (c.done) return;
+    __shared__ double sm[256];
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
+    const int t = threadIdx.x;
     // publish the staged (all-reduced) camera tiles as the target system's H
-    for (int i = threadIdx.x; i < 256 * P.C; i += 256) S.H[tgt][i] = S.H_stage[i];
-    if (threadIdx.x != 0) return;
+    for (int i = t; i < 256 * P.C; i += 256) S.H[tgt][i] = S.H_stage[i];
     const double *H = S.H_stage;
     const double *sc = S.H_stage + 256 * P.C;
-    double cost = 0.0;
-    for (int m = 0; m < P.C; ++m) cost += H[256 * m + kFR * 16 + kFR];
-    cost *= 0.5;
-    double gmax_c, gsq_c, xsq_c;
-    camera_norms(P, S, tgt, H, gmax_c, gsq_c, xsq_c);
+    // camera-side norms |x - Plus(x, -g)|_inf, its 2-norm, |x|^2 and the cost, one thread per parameter
+    double gmax_c = 0.0, gsq_c = 0.0, xsq_c = 0.0, cost = 0.0;
+    if (t < 16 * P.C) {
+        const int m = t >> 4, a = t & 15;
+        if (a < 15 && P.cam_active[m] && !(a < 6 && P.cam_const[m])) {
+            const double x = a < 6 ? S.cam_rt[tgt][6 * m + a] : S.intr[tgt][9 * m + (a - 6)];
+            const double g = a < kFA ? H[256 * m + a * 16 + kFR] : 0.0;   // b, c: zero gradient
+            const double d = x - (x + (-g));
+            gmax_c = fabs(d); gsq_c = d * d; xsq_c = x * x;
+        }
+        if (a == 15) cost = 0.5 * H[256 * m + kFR * 16 + kFR];
+        if (init && a < 15) {
+            const double hii = (a < kFA) ? H[256 * m + a * 16 + a] : 0.0;
+            S.s_c[t] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
+        }
+        if (init && a == 15) S.s_c[t] = 1.0;
+    }
+    gmax_c = block_max256(gmax_c, sm);
+    gsq_c = block_sum256(gsq_c, sm);
+    xsq_c = block_sum256(xsq_c, sm);
+    cost = block_sum256(cost, sm);
+    if (t != 0) return;
     const double gmax_t = fmax(gmax_c, S.M_stage[0]);
     const double gnorm_t = sqrt(gsq_c + sc[3]);
     const double xnorm_t = sqrt(xsq_c + sc[2]);
@@ -665,11 +1018,6 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
     IterLog it;
     it.pad = 0;
     if (init) {
-        for (int i = 0; i < P.n_pad; ++i) {
-            const int m = i >> 4, a = i & 15;
-            const double hii = (a < kFA) ? H[256 * m + a * 16 + a] : 0.0;
-            S.s_c[i] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
-        }
         c.x_cost = cost; c.initial_cost = cost; c.x_norm = xnorm_t; c.gmax = gmax_t; c.gnorm = gnorm_t;
         c.se_min = c.se_cur = c.se_ref = c.se_cand = cost; c.se_acc_ref = 0.0; c.se_acc_cand = 0.0;
         it.iteration = 0; it.step_is_valid = 1; it.step_is_successful = 1;

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -67,6 +68,7 @@ struct tscm_solver {
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
     size_t lds_eval = 0, lds_solve = 0;
+    int ablate = 0;                     // TSCM_ABLATE: profiling aid (skips parts of k_eval_gram; results invalid)
     // dominant-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -165,6 +167,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     std::unique_ptr<tscm_solver, void (*)(tscm_solver *)> sp(new tscm_solver, tscm_solver_destroy);
     tscm_solver *s = sp.get();
     s->device = device;
+    if (const char *ab = std::getenv("TSCM_ABLATE")) s->ablate = std::atoi(ab);
     s->C = p->n_cameras; s->B = p->n_boards; s->n_points = p->n_points; s->mono = p->mono != 0;
     s->n_pad = 16 * s->C;
     s->h_cam_rt = p->cam_rt; s->h_intr = p->intr; s->h_board_rt = p->board_rt;
@@ -204,7 +207,14 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     for (int i = 0; i < V; ++i) cam_active[view_cam[i]] = 1;
 
     // ---- chunks of views (one wave each), never straddling a camera ----------------------------
-    const int target_chunks = 2048;
+    // one round of resident waves: LDS admits floor(160 KiB / lds_eval) single-wave workgroups per CU
+    // Jacobian tile geometry: HV rows per parity (multiple of 4 covering min(64, n) corners), pitch 2*HV + 2
+    // (= 2 * odd: the 16 columns x 2 rows of a 32-lane ds_read_b64 group then hit 32 distinct bank pairs)
+    const int half_rows = 4 * ((std::min(64, p->n_points) + 3) / 4);
+    const int rp = 2 * half_rows + 2;
+    const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)kTcols * rp, 704) + kCst + 2 * (size_t)p->n_points);
+    const int waves_per_cu = std::max(1, std::min(16, (int)((160 * 1024) / lds_eval_bytes)));
+    const int target_chunks = 256 * waves_per_cu - 4 * C;
     const int per_chunk = std::max(1, (V + target_chunks - 1) / target_chunks);
     std::vector<int> chunk_vb, chunk_ve, chunk_cam, cam_chunk_ptr(C + 1, 0);
     {
@@ -240,7 +250,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     const int n_bids = (int)bid_mi.size();
     size_t n_pairs = 0;
     for (auto &v : pairs_by_bid) n_pairs += v.size();
-    const int target_pchunks = 1024;
+    const int target_pchunks = 768;
     const int per_pchunk = std::max<int>(1, (int)((n_pairs + target_pchunks - 1) / target_pchunks));
     std::vector<int> pair_i, pair_j, pc_begin, pc_end, bid_pc_ptr(n_bids + 1, 0);
     for (int bid = 0; bid < n_bids; ++bid) {
@@ -256,6 +266,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     DevProblem &P = s->P;
     DevState &S = s->S;
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
+    P.rp = rp; P.half = half_rows;
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
     std::vector<double> bxy(p->board_xy, p->board_xy + 2 * (size_t)p->n_points);
     int rc;
@@ -281,6 +292,11 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_upload(s, &P.bid_mj, bid_mj))) return rc;
     if ((rc = dev_upload(s, &P.cam_const, cam_const))) return rc;
     if ((rc = dev_upload(s, &P.cam_active, cam_active))) return rc;
+    {
+        std::vector<unsigned char> col_active((size_t)s->n_pad, 0);
+        for (int i = 0; i < s->n_pad; ++i) { const int m = i >> 4, a = i & 15; col_active[i] = (a < kFA && cam_active[m] && !(a < 6 && cam_const[m])) ? 1 : 0; }
+        if ((rc = dev_upload(s, &P.col_active, col_active))) return rc;
+    }
 
     for (int k = 0; k < 2; ++k) {
         if ((rc = dev_alloc(s, &S.cam_rt[k], 6 * (size_t)C))) return rc;
@@ -294,8 +310,10 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_alloc(s, &s->d_init_board, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.board_pc, (size_t)kBoardConst * B))) return rc;
     if ((rc = dev_alloc(s, &S.cam_pc, (size_t)kCamConst * C))) return rc;
-    if ((rc = dev_alloc(s, &S.campart, 256 * (size_t)P.n_chunks))) return rc;
-    if ((rc = dev_alloc(s, &S.campart2, 256 * (size_t)C * kCamG1))) return rc;
+    if ((rc = dev_alloc(s, &S.vconst, (size_t)kVConst * V))) return rc;
+    if ((rc = dev_alloc(s, &S.cconst, (size_t)kCConst * C))) return rc;
+    if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)P.n_chunks))) return rc;
+    if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C * kCamG1))) return rc;
     if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal))) return rc;
     if ((rc = dev_alloc(s, &S.M_stage, 8))) return rc;
     if ((rc = dev_alloc(s, &S.s_b, 6 * (size_t)B))) return rc;
@@ -315,15 +333,15 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     HIP_TRY(hipMemset(S.T, 0, sizeof(double) * (size_t)s->n_pad * s->n_pad));
     HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal)));
     HIP_TRY(hipMemset(S.M_stage, 0, sizeof(double) * 8));
-    HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 256 * (size_t)C * kCamG1));
+    HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 512 * (size_t)C * kCamG1));
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
-    s->lds_eval = sizeof(double) * ((size_t)(kFcols + kE) * kRP + 2 * (size_t)p->n_points);
-    s->lds_solve = sizeof(double) * (size_t)(s->n_pad + 1) * (s->n_pad + 4);
+    s->lds_eval = lds_eval_bytes;
+    { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + NN * TT + TT * TT + 4 * NN); }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     if (s->lds_eval > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval));
-    if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
+    if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
     HIP_TRY(hipDeviceSynchronize());
     *out = sp.release();
     return 0;
@@ -366,7 +384,7 @@ static int launch_eval(tscm_solver *s, int cand)
         e0 = s->ev[s->ev_used].first; e1 = s->ev[s->ev_used].second; ++s->ev_used;
         HIP_TRY(hipEventRecord(e0, s->stream));
     }
-    hipLaunchKernelGGL(k_eval_gram, dim3(P.n_chunks), dim3(64), s->lds_eval, s->stream, P, s->S, cand);
+    hipLaunchKernelGGL(k_eval_gram, dim3(P.n_chunks), dim3(64), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
     if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
 }
@@ -397,7 +415,7 @@ static int enqueue_eval(tscm_solver *s, int cand, int init, int have_backsub)
 {
     const DevProblem &P = s->P;
     DevState &S = s->S;
-    hipLaunchKernelGGL(k_pose_prep, dim3((P.B + P.C + 255) / 256), dim3(256), 0, s->stream, P, S, cand);
+    hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + 255) / 256), dim3(256), 0, s->stream, P, S, cand);
     if (int rc = launch_eval(s, cand)) return rc;
     hipLaunchKernelGGL(k_cam_reduce1, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S);
     if (S.n_st_blocks) hipLaunchKernelGGL(k_board_stats, dim3(S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
@@ -417,10 +435,11 @@ static int enqueue_iteration(tscm_solver *s)
     const DevProblem &P = s->P;
     DevState &S = s->S;
     if (S.n_bs_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
-    if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(64), 0, s->stream, P, S);
-    if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids), dim3(256), 0, s->stream, P, S);
+    if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
+    if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
     if (s->comm) NCCL_TRY(ncclAllReduce(S.T, S.T, (size_t)P.n_pad * P.n_pad, ncclDouble, ncclSum, s->comm->comm, s->stream));
-    hipLaunchKernelGGL(k_solve_reduced, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+    if (P.n_pad <= 64) hipLaunchKernelGGL(k_solve_reduced<4>, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+    else hipLaunchKernelGGL(k_solve_reduced<8>, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
     if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
     return enqueue_eval(s, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
@@ -583,6 +602,7 @@ static int prepare_eval(tscm_solver *s)
     HIP_TRY(hipMemcpy(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
     if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(k_pose_prep, dim3((s->P.B + s->P.C + 255) / 256), dim3(256), 0, s->stream, s->P, S, 0);
+    hipLaunchKernelGGL(k_view_prep, dim3((s->P.V + s->P.C + 255) / 256), dim3(256), 0, s->stream, s->P, S, 0);
     HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
