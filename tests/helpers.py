@@ -51,3 +51,34 @@ def param_rel_err(p: Problem, q: Problem) -> dict:
     d["cam_rt"] = pose(p.cam_rt, q.cam_rt) if not p.mono else 0.0
     d["board_rt"] = pose(p.board_rt, q.board_rt)
     return d
+
+
+def mixed_visibility_rig(seed=5, n_frames=24, n_cameras=4, noise_px=0.05) -> Problem:
+    """Rig whose frames are seen by 1..C cameras (random subsets).  Observations are exact
+    projections of the ground truth (image bounds ignored: the solver does not care), plus noise."""
+    base = synth.make_problem(n_cameras, 2 * n_frames // n_cameras * 2, seed, noise_px=0.0)
+    rng = np.random.default_rng(seed)
+    C, B = n_cameras, min(n_frames, base.n_boards)
+    intr, cam, brd = base.meta["gt_intr"], base.meta["gt_cam_rt"], base.meta["gt_board_rt"][:B]
+    npts = base.n_points
+    P3 = np.concatenate([base.board_xy, np.zeros((npts, 1))], axis=1)
+    vc, vb, u, v = [], [], [], []
+    for b in range(B):
+        k = 1 + (b % C)                                  # 1, 2, 3, 4, 1, ... cameras
+        cams = np.sort(rng.choice(C, size=k, replace=False))
+        Rb = synth.rodrigues(brd[b, :3])
+        Pw = P3 @ Rb.T + brd[b, 3:]
+        for m in cams:
+            Pc = Pw @ synth.rodrigues(cam[m, :3]).T + cam[m, 3:]
+            uu, vv, ks = synth.ts_project(intr[m], Pc)
+            if np.any(ks <= 1e-3):
+                continue
+            vc.append(m); vb.append(b); u.append(uu); v.append(vv)
+    V = len(vc)
+    obs_u = np.concatenate(u) + noise_px * rng.normal(size=V * npts)
+    obs_v = np.concatenate(v) + noise_px * rng.normal(size=V * npts)
+    p = Problem(C, B, base.board_xy, np.array(vc, dtype=np.int32), np.array(vb, dtype=np.int32),
+                (np.arange(V) * npts).astype(np.int32), np.full(V, npts, dtype=np.int32), obs_u, obs_v,
+                base.cam_rt.copy(), base.intr.copy(), base.board_rt[:B].copy(), base.cam_pose_constant.copy(), False,
+                meta=dict(gt_intr=intr, gt_cam_rt=cam, gt_board_rt=brd))
+    return p.normalised()

@@ -224,6 +224,16 @@ def test_big_board_more_than_64_corners(hip_device):
     assert max(H.param_rel_err(pg, po).values()) < 1e-6
 
 
+def test_boards_seen_by_one_to_four_cameras(hip_device):
+    """Frames seen by 1, 2, 3 and 4 cameras: every Schur-complement path (per-signature board
+    tiles for <= 3 views, explicit pair list above that)."""
+    p = H.mixed_visibility_rig(seed=5, n_frames=24)
+    assert sorted(set(np.bincount(p.view_board))) == [1, 2, 3, 4]
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    assert max(H.param_rel_err(pg, po).values()) < 1e-6
+
+
 def test_eight_camera_rig(hip_device):
     """C = 8 (BASELINE config 5 shape, small): 128-wide reduced system (second solver template)."""
     p = synth.make_problem(8, 6, 23)

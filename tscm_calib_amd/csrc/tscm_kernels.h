@@ -108,9 +108,14 @@ struct DevProblem {
     const int *view_cam, *view_board, *view_obs, *view_count;
     const double *obs_u, *obs_v;
     const int *chunk_vb, *chunk_ve, *chunk_cam, *cam_chunk_ptr;
-    const int *bv_ptr, *bv_idx;
+    const int *bv_ptr;                 // board -> range of view SLOTS (records are stored board-major)
+    const int *view_slot, *slot_cam;   // device view -> slot ; slot -> camera
     const int *pair_i, *pair_j;
-    const int *pc_begin, *pc_end, *bid_pc_ptr, *bid_mi, *bid_mj;
+    const int *pc_begin, *pc_end, *pc_tile, *bid_mi, *bid_mj;
+    const int *bid_part_ptr;                   // per camera-pair block: contiguous range of its partial tiles in pairpart
+    const int *sslot;                          // first view slot of each board, boards grouped by camera-set signature
+    const int *bc_begin, *bc_end, *bc_nv, *bc_tile;   // board chunks: range in sslot, views per board, tile ids [chunk*6 + t]
+    int n_bchunks, n_tiles;
     const unsigned char *cam_const, *cam_active;
     const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
 };
@@ -239,13 +244,13 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
 // dynamic LDS: kTcols*rp + kCst + 2*n_points doubles.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
+__global__ __launch_bounds__(64, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
 {
     if (S.ctrl->done) return;
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int RP = P.rp, HV = P.half;          // pitch = 2*odd >= 2*HV: conflict-free ds_read_b64
-    double *Fl = lds;                          // [kTcols][RP]: rows 0..HV-1 u, HV..2HV-1 v
+    const int RP = P.rp, HV = P.half;          // pitch = 2*odd >= HV: conflict-free ds_read_b64
+    double *Fl = lds;                          // [kTcols][RP]: HV rows; holds the u-rows, then the v-rows
     double *TU = Fl;                           // [16][16] staged u tile  } epilogue scratch, aliases the
     double *TV = TU + 256;                     // [16][16] staged v tile  } Jacobian tile (dead after the
     double *MU = TV + 256;                     // [6][16]                 } MFMA loop of the view)
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, i
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             const bool valid = j < cnt;
-            double *fu = Fl + lane, *fv = Fl + HV + lane;
+            double *fu = Fl + lane;
+            double fv[kTcols];                 // v-rows wait in registers until the u-rows have been consumed
             if (valid && !(ablate & 4)) {
                 const double x = bxy[2 * j], y = bxy[2 * j + 1];
                 const double ou = c0 ? P.obs_u[off + j] : ou0, ov = c0 ? P.obs_v[off + j] : ov0;
@@ -315,9 +321,9 @@ __global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, i
                 // -A = -d(u,v)/dPc  (the t_c columns)
                 const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
                 const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
-                fu[6 * RP] = n00; fv[6 * RP] = n10;
-                fu[7 * RP] = n01; fv[7 * RP] = n11;
-                fu[8 * RP] = n02; fv[8 * RP] = n12;
+                fu[6 * RP] = n00; fv[6] = n10;
+                fu[7 * RP] = n01; fv[7] = n11;
+                fu[8 * RP] = n02; fv[8] = n12;
                 // w_b: -A (x e_k0 + y e_k1)
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, i
                     const double h1 = x * cst[10 + 6 * kk] + y * cst[13 + 6 * kk];
                     const double h2 = x * cst[11 + 6 * kk] + y * cst[14 + 6 * kk];
                     fu[kk * RP] = n00 * h0 + n01 * h1 + n02 * h2;
-                    fv[kk * RP] = n10 * h0 + n11 * h1 + n12 * h2;
+                    fv[kk] = n10 * h0 + n11 * h1 + n12 * h2;
                 }
                 // w_c: -A (dR_c/dw_k Pw)
 #pragma unroll
@@ -335,42 +341,57 @@ __global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, i
                     const double g1 = D[3] * Pw0 + D[4] * Pw1 + D[5] * Pw2;
                     const double g2 = D[6] * Pw0 + D[7] * Pw1 + D[8] * Pw2;
                     fu[(3 + kk) * RP] = n00 * g0 + n01 * g1 + n02 * g2;
-                    fv[(3 + kk) * RP] = n10 * g0 + n11 * g1 + n12 * g2;
+                    fv[(3 + kk)] = n10 * g0 + n11 * g1 + n12 * g2;
                 }
                 // f* and one*
-                fu[9 * RP] = -mx;   fv[9 * RP] = -my;
-                fu[10 * RP] = -1.0; fv[10 * RP] = -1.0;
+                fu[9 * RP] = -mx;   fv[9] = -my;
+                fu[10 * RP] = -1.0; fv[10] = -1.0;
                 // xi, lambda, alpha: -du/dk * dk/dparam
                 const double hu = fxk * mx, hv = fyk * my;
                 const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * cc[46];
-                fu[11 * RP] = hu * kxi;  fv[11 * RP] = hv * kxi;
-                fu[12 * RP] = hu * klam; fv[12 * RP] = hv * klam;
-                fu[13 * RP] = hu * kal;  fv[13 * RP] = hv * kal;
+                fu[11 * RP] = hu * kxi;  fv[11] = hv * kxi;
+                fu[12 * RP] = hu * klam; fv[12] = hv * klam;
+                fu[13 * RP] = hu * kal;  fv[13] = hv * kal;
                 // residual = observed - projected (multi_calib.h:192-193)
                 fu[14 * RP] = ou - (fx * mx + cc[41]);
-                fv[14 * RP] = ov - (fy * my + cc[42]);
+                fv[14] = ov - (fy * my + cc[42]);
             } else if (lane < HV) {
 #pragma unroll
-                for (int c = 0; c < kTcols; ++c) { fu[c * RP] = 0.0; fv[c * RP] = 0.0; }
+                for (int c = 0; c < kTcols; ++c) { fu[c * RP] = 0.0; fv[c] = 0.0; }
             }
             wave_lds_fence();
             const int nv = min(64, cnt - c0);
             const int ksteps = (nv + 3) >> 2;
-            // rows past the last corner are zero (every lane wrote its rows), so the loop may run in
+            // rows past the last corner are zero (every lane < HV wrote its row), so the loops run in
             // pairs of k-steps; operands of the next pair are fetched while the current MFMAs issue
             const double *fp = Fl + (col < kTcols ? col : 0) * RP + kq;
             const bool live = col < kTcols;
-            double au0 = live ? fp[0] : 0.0, au1 = live ? fp[4] : 0.0;
-            double av0 = live ? fp[HV] : 0.0, av1 = live ? fp[HV + 4] : 0.0;
-            for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
-                const int tn = min(t + 2, (HV >> 2) - 2);   // stay inside the HV-row half
-                const double nu0 = live ? fp[4 * tn] : 0.0, nu1 = live ? fp[4 * tn + 4] : 0.0;
-                const double nv0 = live ? fp[HV + 4 * tn] : 0.0, nv1 = live ? fp[HV + 4 * tn + 4] : 0.0;
-                accU = __builtin_amdgcn_mfma_f64_16x16x4f64(au0, au0, accU, 0, 0, 0);
-                accV = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, av0, accV, 0, 0, 0);
-                accU = __builtin_amdgcn_mfma_f64_16x16x4f64(au1, au1, accU, 0, 0, 0);
-                accV = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, av1, accV, 0, 0, 0);
-                au0 = nu0; au1 = nu1; av0 = nv0; av1 = nv1;
+            const int tmax = (HV >> 2) - 2;
+            {
+                double a0 = live ? fp[0] : 0.0, a1 = live ? fp[4] : 0.0;
+                for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
+                    const int tn = min(t + 2, tmax);
+                    const double n0 = live ? fp[4 * tn] : 0.0, n1 = live ? fp[4 * tn + 4] : 0.0;
+                    accU = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, accU, 0, 0, 0);
+                    accU = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accU, 0, 0, 0);
+                    a0 = n0; a1 = n1;
+                }
+            }
+            wave_lds_fence();
+            if (lane < HV) {
+#pragma unroll
+                for (int c = 0; c < kTcols; ++c) fu[c * RP] = fv[c];
+            }
+            wave_lds_fence();
+            {
+                double a0 = live ? fp[0] : 0.0, a1 = live ? fp[4] : 0.0;
+                for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
+                    const int tn = min(t + 2, tmax);
+                    const double n0 = live ? fp[4 * tn] : 0.0, n1 = live ? fp[4 * tn + 4] : 0.0;
+                    accV = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, accV, 0, 0, 0);
+                    accV = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accV, 0, 0, 0);
+                    a0 = n0; a1 = n1;
+                }
             }
             wave_lds_fence();
         }
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(64, 2) void k_eval_gram(DevProblem P, DevState S, i
             (par ? MV : MU)[e * 16 + c] = v;
         }
         wave_lds_fence();
-        double *rec = S.rec[tgt] + (size_t)kRec * view;
+        double *rec = S.rec[tgt] + (size_t)kRec * P.view_slot[view];
         for (int idx = lane; idx < kRec; idx += 64) {
             double v;
             if (idx < kRecEE) {
@@ -474,7 +495,7 @@ __global__ void k_board_stats(DevProblem P, DevState S, int cand, int init)
         if (q1 > q0) {
             double g[6] = { 0, 0, 0, 0, 0, 0 }, dg[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
-                const double *rec = S.rec[tgt] + (size_t)kRec * P.bv_idx[q];
+                const double *rec = S.rec[tgt] + (size_t)kRec * q;
                 for (int i = 0; i < 6; ++i) { g[i] += rec[kRecG + i]; dg[i] += rec[kRecG + 6 + i]; }
             }
             for (int i = 0; i < 6; ++i) {
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
     double M[21], g[6] = { 0, 0, 0, 0, 0, 0 };
     for (int i = 0; i < 21; ++i) M[i] = 0.0;
     for (int q = q0; q < q1; ++q) {
-        const double *rec = S.rec[cur] + (size_t)kRec * P.bv_idx[q];
+        const double *rec = S.rec[cur] + (size_t)kRec * q;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
 #pragma unroll
     for (int i = 0; i < 6; ++i) il[i] = 1.0 / L[i * (i + 1) / 2 + i];
     for (int q = q0; q < q1; ++q) {
-        const int v = P.bv_idx[q];
+        const int v = q;
         const double *rec = S.rec[cur] + (size_t)kRec * v;
         double y[6];
 #pragma unroll
@@ -621,10 +642,71 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
     }
 }
 
-// Schur complement contributions  T(mi, mj) += Y'_i^T Y'_j  over pairs of views of one board.
-// Pairs are pre-sorted by camera-pair block; one 4-wave workgroup per chunk of pairs of a single
-// block, each wave keeps a 16x16 tile in registers (4 entries per lane, two pairs in flight),
-// the four tiles are summed in a fixed order through LDS.   grid n_pchunks x 256
+// Schur complement contributions  T(m_p, m_q) += Y'_p^T Y'_q  for the views p <= q of one board.
+// Boards are grouped by their camera set ("signature"); one 4-wave workgroup per chunk of boards
+// of ONE signature, so the NV(NV+1)/2 16x16 tiles of a chunk map to fixed camera-pair blocks and
+// stay in registers (4 entries per lane per tile); every Y' record is read once per board.
+// The four waves' tiles are summed in a fixed order through LDS.   grid n_bchunks x 256
+template <int NV>
+__device__ __forceinline__ void board_gram_chunk(const DevProblem &P, const DevState &S, int chunk, double (*red)[256])
+{
+    constexpr int NT = NV * (NV + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane & 15, bg = lane >> 4;
+    double acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t][0] = 0.0; acc[t][1] = 0.0; acc[t][2] = 0.0; acc[t][3] = 0.0; }
+    const int b1 = P.bc_end[chunk];
+    for (int bi = P.bc_begin[chunk] + wave; bi < b1; bi += 8) {
+        const double *Y = S.Y + (size_t)96 * P.sslot[bi];     // the board's NV records are contiguous
+        double ya[NV][6];
+        d4 yb[NV][6];
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { ya[p][k] = Y[96 * p + k * 16 + a]; yb[p][k] = *reinterpret_cast<const d4 *>(Y + 96 * p + k * 16 + 4 * bg); }
+        }
+        int t = 0;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+#pragma unroll
+            for (int q = p; q < NV; ++q, ++t) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    acc[t][0] += ya[p][k] * yb[q][k][0]; acc[t][1] += ya[p][k] * yb[q][k][1];
+                    acc[t][2] += ya[p][k] * yb[q][k][2]; acc[t][3] += ya[p][k] * yb[q][k][3];
+                }
+            }
+        }
+    }
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][a * 16 + 4 * bg + e] = acc[t][e];
+        __syncthreads();
+        if (tid < 256)
+            S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] =
+                ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(512) void k_board_gram(DevProblem P, DevState S)
+{
+    if (S.ctrl->done) return;
+    __shared__ double red[8][256];
+    const int chunk = blockIdx.x;
+    switch (P.bc_nv[chunk]) {
+    case 1: board_gram_chunk<1>(P, S, chunk, red); break;
+    case 2: board_gram_chunk<2>(P, S, chunk, red); break;
+    case 3: board_gram_chunk<3>(P, S, chunk, red); break;
+    default: break;      // boards seen by more than three cameras go through k_pair_gram
+    }
+}
+
+// Fallback for boards seen by more than three cameras: explicit list of view pairs, pre-sorted by
+// camera-pair block; one 4-wave workgroup per chunk of pairs of a single block.   grid n_pchunks x 256
 __global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
@@ -632,43 +714,26 @@ __global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
     const int pc = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane & 15, bg = lane >> 4;
-    const int pb = P.pc_begin[pc], pe = P.pc_end[pc];
-    const int q = (pe - pb + 3) >> 2;
-    const int wb = pb + wave * q, we = min(pe, wb + q);
-    double acc[4] = { 0.0, 0.0, 0.0, 0.0 }, bcc[4] = { 0.0, 0.0, 0.0, 0.0 };
-    for (int p = wb; p < we; p += 2) {
-        const bool two = p + 1 < we;
-        const double *Yi0 = S.Y + (size_t)96 * P.pair_i[p];
-        const double *Yj0 = S.Y + (size_t)96 * P.pair_j[p];
-        const double *Yi1 = S.Y + (size_t)96 * P.pair_i[two ? p + 1 : p];
-        const double *Yj1 = S.Y + (size_t)96 * P.pair_j[two ? p + 1 : p];
-        double ya0[6], ya1[6];
-        d4 yb0[6], yb1[6];
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (int p = P.pc_begin[pc] + wave; p < P.pc_end[pc]; p += 4) {
+        const double *Yi = S.Y + (size_t)96 * P.pair_i[p];
+        const double *Yj = S.Y + (size_t)96 * P.pair_j[p];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            ya0[k] = Yi0[k * 16 + a]; yb0[k] = *reinterpret_cast<const d4 *>(Yj0 + k * 16 + 4 * bg);
-            ya1[k] = Yi1[k * 16 + a]; yb1[k] = *reinterpret_cast<const d4 *>(Yj1 + k * 16 + 4 * bg);
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            acc[0] += ya0[k] * yb0[k][0]; acc[1] += ya0[k] * yb0[k][1]; acc[2] += ya0[k] * yb0[k][2]; acc[3] += ya0[k] * yb0[k][3];
-        }
-        if (two) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                bcc[0] += ya1[k] * yb1[k][0]; bcc[1] += ya1[k] * yb1[k][1]; bcc[2] += ya1[k] * yb1[k][2]; bcc[3] += ya1[k] * yb1[k][3];
-            }
+            const double ya = Yi[k * 16 + a];
+            const d4 yb = *reinterpret_cast<const d4 *>(Yj + k * 16 + 4 * bg);
+            acc[0] += ya * yb[0]; acc[1] += ya * yb[1]; acc[2] += ya * yb[2]; acc[3] += ya * yb[3];
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][a * 16 + 4 * bg + e] = acc[e] + bcc[e];
+    for (int e = 0; e < 4; ++e) red[wave][a * 16 + 4 * bg + e] = acc[e];
     __syncthreads();
     const int t = threadIdx.x;
-    S.pairpart[(size_t)256 * pc + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    S.pairpart[(size_t)256 * P.pc_tile[pc] + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-// grid (n_bids * 4) x 256: block (bid, quarter) sums 64 tile entries over the pair-chunk tiles of
-// one camera-pair block, the chunk list split four ways across the threads of an entry
+// grid (n_bids * 4) x 256: block (bid, quarter) sums 64 entries of the partial tiles that belong to
+// one camera-pair block, the tile list split four ways across the threads of an entry
 __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
@@ -676,12 +741,16 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
     const int bid = blockIdx.x >> 2, quarter = blockIdx.x & 3;
     const int e = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int entry = quarter * 64 + e;
-    const int cb = P.bid_pc_ptr[bid], ce = P.bid_pc_ptr[bid + 1];
+    const int cb = P.bid_part_ptr[bid], ce = P.bid_part_ptr[bid + 1];
     const int per = (ce - cb + 3) >> 2;
     const int b0 = cb + slice * per, b1 = min(ce, b0 + per);
     double a0 = 0.0, a1 = 0.0;
     int c = b0;
-    for (; c + 1 < b1; c += 2) { a0 += S.pairpart[(size_t)256 * c + entry]; a1 += S.pairpart[(size_t)256 * (c + 1) + entry]; }
+    // the partial tiles of one block are stored contiguously: [bid_part_ptr[bid], bid_part_ptr[bid+1])
+    for (; c + 1 < b1; c += 2) {
+        a0 += S.pairpart[(size_t)256 * c + entry];
+        a1 += S.pairpart[(size_t)256 * (c + 1) + entry];
+    }
     if (c < b1) a0 += S.pairpart[(size_t)256 * c + entry];
     red[slice][e] = a0 + a1;
     __syncthreads();
@@ -928,8 +997,8 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
         } else {
             double p[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
-                const int v = P.bv_idx[q];
-                const double yh = (a < kFA) ? S.yhat[P.view_cam[v] * 16 + a] : 0.0;
+                const int v = q;
+                const double yh = (a < kFA) ? S.yhat[P.slot_cam[v] * 16 + a] : 0.0;
                 const double *Yv = S.Y + (size_t)96 * v;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) p[k] += Yv[k * 16 + a] * yh;

@@ -60,7 +60,7 @@ struct tscm_solver {
     int C = 0, B = 0, V = 0, N = 0, n_points = 0, n_pad = 0;
     bool mono = false;
     std::vector<int> dev2orig;          // device view -> problem view
-    std::vector<int> h_view_obs, h_view_count, h_view_cam, h_view_board;
+    std::vector<int> h_view_obs, h_view_count, h_view_cam, h_view_board, h_view_slot;
     // caller-owned parameter arrays (host)
     double *h_cam_rt = nullptr, *h_intr = nullptr, *h_board_rt = nullptr;
     // resident initial parameters for the benchmark
@@ -208,13 +208,18 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
 
     // ---- chunks of views (one wave each), never straddling a camera ----------------------------
     // one round of resident waves: LDS admits floor(160 KiB / lds_eval) single-wave workgroups per CU
-    // Jacobian tile geometry: HV rows per parity (multiple of 4 covering min(64, n) corners), pitch 2*HV + 2
+    // Jacobian tile geometry: HV rows (multiple of 4 covering min(64, n) corners; u-rows and v-rows take turns), pitch HV + 2
     // (= 2 * odd: the 16 columns x 2 rows of a 32-lane ds_read_b64 group then hit 32 distinct bank pairs)
     const int half_rows = 4 * ((std::min(64, p->n_points) + 3) / 4);
-    const int rp = 2 * half_rows + 2;
+    const int rp = half_rows + 2;      // = 2 * odd (half_rows is a multiple of 4)
     const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)kTcols * rp, 704) + kCst + 2 * (size_t)p->n_points);
-    const int waves_per_cu = std::max(1, std::min(16, (int)((160 * 1024) / lds_eval_bytes)));
-    const int target_chunks = 256 * waves_per_cu - 4 * C;
+    if (lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_bytes));
+    int waves_per_cu = 0;       // resident single-wave workgroups per CU (register- and LDS-limited)
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, reinterpret_cast<const void *>(k_eval_gram), 64, lds_eval_bytes));
+    waves_per_cu = std::max(1, std::min(16, waves_per_cu));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int target_chunks = std::max(64, prop.multiProcessorCount * waves_per_cu - 4 * C);
     const int per_chunk = std::max(1, (V + target_chunks - 1) / target_chunks);
     std::vector<int> chunk_vb, chunk_ve, chunk_cam, cam_chunk_ptr(C + 1, 0);
     {
@@ -236,31 +241,100 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
         std::vector<int> fill(B, 0);
         for (int i = 0; i < V; ++i) { const int b = view_board[i]; bv_idx[bv_ptr[b] + fill[b]++] = i; }
     }
-    // ---- view pairs grouped by camera-pair block --------------------------------------------------
+    // records are stored board-major: slot q of bv order <-> device view bv_idx[q]
+    std::vector<int> view_slot(V), slot_cam(V);
+    for (int q = 0; q < V; ++q) { view_slot[bv_idx[q]] = q; slot_cam[q] = view_cam[bv_idx[q]]; }
+    s->h_view_slot = view_slot;
+    // ---- Schur-complement work lists ------------------------------------------------------------
+    // camera-pair blocks ("bids") of T that receive contributions
     std::vector<int> bid_of(C * C, -1), bid_mi, bid_mj;
-    std::vector<std::vector<std::pair<int, int>>> pairs_by_bid;
-    for (int b = 0; b < B; ++b)
-        for (int q1 = bv_ptr[b]; q1 < bv_ptr[b + 1]; ++q1)
-            for (int q2 = q1; q2 < bv_ptr[b + 1]; ++q2) {
-                const int vi = bv_idx[q1], vj = bv_idx[q2];
-                const int key = view_cam[vi] * C + view_cam[vj];
-                if (bid_of[key] < 0) { bid_of[key] = (int)bid_mi.size(); bid_mi.push_back(view_cam[vi]); bid_mj.push_back(view_cam[vj]); pairs_by_bid.emplace_back(); }
-                pairs_by_bid[bid_of[key]].emplace_back(vi, vj);
+    auto get_bid = [&](int mi, int mj) {
+        const int key = mi * C + mj;
+        if (bid_of[key] < 0) { bid_of[key] = (int)bid_mi.size(); bid_mi.push_back(mi); bid_mj.push_back(mj); }
+        return bid_of[key];
+    };
+    // boards grouped by camera-set signature (views of a board are already sorted by camera)
+    std::vector<int> order_b;
+    for (int b = 0; b < B; ++b) if (bv_ptr[b + 1] > bv_ptr[b]) order_b.push_back(b);
+    auto sig_less = [&](int x, int y) {
+        const int nx = bv_ptr[x + 1] - bv_ptr[x], ny = bv_ptr[y + 1] - bv_ptr[y];
+        if (nx != ny) return nx < ny;
+        for (int k = 0; k < nx; ++k) {
+            const int cx = slot_cam[bv_ptr[x] + k], cy = slot_cam[bv_ptr[y] + k];
+            if (cx != cy) return cx < cy;
+        }
+        return false;
+    };
+    std::stable_sort(order_b.begin(), order_b.end(), sig_less);
+    // Every partial tile belongs to one camera-pair block; tiles of a block are numbered contiguously
+    // (two passes: count, then assign) so that k_T_reduce streams them without indirection.
+    struct ChunkT { int begin, end, nv, bid[6]; };
+    std::vector<ChunkT> bchunks;
+    std::vector<int> sslot, pair_i, pair_j;
+    struct PChunk { int begin, end, bid; };
+    std::vector<PChunk> pchunks;
+    std::vector<std::vector<std::pair<int, int>>> fb_pairs;      // fallback pairs per bid (boards with > 3 views)
+    {
+        size_t fast_boards = 0;
+        for (int b : order_b) if (bv_ptr[b + 1] - bv_ptr[b] <= 3) ++fast_boards;
+        const int target_bchunks = 256;
+        const int per_bchunk = std::max<int>(1, (int)((fast_boards + target_bchunks - 1) / target_bchunks));
+        size_t i = 0;
+        while (i < order_b.size()) {
+            size_t e = i + 1;
+            while (e < order_b.size() && !sig_less(order_b[i], order_b[e]) && !sig_less(order_b[e], order_b[i])) ++e;
+            const int b0 = order_b[i];
+            const int nv = bv_ptr[b0 + 1] - bv_ptr[b0];
+            if (nv <= 3) {
+                for (size_t c0 = i; c0 < e; c0 += per_bchunk) {
+                    const size_t c1 = std::min(e, c0 + per_bchunk);
+                    ChunkT ch{};
+                    ch.begin = (int)sslot.size();
+                    for (size_t k = c0; k < c1; ++k) sslot.push_back(bv_ptr[order_b[k]]);
+                    ch.end = (int)sslot.size();
+                    ch.nv = nv;
+                    int t = 0;
+                    for (int p1 = 0; p1 < nv; ++p1)
+                        for (int p2 = p1; p2 < nv; ++p2) ch.bid[t++] = get_bid(slot_cam[bv_ptr[b0] + p1], slot_cam[bv_ptr[b0] + p2]);
+                    bchunks.push_back(ch);
+                }
+            } else {
+                for (size_t k = i; k < e; ++k) {
+                    const int b = order_b[k];
+                    for (int q1 = bv_ptr[b]; q1 < bv_ptr[b + 1]; ++q1)
+                        for (int q2 = q1; q2 < bv_ptr[b + 1]; ++q2) {
+                            const int bid = get_bid(slot_cam[q1], slot_cam[q2]);
+                            if ((int)fb_pairs.size() <= bid) fb_pairs.resize(bid + 1);
+                            fb_pairs[bid].emplace_back(q1, q2);
+                        }
+                }
             }
-    const int n_bids = (int)bid_mi.size();
-    size_t n_pairs = 0;
-    for (auto &v : pairs_by_bid) n_pairs += v.size();
-    const int target_pchunks = 768;
-    const int per_pchunk = std::max<int>(1, (int)((n_pairs + target_pchunks - 1) / target_pchunks));
-    std::vector<int> pair_i, pair_j, pc_begin, pc_end, bid_pc_ptr(n_bids + 1, 0);
-    for (int bid = 0; bid < n_bids; ++bid) {
-        bid_pc_ptr[bid] = (int)pc_begin.size();
-        const int base = (int)pair_i.size();
-        for (auto &pr : pairs_by_bid[bid]) { pair_i.push_back(pr.first); pair_j.push_back(pr.second); }
-        const int end = (int)pair_i.size();
-        for (int b0 = base; b0 < end; b0 += per_pchunk) { pc_begin.push_back(b0); pc_end.push_back(std::min(end, b0 + per_pchunk)); }
+            i = e;
+        }
+        size_t n_fb = 0;
+        for (auto &v : fb_pairs) n_fb += v.size();
+        const int per_pchunk = std::max<int>(1, (int)((n_fb + 511) / 512));
+        for (size_t bid = 0; bid < fb_pairs.size(); ++bid) {
+            const int base = (int)pair_i.size();
+            for (auto &pr : fb_pairs[bid]) { pair_i.push_back(pr.first); pair_j.push_back(pr.second); }
+            const int end = (int)pair_i.size();
+            for (int b0 = base; b0 < end; b0 += per_pchunk) pchunks.push_back({ b0, std::min(end, b0 + per_pchunk), (int)bid });
+        }
     }
-    bid_pc_ptr[n_bids] = (int)pc_begin.size();
+    const int n_bids = (int)bid_mi.size();
+    std::vector<int> bid_part_ptr(n_bids + 1, 0);
+    for (auto &ch : bchunks) for (int t = 0; t < ch.nv * (ch.nv + 1) / 2; ++t) bid_part_ptr[ch.bid[t] + 1]++;
+    for (auto &pc : pchunks) bid_part_ptr[pc.bid + 1]++;
+    for (int b = 0; b < n_bids; ++b) bid_part_ptr[b + 1] += bid_part_ptr[b];
+    const int n_tiles = bid_part_ptr[n_bids];
+    std::vector<int> next_tile(bid_part_ptr.begin(), bid_part_ptr.end() - 1);
+    std::vector<int> bc_begin, bc_end, bc_nv, bc_tile, pc_begin, pc_end, pc_tile;
+    for (auto &ch : bchunks) {
+        bc_begin.push_back(ch.begin); bc_end.push_back(ch.end); bc_nv.push_back(ch.nv);
+        for (int t = 0; t < 6; ++t) bc_tile.push_back(t < ch.nv * (ch.nv + 1) / 2 ? next_tile[ch.bid[t]]++ : -1);
+    }
+    for (auto &pc : pchunks) { pc_begin.push_back(pc.begin); pc_end.push_back(pc.end); pc_tile.push_back(next_tile[pc.bid]++); }
+    const size_t n_pairs = pair_i.size();
 
     // ---- upload --------------------------------------------------------------------------------
     DevProblem &P = s->P;
@@ -268,6 +342,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
     P.rp = rp; P.half = half_rows;
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
+    P.n_bchunks = (int)bc_begin.size(); P.n_tiles = n_tiles;
     std::vector<double> bxy(p->board_xy, p->board_xy + 2 * (size_t)p->n_points);
     int rc;
     if ((rc = dev_upload(s, &P.board_xy, bxy))) return rc;
@@ -282,12 +357,19 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_upload(s, &P.chunk_cam, chunk_cam))) return rc;
     if ((rc = dev_upload(s, &P.cam_chunk_ptr, cam_chunk_ptr))) return rc;
     if ((rc = dev_upload(s, &P.bv_ptr, bv_ptr))) return rc;
-    if ((rc = dev_upload(s, &P.bv_idx, bv_idx))) return rc;
+    if ((rc = dev_upload(s, &P.view_slot, view_slot))) return rc;
+    if ((rc = dev_upload(s, &P.slot_cam, slot_cam))) return rc;
     if ((rc = dev_upload(s, &P.pair_i, pair_i))) return rc;
     if ((rc = dev_upload(s, &P.pair_j, pair_j))) return rc;
     if ((rc = dev_upload(s, &P.pc_begin, pc_begin))) return rc;
     if ((rc = dev_upload(s, &P.pc_end, pc_end))) return rc;
-    if ((rc = dev_upload(s, &P.bid_pc_ptr, bid_pc_ptr))) return rc;
+    if ((rc = dev_upload(s, &P.pc_tile, pc_tile))) return rc;
+    if ((rc = dev_upload(s, &P.bid_part_ptr, bid_part_ptr))) return rc;
+    if ((rc = dev_upload(s, &P.sslot, sslot))) return rc;
+    if ((rc = dev_upload(s, &P.bc_begin, bc_begin))) return rc;
+    if ((rc = dev_upload(s, &P.bc_end, bc_end))) return rc;
+    if ((rc = dev_upload(s, &P.bc_nv, bc_nv))) return rc;
+    if ((rc = dev_upload(s, &P.bc_tile, bc_tile))) return rc;
     if ((rc = dev_upload(s, &P.bid_mi, bid_mi))) return rc;
     if ((rc = dev_upload(s, &P.bid_mj, bid_mj))) return rc;
     if ((rc = dev_upload(s, &P.cam_const, cam_const))) return rc;
@@ -322,7 +404,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_alloc(s, &S.z, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.D2, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.Y, 96 * (size_t)V))) return rc;
-    if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_pchunks))) return rc;
+    if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
     if ((rc = dev_alloc(s, &S.T, (size_t)s->n_pad * s->n_pad))) return rc;
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
     S.n_bs_blocks = (B + 15) / 16;
@@ -340,7 +422,6 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     s->lds_eval = lds_eval_bytes;
     { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + NN * TT + TT * TT + 4 * NN); }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
-    if (s->lds_eval > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval));
     if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
     HIP_TRY(hipDeviceSynchronize());
     *out = sp.release();
@@ -435,6 +516,7 @@ static int enqueue_iteration(tscm_solver *s)
     const DevProblem &P = s->P;
     DevState &S = s->S;
     if (S.n_bs_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+    if (P.n_bchunks) hipLaunchKernelGGL(k_board_gram, dim3(P.n_bchunks), dim3(512), 0, s->stream, P, S);
     if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
     if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
     if (s->comm) NCCL_TRY(ncclAllReduce(S.T, S.T, (size_t)P.n_pad * P.n_pad, ncclDouble, ncclSum, s->comm->comm, s->stream));
@@ -676,7 +758,7 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     if (board_grad) std::memset(board_grad, 0, sizeof(double) * 6 * (size_t)s->B);
     if (view_cross) std::memset(view_cross, 0, sizeof(double) * 90 * (size_t)p->n_views);
     for (int dv = 0; dv < s->V; ++dv) {
-        const double *r = rec.data() + (size_t)kRec * dv;
+        const double *r = rec.data() + (size_t)kRec * s->h_view_slot[dv];
         const int b = s->h_view_board[dv], ov = s->dev2orig[dv];
         for (int i = 0; i < 6; ++i) {
             if (board_gram) for (int j = 0; j < 6; ++j) board_gram[36 * (size_t)b + 6 * i + j] += r[kRecEE + 6 * i + j];
