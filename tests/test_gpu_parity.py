@@ -186,6 +186,33 @@ def test_lm_one_shot_entry_points(hip_device):
         api.calibrate(pg)
 
 
+def test_cpp_host_program_through_c_abi(hip_device, tmp_path):
+    """examples/dropin_demo.cpp: a C++11 host (the reference's language) linked against the C ABI,
+    doing what the rewritten MultiCalib::calibrate() of INTEGRATION.md does."""
+    import os, struct, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dropin_demo")
+    csrc = os.path.join(root, "tscm_calib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "dropin_demo.cpp"),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", exe])
+    p = H.small_rig(4, 12, seed=13)
+    with open(tmp_path / "problem.bin", "wb") as f:
+        f.write(struct.pack("6i", p.n_cameras, p.n_boards, p.n_points, p.n_views, p.n_corners, int(p.mono)))
+        for a in (p.board_xy, p.view_camera, p.view_board, p.view_offset, p.view_count, p.obs_u, p.obs_v,
+                  p.cam_rt, p.intr, p.board_rt, p.cam_pose_constant):
+            f.write(np.ascontiguousarray(a).tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "problem.bin"), str(tmp_path / "result.bin")]).decode()
+    assert "Function tolerance reached." in out or "tolerance" in out
+    raw = open(tmp_path / "result.bin", "rb").read()
+    C, B = p.n_cameras, p.n_boards
+    vals = np.frombuffer(raw[:8 * (15 * C + 6 * B)], dtype=np.float64)
+    po = p.copy().normalised()
+    os_ = orc.solve(po)
+    assert np.max(np.abs(vals[6 * C:15 * C].reshape(C, 9)[:, :7] - po.intr[:, :7]) / np.abs(po.intr[:, :7])) < 1e-6
+    term, iters = struct.unpack("2i", raw[8 * (15 * C + 6 * B):8 * (15 * C + 6 * B) + 8])
+    assert term == os_["termination_type"] and iters == os_["num_iterations"]
+
+
 def test_lm_rejected_and_invalid_steps(hip_device):
     """A tiny initial radius forces heavily damped steps and a huge one an aggressive first
     step; the accept/reject bookkeeping must follow the oracle either way."""
