@@ -134,7 +134,7 @@ def main():
     # warmup (untimed)
     if args.warmup > 0:
         run_iterations(solver, args.warmup)
-    solver.kernel_time(enable=True)
+    solver.kernel_time(enable=os.environ.get("TSCM_BENCH_NO_EVENTS") is None)
     barrier()
     t0 = time.perf_counter()
     last = run_iterations(solver, args.steps)
@@ -151,7 +151,7 @@ def main():
         n_local = prob.n_corners
         avg_ms = kms / max(launches, 1)
         flops = n_local * FLOP_PER_CORNER
-        achieved_tf = flops / (avg_ms * 1e-3) / 1e12
+        achieved_tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
         if os.path.exists(pmc) and world == 1:
@@ -182,7 +182,7 @@ def main():
                 "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                 "launches": launches, "avg_launch_ms": avg_ms,
                 "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
-                "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

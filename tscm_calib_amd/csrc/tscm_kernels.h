@@ -90,7 +90,7 @@ struct Ctrl {
     // ---- header (polled by the host) ----
     int done, term_type, term_reason, iteration;
     int cur, lin_fail, num_successful, num_unsuccessful;
-    int num_invalid, n_log, lm_iterations, pad0;
+    int num_invalid, n_log, lm_iterations, fin_count;   // fin_count: arrival counter of k_finalize_eval
     double radius, decrease_factor;
     double x_cost, x_norm, gmax, gnorm;
     double model_cam, stepsq_cam;
@@ -103,7 +103,8 @@ struct Ctrl {
 struct DevProblem {
     int C, B, n_points, V, N, n_pad;
     int n_chunks, n_pairs, n_pchunks, n_bids;
-    int rp, half;                      // LDS pitch (doubles) and v-row offset of the Jacobian tile
+    int rp, half;                      // LDS pitch (doubles) and rows of the Jacobian tile
+    int lds_wave;                      // doubles of LDS per wave of k_eval_gram
     const double *board_xy;
     const int *view_cam, *view_board, *view_obs, *view_count;
     const double *obs_u, *obs_v;
@@ -238,27 +239,25 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 //     by keeping the u-rows and the v-rows of the Jacobian in two accumulators.
 //   -> 15 tile columns, v_mfma_f64_16x16x4_f64 count per view = 2*ceil(n/4) (28 for 54 corners)
 //      instead of 3*ceil(2n/4) = 81 for the naive [E|F|r] padding.
-// One wave (= one 64-thread workgroup) per chunk of consecutive views of ONE camera;
+// One wave per chunk of consecutive views of ONE camera, four such waves (same camera) per workgroup;
 // lane = corner (coalesced SoA loads of u[], v[]), board points and all wave-uniform constants in
 // LDS, Jacobian columns transposed through LDS (column-major, pitch 130: conflict-free
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
 // dynamic LDS: kTcols*rp + kCst + 2*n_points doubles.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
+__global__ __launch_bounds__(256, 3) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
 {
     if (S.ctrl->done) return;
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = threadIdx.x >> 6;
+    double *lds = lds_all + (size_t)wave * P.lds_wave;     // every wave works in its own LDS region
     const int RP = P.rp, HV = P.half;          // pitch = 2*odd >= HV: conflict-free ds_read_b64
     double *Fl = lds;                          // [kTcols][RP]: HV rows; holds the u-rows, then the v-rows
-    double *TU = Fl;                           // [16][16] staged u tile  } epilogue scratch, aliases the
-    double *TV = TU + 256;                     // [16][16] staged v tile  } Jacobian tile (dead after the
-    double *MU = TV + 256;                     // [6][16]                 } MFMA loop of the view)
-    double *MV = MU + 96;                      // [6][16]
-    double *cst = Fl + max(kTcols * RP, 704);  // [kCst]  (704 = epilogue scratch, for tiny boards)
+    double *cst = Fl + max(kTcols * RP, 512);  // [kCst]  (512 = final camera-tile exchange, for tiny boards)
     double *bxy = cst + kCst;
-    const int lane = threadIdx.x;
-    const int chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + wave;
     const int cam = P.chunk_cam[chunk];
     for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
     if (lane < kCConst) cst[kVConst + lane] = S.cconst[kCConst * cam + lane];
@@ -397,48 +396,67 @@ __global__ __launch_bounds__(64, 4) void k_eval_gram(DevProblem P, DevState S, i
         }
         camU += accU; camV += accV;
         if (ablate & 2) continue;
-        // ---- epilogue: tile -> record  (E rows: w_b directly, t_b = R_c^T t_c rows) -------------
+        // ---- epilogue: tile -> record, entirely in registers (cross-lane shuffles, no LDS phases) ------
+        // D layout: lane (col, kq) holds rows kq + 4*reg of column col.  E rows of the record:
+        //   e = kq       (w_b rows = tile rows 0..2: reg 0 of the lanes with kq < 3)
+        //   e = 3 + l    (t_b rows = sum_j R_c[j][l] * tile row 6+j; rows 6,7 are reg 1 of kq = 2,3, row 8 is
+        //                 reg 2 of kq = 0) -- lane (col, kq = l) builds row 3 + l of its column.
+        {
+            const d4 sT = accU + accV;
+            const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
+            const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
+            const int l = kq < 3 ? kq : 0;
+            const double r0 = cc[l], r1 = cc[3 + l], r2 = cc[6 + l];          // R_c[j][l], j = 0..2
+            const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;   // rows kq and 3+kq (u+v)
+            const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8; // their u-row parts
+            const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
+            const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
+            double *rec = S.rec[tgt] + (size_t)kRec * P.view_slot[view];
+            if (kq < 3) {
+                double *lo = rec + 16 * kq, *hi = rec + 16 * (3 + kq);
+                if (col >= 3 && col <= 8) { lo[col - 3] = mT_lo; hi[col - 3] = mT_hi; }                 // w_c, t_c
+                else if (col == 9) { lo[6] = mU_lo; hi[6] = mU_hi; lo[7] = mT_lo - mU_lo; hi[7] = mT_hi - mU_hi; }   // fx | fy
+                else if (col == 10) { lo[8] = mU_lo; hi[8] = mU_hi; lo[9] = mT_lo - mU_lo; hi[9] = mT_hi - mU_hi; }  // cx | cy
+                else if (col >= 11 && col <= 14) { lo[col - 1] = mT_lo; hi[col - 1] = mT_hi; }          // xi lambda alpha r
+                else if (col == 15) { lo[14] = 0.0; lo[15] = 0.0; hi[14] = 0.0; hi[15] = 0.0; }
+                else {                                                                                  // col 0..2: E^T E, w_b columns
+                    rec[kRecEE + 6 * kq + col] = mT_lo;
+                    rec[kRecEE + 6 * (3 + kq) + col] = mT_hi;
+                    if (col == kq) rec[kRecG + 6 + kq] = mT_lo;                                         // diag(E^T E), w_b part
+                }
+                if (col == 6) {
+                    // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) { TU[(kq + 4 * rg) * 16 + col] = accU[rg]; TV[(kq + 4 * rg) * 16 + col] = accV[rg]; }
-        wave_lds_fence();
-        for (int idx = lane; idx < 192; idx += 64) {
-            const int par = idx >= 96, e = (idx % 96) >> 4, c = idx & 15;
-            const double *T = par ? TV : TU;
-            double v;
-            if (e < 3) v = T[e * 16 + c];
-            else { const int l = e - 3; v = cc[l] * T[6 * 16 + c] + cc[3 + l] * T[7 * 16 + c] + cc[6 + l] * T[8 * 16 + c]; }
-            (par ? MV : MU)[e * 16 + c] = v;
-        }
-        wave_lds_fence();
-        double *rec = S.rec[tgt] + (size_t)kRec * P.view_slot[view];
-        for (int idx = lane; idx < kRec; idx += 64) {
-            double v;
-            if (idx < kRecEE) {
-                const int e = idx >> 4, f = idx & 15;
-                if (f >= 14) v = 0.0;
-                else { const int t = f_tile(f), m = f_mask(f); v = ((m & 1) ? MU[e * 16 + t] : 0.0) + ((m & 2) ? MV[e * 16 + t] : 0.0); }
-            } else if (idx >= kRecG && idx < kRecG + 6) {
-                const int e = idx - kRecG;
-                v = MU[e * 16 + 14] + MV[e * 16 + 14];
-            } else {
-                const int k = idx < kRecG ? idx - kRecEE : (idx - kRecG - 6) * 7;     // diagonal entry for the compact copy
-                const int e = k / 6, jj = k % 6;
-                if (jj < 3) v = MU[e * 16 + jj] + MV[e * 16 + jj];
-                else { const int l = jj - 3; v = cc[l] * (MU[e * 16 + 6] + MV[e * 16 + 6]) + cc[3 + l] * (MU[e * 16 + 7] + MV[e * 16 + 7]) + cc[6 + l] * (MU[e * 16 + 8] + MV[e * 16 + 8]); }
+                    for (int lp = 0; lp < 3; ++lp) {
+                        const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
+                        const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
+                        rec[kRecEE + 6 * kq + 3 + lp] = vlo;
+                        rec[kRecEE + 6 * (3 + kq) + 3 + lp] = vhi;
+                        if (lp == kq) rec[kRecG + 9 + kq] = vhi;                                        // diag, t_b part
+                    }
+                }
+                if (col == 14) { rec[kRecG + kq] = mT_lo; rec[kRecG + 3 + kq] = mT_hi; }                // compact E^T r
             }
-            rec[idx] = v;
         }
     }
-    double *part = S.campart + (size_t)512 * chunk;
+    // the four waves of the workgroup (same camera) sum their tiles through LDS in a fixed order
+    wave_lds_fence();
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) { part[(kq + 4 * rg) * 16 + col] = camU[rg]; part[256 + (kq + 4 * rg) * 16 + col] = camV[rg]; }
+    for (int rg = 0; rg < 4; ++rg) { lds[(kq + 4 * rg) * 16 + col] = camU[rg]; lds[256 + (kq + 4 * rg) * 16 + col] = camV[rg]; }
+    __syncthreads();
+    {
+        const int t = threadIdx.x;
+        const size_t st = P.lds_wave;
+        double *part = S.campart + (size_t)512 * blockIdx.x;
+        part[t] = (lds_all[t] + lds_all[st + t]) + (lds_all[2 * st + t] + lds_all[3 * st + t]);
+        part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
+    }
 }
 
-// per-camera raw tile (GU | GV) reduction, level 1: grid (C * kCamG1) x 256
-__global__ void k_cam_reduce1(DevProblem P, DevState S)
+// per-camera raw tile (GU | GV) reduction, level 1: one block per (camera, group)
+__device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int blk)
 {
-    if (S.ctrl->done) return;
-    const int cam = blockIdx.x / kCamG1, g = blockIdx.x % kCamG1;
+    const int cam = blk / kCamG1, g = blk % kCamG1;
     const int cb = P.cam_chunk_ptr[cam], ce = P.cam_chunk_ptr[cam + 1];
     const int n = ce - cb;
     const int per = (n + kCamG1 - 1) / kCamG1;
@@ -455,7 +473,7 @@ __global__ void k_cam_reduce1(DevProblem P, DevState S)
             a3 += src[(size_t)512 * (c + 3)];
         }
         for (; c < e; ++c) a0 += src[(size_t)512 * c];
-        S.campart2[(size_t)512 * blockIdx.x + 256 * half + t] = (a0 + a1) + (a2 + a3);
+        S.campart2[(size_t)512 * blk + 256 * half + t] = (a0 + a1) + (a2 + a3);
     }
 }
 
@@ -483,12 +501,10 @@ __device__ __forceinline__ double block_max256(double v, double *sm)
 
 // per-board gradient / norm statistics of the evaluation target (and, at iteration 0, the
 // Jacobi scaling of the board columns: s = 1/(1 + ||J_col||)).  grid ceil(B/256) x 256
-__global__ void k_board_stats(DevProblem P, DevState S, int cand, int init)
+__device__ void board_stats_block(const DevProblem &P, const DevState &S, int cand, int init, int blk, double *sm)
 {
-    if (S.ctrl->done) return;
-    __shared__ double sm[256];
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
-    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int b = blk * 256 + threadIdx.x;
     double gmax = 0.0, gsq = 0.0, xsq = 0.0;
     if (b < P.B) {
         const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
@@ -511,18 +527,36 @@ __global__ void k_board_stats(DevProblem P, DevState S, int cand, int init)
     const double m = block_max256(gmax, sm);
     const double s1 = block_sum256(gsq, sm);
     const double s2 = block_sum256(xsq, sm);
-    if (threadIdx.x == 0) { S.st_part[3 * blockIdx.x] = m; S.st_part[3 * blockIdx.x + 1] = s1; S.st_part[3 * blockIdx.x + 2] = s2; }
+    if (threadIdx.x == 0) { S.st_part[3 * blk] = m; S.st_part[3 * blk + 1] = s1; S.st_part[3 * blk + 2] = s2; }
+}
+
+// one launch for the two independent post-evaluation reductions:
+//   blocks [0, C*kCamG1)            level-1 sums of the per-workgroup camera tiles
+//   blocks [C*kCamG1, +ceil(B/256)) per-board gradient / norm statistics (+ Jacobi scaling at iteration 0)
+__global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, int cand, int init)
+{
+    if (S.ctrl->done) return;
+    __shared__ double sm[256];
+    const int nc = P.C * kCamG1;
+    if ((int)blockIdx.x < nc) cam_reduce1_block(P, S, blockIdx.x);
+    else board_stats_block(P, S, cand, init, blockIdx.x - nc, sm);
 }
 
 // level-2 camera reduction (raw u/v tiles -> [F|r]^T[F|r]) into H_stage + reduction of the per-block scalar partials.
 // grid (C + 1) x 256.  H_stage scal: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b ; M_stage[0] gmax_b
-__global__ void k_finalize_eval(DevProblem P, DevState S, int have_backsub)
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, double *sm);
+
+// fused_control: -1 = none (multi-GPU: the all-reduce sits between this kernel and k_control);
+// 0 / 1 = the last block to arrive also runs the LM control step with init = fused_control
+// (release/acquire hand-off at agent scope, arrival counter reset for the next launch).
+__global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S, int have_backsub, int fused_control)
 {
     if (S.ctrl->done) return;
     __shared__ double sm[256];
+    __shared__ double G[512];
+    __shared__ int s_last;
     const int t = threadIdx.x;
     if ((int)blockIdx.x < P.C) {
-        __shared__ double G[512];
         const int cam = blockIdx.x;
         for (int half = 0; half < 2; ++half) {
             double a = 0.0;
@@ -539,19 +573,37 @@ __global__ void k_finalize_eval(DevProblem P, DevState S, int have_backsub)
             if (m & 2) v += G[256 + ta * 16 + tb];
         }
         S.H_stage[256 * cam + t] = v;
-        return;
+    } else {
+        double mb = 0.0, ss = 0.0;
+        if (have_backsub) for (int i = t; i < S.n_bs_blocks; i += 256) { mb += S.bs_part[2 * i]; ss += S.bs_part[2 * i + 1]; }
+        double gm = 0.0, gs = 0.0, xs = 0.0;
+        for (int i = t; i < S.n_st_blocks; i += 256) { gm = fmax(gm, S.st_part[3 * i]); gs += S.st_part[3 * i + 1]; xs += S.st_part[3 * i + 2]; }
+        mb = block_sum256(mb, sm); ss = block_sum256(ss, sm); gs = block_sum256(gs, sm); xs = block_sum256(xs, sm);
+        gm = block_max256(gm, sm);
+        if (t == 0) {
+            double *sc = S.H_stage + 256 * P.C;
+            sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
+            S.M_stage[0] = gm;
+        }
     }
-    double mb = 0.0, ss = 0.0;
-    if (have_backsub) for (int i = t; i < S.n_bs_blocks; i += 256) { mb += S.bs_part[2 * i]; ss += S.bs_part[2 * i + 1]; }
-    double gm = 0.0, gs = 0.0, xs = 0.0;
-    for (int i = t; i < S.n_st_blocks; i += 256) { gm = fmax(gm, S.st_part[3 * i]); gs += S.st_part[3 * i + 1]; xs += S.st_part[3 * i + 2]; }
-    mb = block_sum256(mb, sm); ss = block_sum256(ss, sm); gs = block_sum256(gs, sm); xs = block_sum256(xs, sm);
-    gm = block_max256(gm, sm);
+    if (fused_control < 0) return;
+    // ---- last block to arrive runs the control step (cdna guide G16: release -> counter -> acquire) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (t == 0) {
-        double *sc = S.H_stage + 256 * P.C;
-        sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
-        S.M_stage[0] = gm;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(&S.ctrl->fin_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
     }
+    __syncthreads();
+    if (!s_last) return;
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&S.ctrl->fin_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    control_step(P, S, fused_control, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -648,33 +700,57 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
 // stay in registers (4 entries per lane per tile); every Y' record is read once per board.
 // The four waves' tiles are summed in a fixed order through LDS.   grid n_bchunks x 256
 template <int NV>
-__device__ __forceinline__ void board_gram_chunk(const DevProblem &P, const DevState &S, int chunk, double (*red)[256])
+__device__ __forceinline__ void board_gram_chunk(const DevProblem &P, const DevState &S, int chunk, double (*red)[256], double *stage)
 {
     constexpr int NT = NV * (NV + 1) / 2;
+    constexpr int NR = (NV * 96 + 63) / 64;          // raw doubles per lane for one board's records
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane & 15, bg = lane >> 4;
+    double *ly = stage + wave * (3 * 96);            // this wave's staging copy of the board's records
     double acc[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t][0] = 0.0; acc[t][1] = 0.0; acc[t][2] = 0.0; acc[t][3] = 0.0; }
     const int b1 = P.bc_end[chunk];
-    for (int bi = P.bc_begin[chunk] + wave; bi < b1; bi += 8) {
-        const double *Y = S.Y + (size_t)96 * P.sslot[bi];     // the board's NV records are contiguous
-        double ya[NV][6];
-        d4 yb[NV][6];
+    // The wave's board list (every 8th board of the chunk) is fetched 64 boards at a time and
+    // broadcast; each board's NV contiguous records are loaded fully coalesced ONE BOARD AHEAD into
+    // registers, passed through LDS, and read back as the (column a | 4 columns of group bg) operands.
+    for (int base = P.bc_begin[chunk] + wave; base < b1; base += 8 * 64) {
+        const int mine = base + 8 * lane;
+        const int myslot = mine < b1 ? P.sslot[mine] : 0;
+        const int nb = min(64, (b1 - base + 7) >> 3);
+        double raw[NR];
+        {
+            const double *Y = S.Y + (size_t)96 * __shfl(myslot, 0);
 #pragma unroll
-        for (int p = 0; p < NV; ++p) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { ya[p][k] = Y[96 * p + k * 16 + a]; yb[p][k] = *reinterpret_cast<const d4 *>(Y + 96 * p + k * 16 + 4 * bg); }
+            for (int r = 0; r < NR; ++r) raw[r] = (lane + 64 * r < NV * 96) ? Y[lane + 64 * r] : 0.0;
         }
-        int t = 0;
+        for (int jb = 0; jb < nb; ++jb) {
+            wave_lds_fence();
 #pragma unroll
-        for (int p = 0; p < NV; ++p) {
+            for (int r = 0; r < NR; ++r) if (lane + 64 * r < NV * 96) ly[lane + 64 * r] = raw[r];
+            if (jb + 1 < nb) {
+                const double *Y = S.Y + (size_t)96 * __shfl(myslot, jb + 1);
 #pragma unroll
-            for (int q = p; q < NV; ++q, ++t) {
+                for (int r = 0; r < NR; ++r) raw[r] = (lane + 64 * r < NV * 96) ? Y[lane + 64 * r] : 0.0;
+            }
+            wave_lds_fence();
+            double ya[NV][6];
+            d4 yb[NV][6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    acc[t][0] += ya[p][k] * yb[q][k][0]; acc[t][1] += ya[p][k] * yb[q][k][1];
-                    acc[t][2] += ya[p][k] * yb[q][k][2]; acc[t][3] += ya[p][k] * yb[q][k][3];
+            for (int p = 0; p < NV; ++p) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { ya[p][k] = ly[96 * p + k * 16 + a]; yb[p][k] = *reinterpret_cast<const d4 *>(ly + 96 * p + k * 16 + 4 * bg); }
+            }
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+#pragma unroll
+                for (int q = p; q < NV; ++q, ++t) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        acc[t][0] += ya[p][k] * yb[q][k][0]; acc[t][1] += ya[p][k] * yb[q][k][1];
+                        acc[t][2] += ya[p][k] * yb[q][k][2]; acc[t][3] += ya[p][k] * yb[q][k][3];
+                    }
                 }
             }
         }
@@ -696,11 +772,12 @@ __global__ __launch_bounds__(512) void k_board_gram(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
     __shared__ double red[8][256];
+    __shared__ __attribute__((aligned(16))) double stage[8 * 3 * 96];
     const int chunk = blockIdx.x;
     switch (P.bc_nv[chunk]) {
-    case 1: board_gram_chunk<1>(P, S, chunk, red); break;
-    case 2: board_gram_chunk<2>(P, S, chunk, red); break;
-    case 3: board_gram_chunk<3>(P, S, chunk, red); break;
+    case 1: board_gram_chunk<1>(P, S, chunk, red, stage); break;
+    case 2: board_gram_chunk<2>(P, S, chunk, red, stage); break;
+    case 3: board_gram_chunk<3>(P, S, chunk, red, stage); break;
     default: break;      // boards seen by more than three cameras go through k_pair_gram
     }
 }
@@ -917,21 +994,42 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     }
     __syncthreads();
     if (tid < 64) {
+        // blocked back-substitution, TS unknowns per step: all lanes solve the TS x TS upper-triangular
+        // diagonal system redundantly (operands by broadcast), then lane i applies the TS columns to w[i]
         constexpr int R = N / 64;
-        double w[R], idg[R];
+        double w[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) { w[q] = wp[tid + 64 * q]; idg[q] = 1.0 / Lm[(tid + 64 * q) * LD + tid + 64 * q]; }
-        for (int k = N - 1; k >= 0; --k) {
-            const int q = k >> 6, src = k & 63;
-            double wk = 0.0, ik = 0.0;
+        for (int q = 0; q < R; ++q) w[q] = wp[tid + 64 * q];
+        for (int tk = 15; tk >= 0; --tk) {
+            const int k0 = tk * TS;
+            double y[TS];
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) if (qq == q) { wk = w[qq]; ik = idg[qq]; }
-            const double yk = __shfl(wk * ik, src);
+            for (int c = 0; c < TS; ++c) {
+                const int k = k0 + c;
+                double v = 0.0;
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) {
-                const int i = tid + 64 * qq;
-                if (i < k) w[qq] -= Lm[k * LD + i] * yk;
-                else if (i == k) w[qq] = yk;
+                for (int q = 0; q < R; ++q) if ((k >> 6) == q) v = w[q];
+                y[c] = __shfl(v, k & 63);
+            }
+#pragma unroll
+            for (int c = TS - 1; c >= 0; --c) {
+                double v = y[c];
+#pragma unroll
+                for (int q = c + 1; q < TS; ++q) v -= Lm[(k0 + q) * LD + k0 + c] * y[q];
+                y[c] = v / Lm[(k0 + c) * LD + k0 + c];
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int i = tid + 64 * q;
+                if (i < k0) {
+                    double v = w[q];
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) v -= Lm[(k0 + c) * LD + i] * y[c];
+                    w[q] = v;
+                } else if (i < k0 + TS) {
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) if (i == k0 + c) w[q] = y[c];
+                }
             }
         }
 #pragma unroll
@@ -1046,11 +1144,10 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
 // one thread.  `init` = IterationZero; otherwise the tail of one loop iteration followed by
 // FinalizeIterationAndCheckIfMinimizerCanContinue.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int init)
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, double *sm)
 {
     Ctrl &c = *S.ctrl;
     if (c.done) return;
-    __shared__ double sm[256];
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
     const int t = threadIdx.x;
@@ -1159,6 +1256,12 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
     if (it.iteration >= o.max_num_iterations) { c.done = 1; c.term_type = 1; c.term_reason = kMaxIter; return; }
     if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { c.done = 1; c.term_type = 0; c.term_reason = kGradTol; return; }
     if (c.radius <= o.min_radius) { c.done = 1; c.term_type = 0; c.term_reason = kMinRadius; return; }
+}
+
+__global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int init)
+{
+    __shared__ double sm[256];
+    control_step(P, S, init, sm);
 }
 
 // ---------------------------------------------------------------------------------------------

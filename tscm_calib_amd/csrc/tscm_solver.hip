@@ -212,11 +212,12 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     // (= 2 * odd: the 16 columns x 2 rows of a 32-lane ds_read_b64 group then hit 32 distinct bank pairs)
     const int half_rows = 4 * ((std::min(64, p->n_points) + 3) / 4);
     const int rp = half_rows + 2;      // = 2 * odd (half_rows is a multiple of 4)
-    const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)kTcols * rp, 704) + kCst + 2 * (size_t)p->n_points);
-    if (lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval_bytes));
-    int waves_per_cu = 0;       // resident single-wave workgroups per CU (register- and LDS-limited)
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, reinterpret_cast<const void *>(k_eval_gram), 64, lds_eval_bytes));
-    waves_per_cu = std::max(1, std::min(16, waves_per_cu));
+    const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)kTcols * rp, 512) + kCst + 2 * (size_t)p->n_points);
+    // k_eval_gram runs 4 single-chunk waves per workgroup (they share only the final camera-tile sum)
+    if (4 * lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_eval_bytes)));
+    int wgs_per_cu = 0;         // resident workgroups per CU (register- and LDS-limited)
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void *>(k_eval_gram), 256, 4 * lds_eval_bytes));
+    const int waves_per_cu = 4 * std::max(1, std::min(4, wgs_per_cu));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     const int target_chunks = std::max(64, prop.multiProcessorCount * waves_per_cu - 4 * C);
@@ -225,13 +226,14 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     {
         int i = 0;
         for (int m = 0; m < C; ++m) {
-            cam_chunk_ptr[m] = (int)chunk_vb.size();
+            cam_chunk_ptr[m] = (int)chunk_vb.size() / 4;     // in workgroups
             int e = i;
             while (e < V && view_cam[e] == m) ++e;
             for (int b0 = i; b0 < e; b0 += per_chunk) { chunk_vb.push_back(b0); chunk_ve.push_back(std::min(e, b0 + per_chunk)); chunk_cam.push_back(m); }
+            while (chunk_vb.size() % 4) { chunk_vb.push_back(e); chunk_ve.push_back(e); chunk_cam.push_back(m); }   // empty chunks: whole workgroups per camera
             i = e;
         }
-        cam_chunk_ptr[C] = (int)chunk_vb.size();
+        cam_chunk_ptr[C] = (int)chunk_vb.size() / 4;
     }
     // ---- board -> views (device order => increasing camera) --------------------------------------
     std::vector<int> bv_ptr(B + 1, 0), bv_idx(V);
@@ -340,7 +342,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     DevProblem &P = s->P;
     DevState &S = s->S;
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
-    P.rp = rp; P.half = half_rows;
+    P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double));
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
     P.n_bchunks = (int)bc_begin.size(); P.n_tiles = n_tiles;
     std::vector<double> bxy(p->board_xy, p->board_xy + 2 * (size_t)p->n_points);
@@ -394,7 +396,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_alloc(s, &S.cam_pc, (size_t)kCamConst * C))) return rc;
     if ((rc = dev_alloc(s, &S.vconst, (size_t)kVConst * V))) return rc;
     if ((rc = dev_alloc(s, &S.cconst, (size_t)kCConst * C))) return rc;
-    if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)P.n_chunks))) return rc;
+    if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)(P.n_chunks / 4)))) return rc;
     if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C * kCamG1))) return rc;
     if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal))) return rc;
     if ((rc = dev_alloc(s, &S.M_stage, 8))) return rc;
@@ -419,7 +421,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
-    s->lds_eval = lds_eval_bytes;
+    s->lds_eval = 4 * lds_eval_bytes;
     { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + NN * TT + TT * TT + 4 * NN); }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
@@ -465,7 +467,7 @@ static int launch_eval(tscm_solver *s, int cand)
         e0 = s->ev[s->ev_used].first; e1 = s->ev[s->ev_used].second; ++s->ev_used;
         HIP_TRY(hipEventRecord(e0, s->stream));
     }
-    hipLaunchKernelGGL(k_eval_gram, dim3(P.n_chunks), dim3(64), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
+    hipLaunchKernelGGL(k_eval_gram, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
     if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
 }
@@ -498,16 +500,15 @@ static int enqueue_eval(tscm_solver *s, int cand, int init, int have_backsub)
     DevState &S = s->S;
     hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + 255) / 256), dim3(256), 0, s->stream, P, S, cand);
     if (int rc = launch_eval(s, cand)) return rc;
-    hipLaunchKernelGGL(k_cam_reduce1, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S);
-    if (S.n_st_blocks) hipLaunchKernelGGL(k_board_stats, dim3(S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
-    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1 + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
+    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub, s->comm ? -1 : init);
     if (s->comm) {
         NCCL_TRY(ncclGroupStart());
         NCCL_TRY(ncclAllReduce(S.H_stage, S.H_stage, 256 * (size_t)P.C + kScal, ncclDouble, ncclSum, s->comm->comm, s->stream));
         NCCL_TRY(ncclAllReduce(S.M_stage, S.M_stage, 1, ncclDouble, ncclMax, s->comm->comm, s->stream));
         NCCL_TRY(ncclGroupEnd());
     }
-    hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, P, S, init);
+    if (s->comm) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, P, S, init);   // single GPU: fused into k_finalize_eval
     return 0;
 }
 
@@ -747,8 +748,8 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     const DevProblem &P = s->P;
     DevState &S = s->S;
     if ((rc = launch_eval(s, 0))) return rc;
-    hipLaunchKernelGGL(k_cam_reduce1, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S);
-    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C), dim3(256), 0, s->stream, P, S, 0);   // camera blocks only
+    hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S, 0, 0);   // camera blocks only
+    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C), dim3(256), 0, s->stream, P, S, 0, -1);        // camera blocks only
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipGetLastError());
     std::vector<double> rec((size_t)kRec * s->V), H(256 * (size_t)s->C);
