@@ -842,12 +842,13 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
 //   A = S_c (H_cc - T) S_c + D_c^2, rhs = S_c (g_c - t_r); inactive columns (tile padding,
 //   constant camera pose, cameras without views) become identity rows.
 // Blocked right-looking Cholesky with the matrix held in REGISTERS: thread (ti, tj) owns the
-// TS x TS tile (TS = N/16).  Per panel: (1) the diagonal thread factors its tile and forward-
-// substitutes its slice of the rhs, (2) the threads below it solve their tile against L_kk^T,
-// (3) everybody applies the rank-TS update -- two barriers per panel, 32 in total.
+// TS x TS tile (TS = N/16).  Per panel: the diagonal thread factors and inverts its tile and forward-
+// substitutes its slice of the rhs while the column threads publish their raw tiles; after ONE
+// barrier every trailing thread forms the needed X = A L_kk^{-T} tiles itself and applies the rank-TS
+// update -- 16 barriers in total.
 // Back-substitution: one wave, w in registers, rows of L streamed from LDS.  Writes
 // yhat = S_c y (camera step = -yhat) and the candidate camera parameters.
-// grid 1 x 256, dynamic LDS N*(N+1) + N*TS + TS*TS + 4*N doubles.
+// grid 1 x 256, dynamic LDS N*(N+1) + 2*N*TS + 2*TS*TS + 2*TS + 5*N doubles.
 // ---------------------------------------------------------------------------------------------
 template <int TS>
 __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
@@ -857,12 +858,14 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     constexpr int LD = N + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Lm = lds;                 // [N][LD] lower factor (for the back-substitution)
-    double *Xb = Lm + N * LD;         // [N][TS] panel column  L[:, panel]
-    double *Ld = Xb + N * TS;         // [TS][TS] factor of the diagonal tile
-    double *wp = Ld + TS * TS;        // [N] forward-substituted rhs  w = L^{-1} b
+    double *Xb = Lm + N * LD;         // [2][N][TS] raw panel column (double-buffered)
+    double *Ld = Xb + 2 * N * TS;     // [2][TS][TS] inverse of the diagonal factor
+    double *wq = Ld + 2 * TS * TS;    // [2][TS] rhs slice of the panel
+    double *wp = wq + 2 * TS;         // [N] forward-substituted rhs  w = L^{-1} b
     double *yv = wp + N;              // [N]
     double *s_sc = yv + N;            // [N]
     double *s_yh = s_sc + N;          // [N]
+    double *idg = s_yh + N;           // [N] 1 / L_kk
     __shared__ int s_fail;
     __shared__ unsigned char s_act[N];
     __shared__ double sred[256];
@@ -905,10 +908,22 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
             if (s_act[i]) { const int mj = i >> 4, b = i & 15; bd[r] = s_sc[i] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)i * n + mj * 16 + kFR]); }
         }
     }
-    // ---- factorisation ------------------------------------------------------------------------
+    // ---- factorisation: ONE barrier per panel ------------------------------------------------------
+    // before the barrier of panel tk: the column threads (ti > tk, tj == tk) publish their raw tiles,
+    // the diagonal thread factors its tile, inverts the 4x4 / 8x8 factor and forward-substitutes its
+    // rhs slice; after it every trailing thread forms X_i = A_i L_kk^{-T}, X_j itself and applies the
+    // rank-TS update (LDS buffers alternate between panels, so no second barrier is needed).
     for (int tk = 0; tk < 16; ++tk) {
+        double *Ar = Xb + (tk & 1) * (N * TS);          // raw panel column  [N][TS]
+        double *Li = Ld + (tk & 1) * (TS * TS);         // inverse of the diagonal factor (lower)
+        double *wk = wq + (tk & 1) * TS;                // w slice of the panel
+        if (tj == tk && ti > tk) {
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c) Ar[(ti * TS + r) * TS + c] = a[r][c];
+        }
         if (ti == tk && tj == tk) {
-            // (1) Cholesky of the diagonal tile + forward substitution of its rhs slice
             double il[TS];
 #pragma unroll
             for (int c = 0; c < TS; ++c) {
@@ -916,9 +931,8 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
 #pragma unroll
                 for (int q = 0; q < c; ++q) d -= a[c][q] * a[c][q];
                 if (!(d > 0.0)) { s_fail = 1; d = 1.0; }
-                double sd, isd;
-                sqrt_and_inverse(d, sd, isd);
-                a[c][c] = sd; il[c] = isd;
+                const double isd = fast_rsqrt(d);      // this thread is the critical path of the whole kernel
+                a[c][c] = d * isd; il[c] = isd;
 #pragma unroll
                 for (int r = c + 1; r < TS; ++r) {
                     double v = a[r][c];
@@ -927,63 +941,92 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
                     a[r][c] = v * isd;
                 }
             }
+            // forward substitution of the rhs slice
 #pragma unroll
             for (int c = 0; c < TS; ++c) {
                 double w = bd[c];
 #pragma unroll
                 for (int q = 0; q < c; ++q) w -= a[c][q] * bd[q];
                 bd[c] = w * il[c];
+                wk[c] = bd[c];
                 wp[tk * TS + c] = bd[c];
+                idg[tk * TS + c] = il[c];
             }
+            // inverse of the lower-triangular factor, column by column
+            double inv[TS][TS];
 #pragma unroll
-            for (int r = 0; r < TS; ++r)
-#pragma unroll
-                for (int c = 0; c < TS; ++c) Ld[r * TS + c] = (c < r) ? a[r][c] : (c == r ? il[r] : 0.0);   // diag slot holds 1/L_rr
-        }
-        __syncthreads();
-        if (tj == tk && ti > tk) {
-            // (2) X = A_tile L_kk^{-T}
-#pragma unroll
-            for (int r = 0; r < TS; ++r) {
-#pragma unroll
-                for (int c = 0; c < TS; ++c) {
-                    double v = a[r][c];
-#pragma unroll
-                    for (int q = 0; q < c; ++q) v -= a[r][q] * Ld[c * TS + q];
-                    a[r][c] = v * Ld[c * TS + c];
-                    Xb[(ti * TS + r) * TS + c] = a[r][c];
-                }
-            }
-        }
-        __syncthreads();
-        if (ti > tk && tj > tk && tj <= ti) {
-            // (3) trailing update  A_ij -= X_i X_j^T ;  rhs slice  b_i -= X_i w_k
-            double xi[TS][TS], xj[TS][TS];
-#pragma unroll
-            for (int r = 0; r < TS; ++r)
-#pragma unroll
-                for (int q = 0; q < TS; ++q) { xi[r][q] = Xb[(ti * TS + r) * TS + q]; xj[r][q] = Xb[(tj * TS + r) * TS + q]; }
-#pragma unroll
-            for (int r = 0; r < TS; ++r)
-#pragma unroll
-                for (int c = 0; c < TS; ++c) {
-                    double v = a[r][c];
-#pragma unroll
-                    for (int q = 0; q < TS; ++q) v -= xi[r][q] * xj[c][q];
-                    a[r][c] = v;
-                }
-            if (ti == tj) {
+            for (int c = 0; c < TS; ++c) {
 #pragma unroll
                 for (int r = 0; r < TS; ++r) {
-                    double v = bd[r];
+                    if (r < c) { inv[r][c] = 0.0; continue; }
+                    double v = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-                    for (int q = 0; q < TS; ++q) v -= xi[r][q] * wp[tk * TS + q];
-                    bd[r] = v;
+                    for (int q = c; q < r; ++q) v -= a[r][q] * inv[q][c];
+                    inv[r][c] = v * il[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c) Li[r * TS + c] = inv[r][c];
+        }
+        __syncthreads();
+        if (ti > tk && tj >= tk && tj <= ti) {
+            // X_i = A_i L_kk^{-T}:  X[r][c] = sum_{q <= c} A[r][q] * inv[c][q]
+            double xi[TS][TS];
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q <= c; ++q) v += Ar[(ti * TS + r) * TS + q] * Li[c * TS + q];
+                    xi[r][c] = v;
+                }
+            if (tj == tk) {
+                // my tile IS the panel column: keep the final factor entries
+#pragma unroll
+                for (int r = 0; r < TS; ++r)
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) a[r][c] = xi[r][c];
+            } else {
+                double xj[TS][TS];
+                if (ti == tj) {
+#pragma unroll
+                    for (int r = 0; r < TS; ++r)
+#pragma unroll
+                        for (int c = 0; c < TS; ++c) xj[r][c] = xi[r][c];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < TS; ++r)
+#pragma unroll
+                        for (int c = 0; c < TS; ++c) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int q = 0; q <= c; ++q) v += Ar[(tj * TS + r) * TS + q] * Li[c * TS + q];
+                            xj[r][c] = v;
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < TS; ++r)
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) {
+                        double v = a[r][c];
+#pragma unroll
+                        for (int q = 0; q < TS; ++q) v -= xi[r][q] * xj[c][q];
+                        a[r][c] = v;
+                    }
+                if (ti == tj) {
+#pragma unroll
+                    for (int r = 0; r < TS; ++r) {
+                        double v = bd[r];
+#pragma unroll
+                        for (int q = 0; q < TS; ++q) v -= xi[r][q] * wk[q];
+                        bd[r] = v;
+                    }
                 }
             }
         }
-        // no barrier needed here: the next panel's diagonal thread only touches its own registers
-        // before the next barrier, and Xb / Ld / wp are rewritten only after it.
     }
     // ---- publish L, back-substitute L^T y = w with one wave -----------------------------------------
     if (tj <= ti) {
@@ -1016,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
                 double v = y[c];
 #pragma unroll
                 for (int q = c + 1; q < TS; ++q) v -= Lm[(k0 + q) * LD + k0 + c] * y[q];
-                y[c] = v / Lm[(k0 + c) * LD + k0 + c];
+                y[c] = v * idg[k0 + c];
             }
 #pragma unroll
             for (int q = 0; q < R; ++q) {

@@ -422,7 +422,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
     s->lds_eval = 4 * lds_eval_bytes;
-    { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + NN * TT + TT * TT + 4 * NN); }
+    { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 5 * NN); }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
     HIP_TRY(hipDeviceSynchronize());
