@@ -245,12 +245,12 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
 // dynamic LDS: kTcols*rp + kCst + 2*n_points doubles.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
+__global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
 {
     if (S.ctrl->done) return;
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps chunk/view/cnt in SGPRs
     double *lds = lds_all + (size_t)wave * P.lds_wave;     // every wave works in its own LDS region
     const int RP = P.rp, HV = P.half;          // pitch = 2*odd >= HV: conflict-free ds_read_b64
     double *Fl = lds;                          // [kTcols][RP]: HV rows; holds the u-rows, then the v-rows
