@@ -272,6 +272,25 @@ def test_eight_camera_rig(hip_device):
     assert np.max(np.abs(g["cam_gram"] - o["cam_gram"])) <= 1e-11 * np.abs(o["cam_gram"]).max()
 
 
+def test_rccl_code_path_single_rank(hip_device, monkeypatch):
+    """The multi-GPU code path (RCCL all-reduce of T, grouped sum/max all-reduce of the staged camera
+    tiles, separate k_control) on a one-rank communicator: must reproduce the single-GPU path bit for bit."""
+    p = H.small_rig(4, 10, seed=33)
+    ref = p.copy().normalised()
+    with api.Solver(ref) as s:
+        rs = s.solve()
+    monkeypatch.setenv("TSCM_FORCE_COMM", "1")
+    comm = api.Comm(api.Comm.unique_id(), 0, 1, 0)
+    q = p.copy().normalised()
+    with api.Solver(q) as s:
+        s.set_comm(comm)
+        qs = s.solve()
+        s.set_comm(None)
+    comm.close()
+    assert qs["num_iterations"] == rs["num_iterations"] and qs["message"] == rs["message"]
+    assert np.array_equal(q.intr, ref.intr) and np.array_equal(q.cam_rt, ref.cam_rt) and np.array_equal(q.board_rt, ref.board_rt)
+
+
 def test_invalid_arguments(hip_device):
     from tscm_calib_amd.lib import TscmError
     p = H.small_rig(4, 4, seed=1)

@@ -434,7 +434,10 @@ extern "C" int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm)
 {
     if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
     if (comm && comm->device != s->device) return fail(TSCM_E_INVALID, "communicator and solver live on different devices");
-    s->comm = (comm && comm->world > 1) ? comm : nullptr;
+    // a single-rank communicator is a no-op; TSCM_FORCE_COMM=1 keeps it anyway so that the RCCL code path
+    // (separate k_control, stream-ordered all-reduces) can be exercised on one GPU
+    const bool force = std::getenv("TSCM_FORCE_COMM") != nullptr;
+    s->comm = (comm && (comm->world > 1 || force)) ? comm : nullptr;
     return 0;
 }
 
