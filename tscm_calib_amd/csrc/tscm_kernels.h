@@ -243,8 +243,9 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 // lane = corner (coalesced SoA loads of u[], v[]), board points and all wave-uniform constants in
 // LDS, Jacobian columns transposed through LDS (column-major, pitch 130: conflict-free
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
-// dynamic LDS: kTcols*rp + kCst + 2*n_points doubles.
+// dynamic LDS: 16*rp + kCst + 2*n_points doubles.
 // ---------------------------------------------------------------------------------------------
+template <int RPC>   // RPC > 0: compile-time LDS pitch (HV = RPC - 2): all tile offsets become immediates
 __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
 {
     if (S.ctrl->done) return;
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps chunk/view/cnt in SGPRs
     double *lds = lds_all + (size_t)wave * P.lds_wave;     // every wave works in its own LDS region
-    const int RP = P.rp, HV = P.half;          // pitch = 2*odd >= HV: conflict-free ds_read_b64
+    const int RP = RPC > 0 ? RPC : P.rp, HV = RPC > 0 ? RPC - 2 : P.half;   // pitch = 2*odd >= HV: conflict-free ds_read_b64
     double *Fl = lds;                          // [kTcols][RP]: HV rows; holds the u-rows, then the v-rows
-    double *cst = Fl + max(kTcols * RP, 512);  // [kCst]  (512 = final camera-tile exchange, for tiny boards)
+    double *cst = Fl + max(16 * RP, 512);      // [kCst]  (column 15 of Fl stays zero; 512 = final camera-tile exchange)
     double *bxy = cst + kCst;
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
@@ -265,6 +266,18 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
     const double *cc = cst + kVConst;          // camera constants
+    // rows of lanes without a corner are kept at zero instead of being re-written every pass
+    if (lane < HV) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) Fl[c * RP + lane] = 0.0;      // incl. the all-zero 16th tile column
+    }
+    int prev_nv = 0;                           // lanes [nv, prev_nv) hold stale rows of the previous pass
+    // lane-constant byte offsets of this lane's record entries (see the epilogue)
+    const unsigned oA = 8u * (unsigned)(col <= 2 ? kRecEE + 6 * kq + col
+                                      : col <= 8 ? 16 * kq + col - 3
+                                      : col == 9 ? 16 * kq + 6 : col == 10 ? 16 * kq + 8
+                                      : col <= 14 ? 16 * kq + col - 1 : 16 * kq + 14);
+    const unsigned oB = 8u * (unsigned)(kRecEE + 6 * kq + 3);
     // software prefetch: the next view's constants and first 64 observations are loaded while
     // the current view computes (one wave per SIMD-slot cannot hide HBM latency otherwise)
     double pf_c = 0.0, pf_u = 0.0, pf_v = 0.0;
@@ -354,39 +367,39 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 // residual = observed - projected (multi_calib.h:192-193)
                 fu[14 * RP] = ou - (fx * mx + cc[41]);
                 fv[14] = ov - (fy * my + cc[42]);
-            } else if (lane < HV) {
+            } else if (lane < prev_nv) {
 #pragma unroll
-                for (int c = 0; c < kTcols; ++c) { fu[c * RP] = 0.0; fv[c] = 0.0; }
+                for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.0;
             }
             wave_lds_fence();
             const int nv = min(64, cnt - c0);
+            prev_nv = nv;
             const int ksteps = (nv + 3) >> 2;
-            // rows past the last corner are zero (every lane < HV wrote its row), so the loops run in
+            // rows past the last corner are zero, so the loops run in
             // pairs of k-steps; operands of the next pair are fetched while the current MFMAs issue
-            const double *fp = Fl + (col < kTcols ? col : 0) * RP + kq;
-            const bool live = col < kTcols;
+            const double *fp = Fl + col * RP + kq;      // lane (col, kq) feeds tile column col, row 4t + kq
             const int tmax = (HV >> 2) - 2;
             {
-                double a0 = live ? fp[0] : 0.0, a1 = live ? fp[4] : 0.0;
+                double a0 = fp[0], a1 = fp[4];
                 for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
                     const int tn = min(t + 2, tmax);
-                    const double n0 = live ? fp[4 * tn] : 0.0, n1 = live ? fp[4 * tn + 4] : 0.0;
+                    const double n0 = fp[4 * tn], n1 = fp[4 * tn + 4];
                     accU = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, accU, 0, 0, 0);
                     accU = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accU, 0, 0, 0);
                     a0 = n0; a1 = n1;
                 }
             }
             wave_lds_fence();
-            if (lane < HV) {
+            if (valid) {
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = fv[c];
             }
             wave_lds_fence();
             {
-                double a0 = live ? fp[0] : 0.0, a1 = live ? fp[4] : 0.0;
+                double a0 = fp[0], a1 = fp[4];
                 for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
                     const int tn = min(t + 2, tmax);
-                    const double n0 = live ? fp[4 * tn] : 0.0, n1 = live ? fp[4 * tn + 4] : 0.0;
+                    const double n0 = fp[4 * tn], n1 = fp[4 * tn + 4];
                     accV = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, accV, 0, 0, 0);
                     accV = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, accV, 0, 0, 0);
                     a0 = n0; a1 = n1;
@@ -411,18 +424,17 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
             const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8; // their u-row parts
             const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
             const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
-            double *rec = S.rec[tgt] + (size_t)kRec * P.view_slot[view];
+            char *rec = reinterpret_cast<char *>(S.rec[tgt] + (size_t)kRec * P.view_slot[view]);   // wave-uniform base
+            auto st = [&](unsigned byte_off, double v) { *reinterpret_cast<double *>(rec + byte_off) = v; };
             if (kq < 3) {
-                double *lo = rec + 16 * kq, *hi = rec + 16 * (3 + kq);
-                if (col >= 3 && col <= 8) { lo[col - 3] = mT_lo; hi[col - 3] = mT_hi; }                 // w_c, t_c
-                else if (col == 9) { lo[6] = mU_lo; hi[6] = mU_hi; lo[7] = mT_lo - mU_lo; hi[7] = mT_hi - mU_hi; }   // fx | fy
-                else if (col == 10) { lo[8] = mU_lo; hi[8] = mU_hi; lo[9] = mT_lo - mU_lo; hi[9] = mT_hi - mU_hi; }  // cx | cy
-                else if (col >= 11 && col <= 14) { lo[col - 1] = mT_lo; hi[col - 1] = mT_hi; }          // xi lambda alpha r
-                else if (col == 15) { lo[14] = 0.0; lo[15] = 0.0; hi[14] = 0.0; hi[15] = 0.0; }
+                if (col >= 3 && col <= 8) { st(oA, mT_lo); st(oA + 384, mT_hi); }                       // w_c, t_c
+                else if (col == 9 || col == 10) {                                                       // fx | fy , cx | cy
+                    st(oA, mU_lo); st(oA + 8, mT_lo - mU_lo); st(oA + 384, mU_hi); st(oA + 392, mT_hi - mU_hi);
+                } else if (col >= 11 && col <= 14) { st(oA, mT_lo); st(oA + 384, mT_hi); }              // xi lambda alpha r
+                else if (col == 15) { st(oA, 0.0); st(oA + 8, 0.0); st(oA + 384, 0.0); st(oA + 392, 0.0); }
                 else {                                                                                  // col 0..2: E^T E, w_b columns
-                    rec[kRecEE + 6 * kq + col] = mT_lo;
-                    rec[kRecEE + 6 * (3 + kq) + col] = mT_hi;
-                    if (col == kq) rec[kRecG + 6 + kq] = mT_lo;                                         // diag(E^T E), w_b part
+                    st(oA, mT_lo); st(oA + 144, mT_hi);
+                    if (col == kq) st(8 * (kRecG + 6) + 8 * kq, mT_lo);                                 // diag(E^T E), w_b part
                 }
                 if (col == 6) {
                     // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]
@@ -430,12 +442,12 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                     for (int lp = 0; lp < 3; ++lp) {
                         const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
                         const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
-                        rec[kRecEE + 6 * kq + 3 + lp] = vlo;
-                        rec[kRecEE + 6 * (3 + kq) + 3 + lp] = vhi;
-                        if (lp == kq) rec[kRecG + 9 + kq] = vhi;                                        // diag, t_b part
+                        st(oB + 8 * lp, vlo);
+                        st(oB + 144 + 8 * lp, vhi);
+                        if (lp == kq) st(8 * (kRecG + 9) + 8 * kq, vhi);                                // diag, t_b part
                     }
                 }
-                if (col == 14) { rec[kRecG + kq] = mT_lo; rec[kRecG + 3 + kq] = mT_hi; }                // compact E^T r
+                if (col == 14) { st(8 * kRecG + 8 * kq, mT_lo); st(8 * (kRecG + 3) + 8 * kq, mT_hi); }  // compact E^T r
             }
         }
     }

@@ -212,11 +212,11 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     // (= 2 * odd: the 16 columns x 2 rows of a 32-lane ds_read_b64 group then hit 32 distinct bank pairs)
     const int half_rows = 4 * ((std::min(64, p->n_points) + 3) / 4);
     const int rp = half_rows + 2;      // = 2 * odd (half_rows is a multiple of 4)
-    const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)kTcols * rp, 512) + kCst + 2 * (size_t)p->n_points);
+    const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)16 * rp, 512) + kCst + 2 * (size_t)p->n_points);
     // k_eval_gram runs 4 single-chunk waves per workgroup (they share only the final camera-tile sum)
-    if (4 * lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_eval_bytes)));
+    if (4 * lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_eval_bytes)));
     int wgs_per_cu = 0;         // resident workgroups per CU (register- and LDS-limited)
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void *>(k_eval_gram), 256, 4 * lds_eval_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void *>(rp == 58 ? k_eval_gram<58> : k_eval_gram<0>), 256, 4 * lds_eval_bytes));
     const int waves_per_cu = 4 * std::max(1, std::min(4, wgs_per_cu));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -470,7 +470,9 @@ static int launch_eval(tscm_solver *s, int cand)
         e0 = s->ev[s->ev_used].first; e1 = s->ev[s->ev_used].second; ++s->ev_used;
         HIP_TRY(hipEventRecord(e0, s->stream));
     }
-    hipLaunchKernelGGL(k_eval_gram, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
+    // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
+    if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
+    else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
     if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
 }
