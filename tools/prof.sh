@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): bash tools_prof.sh <tag> [bench args]
+# usage (on the GPU box, via gpurun): bash tools/prof.sh <tag> [bench args]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 10 --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
