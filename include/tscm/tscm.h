@@ -214,6 +214,43 @@ void tscm_comm_destroy(tscm_comm *c);
 /* owner[b] = rank owning board b: contiguous ranges balanced by corner count.       */
 int tscm_shard_frames(const tscm_problem *problem, int world, int *owner);
 
+
+/* ------------------------------------------------------------------ rig initialisation
+ * tscm_rig_init = the constructor MultiCalib::MultiCalib(cameras, worlds) (multi_calib.cpp:6-153),
+ * the step right before calibrate(): camera i is chained to camera i-1 through every board both
+ * see; each common board gives a pose hypothesis and the one with the smallest summed reprojection
+ * error over ALL common boards and both cameras wins (:50-85 -- quadratic in the number of common
+ * boards, 2.7e9 projections per camera pair at 10k views/camera: the GPU part); every board pose is
+ * then chosen the same way among the cameras that see it (:90-151).  Semantics kept: Rt_to_R_t
+ * builds R from float32 copies of r1, r2 and their float cross product (multi_calib.h:130-137),
+ * TripleSphereCamera::ReprojectError is the SUM of pixel errors with the skew projection
+ * (TS.h:58-69), strict `<` keeps the first minimum, rt_ = [cv::Rodrigues(R), t]
+ * (multi_calib.h:16-18, 94-96).  The error sums are reduced in a different (tree) order than the
+ * reference's sequential loop, so exact ties / 1-ulp near-ties may pick another hypothesis.
+ * Adjacent cameras without a common board (undefined behaviour in the reference, :51/:86) ->
+ * TSCM_E_INVALID.                                                                             */
+typedef struct tscm_rig_input {
+    int n_cameras, n_boards, n_points;
+    const double *worlds;          /* [n_points*3] board points x, y, z                          */
+    const double *intr;            /* [C*9]                                                      */
+    const unsigned char *has;      /* [C*B] has_chessboard(j) of camera m                        */
+    const double *Rt;              /* [C*B*9] row-major 3x3 [r1 r2 t] = TripleSphereCamera::Rt(j) */
+    const double *pix_u, *pix_v;   /* [C*B*n_points] pixels()[j] (read only where has)           */
+} tscm_rig_input;
+
+typedef struct tscm_rig_result {
+    double *cam_R, *cam_t, *cam_rt;        /* [C*9] row-major, [C*3], [C*6]  (host, caller-owned) */
+    double *board_R, *board_t, *board_rt;  /* [B*9], [B*3], [B*6]                                 */
+    unsigned char *board_initial;          /* [B] is_initial()                                     */
+    int *cam_choice;                       /* [C] winning hypothesis (index among the common boards) or NULL */
+    double *cam_min_error;                 /* [C] its summed error, or NULL                        */
+    double seconds_hypotheses;             /* device time of the camera-chaining kernels           */
+    double seconds_total;
+    long long n_projections;               /* point projections evaluated on the device            */
+} tscm_rig_result;
+
+int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_result *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,10 +17,9 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "tscm_oracle.c")
-    hdr = os.path.join(_HERE, "tscm_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("tscm_oracle.c", "tscm_oracle_rig.c", "tscm_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in (src, hdr))
+        os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"])
     return _LIB_PATH
@@ -64,6 +63,14 @@ class OrcSummary(C.Structure):
     ]
 
 
+class OrcRigInput(C.Structure):
+    _fields_ = [
+        ("n_cameras", C.c_int), ("n_boards", C.c_int), ("n_points", C.c_int),
+        ("worlds", C.c_void_p), ("intr", C.c_void_p), ("has", C.c_void_p), ("Rt", C.c_void_p),
+        ("pix_u", C.c_void_p), ("pix_v", C.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -90,6 +97,12 @@ def lib():
         L.orc_mean_reprojection_error.restype = C.c_double
         L.orc_rmse.argtypes = [C.POINTER(OrcProblem)]
         L.orc_rmse.restype = C.c_double
+        L.orc_rig_init.argtypes = [C.POINTER(OrcRigInput), dp, dp, dp, dp, dp, dp, C.c_void_p, C.c_void_p, dp]
+        L.orc_rig_init.restype = C.c_int
+        L.orc_rodrigues_inverse.argtypes = [dp, dp]
+        L.orc_rig_hypothesis_errors.argtypes = [C.POINTER(OrcRigInput), C.c_int, dp, dp, dp, dp, C.c_int, dp]
+        L.orc_rig_hypothesis_errors.restype = None
+        L.orc_Rt_to_R_t.argtypes = [dp, dp, dp]
         _lib = L
     return _lib
 
@@ -227,3 +240,53 @@ def mean_reprojection_error(p):
 def rmse(p) -> float:
     q = c_problem(p)
     return lib().orc_rmse(C.byref(q))
+
+
+def rodrigues_inverse(R) -> np.ndarray:
+    R = _f(R)
+    out = np.zeros(3)
+    lib().orc_rodrigues_inverse(_dp(R), _dp(out))
+    return out
+
+
+def Rt_to_R_t(Rt):
+    Rt = _f(Rt)
+    R, t = np.zeros(9), np.zeros(3)
+    lib().orc_Rt_to_R_t(_dp(Rt), _dp(R), _dp(t))
+    return R.reshape(3, 3), t
+
+
+def c_rig_input(inp) -> OrcRigInput:
+    q = OrcRigInput()
+    q.n_cameras, q.n_boards, q.n_points = inp.n_cameras, inp.n_boards, inp.n_points
+    for name in ("worlds", "intr", "has", "Rt", "pix_u", "pix_v"):
+        arr = getattr(inp, name)
+        assert arr.flags["C_CONTIGUOUS"]
+        setattr(q, name, arr.ctypes.data)
+    return q
+
+
+def rig_hypothesis_errors(inp, i, Rp, tp, Rs, ts) -> np.ndarray:
+    """multi_calib.cpp:52-78 for the given hypotheses of camera i."""
+    q = c_rig_input(inp)
+    Rp, tp, Rs, ts = _f(Rp), _f(tp), _f(Rs), _f(ts)
+    nj = Rs.size // 9
+    err = np.zeros(nj)
+    lib().orc_rig_hypothesis_errors(C.byref(q), int(i), _dp(Rp), _dp(tp), _dp(Rs), _dp(ts), nj, _dp(err))
+    return err
+
+
+def rig_init(inp) -> dict:
+    """MultiCalib::MultiCalib (multi_calib.cpp:6-153) on a tscm_calib_amd.rig.RigInput."""
+    Cn, B = inp.n_cameras, inp.n_boards
+    q = c_rig_input(inp)
+    out = dict(cam_R=np.zeros((Cn, 3, 3)), cam_t=np.zeros((Cn, 3)), cam_rt=np.zeros((Cn, 6)),
+               board_R=np.zeros((B, 3, 3)), board_t=np.zeros((B, 3)), board_rt=np.zeros((B, 6)),
+               board_initial=np.zeros(B, dtype=np.uint8), cam_choice=np.zeros(Cn, dtype=np.int32),
+               cam_min_error=np.zeros(Cn))
+    rc = lib().orc_rig_init(C.byref(q), _dp(out["cam_R"]), _dp(out["cam_t"]), _dp(out["cam_rt"]),
+                            _dp(out["board_R"]), _dp(out["board_t"]), _dp(out["board_rt"]),
+                            out["board_initial"].ctypes.data, out["cam_choice"].ctypes.data,
+                            _dp(out["cam_min_error"]))
+    out["rc"] = rc
+    return out

@@ -144,6 +144,40 @@ double orc_mean_reprojection_error(const orc_problem *p, double *per_camera);
 /* sqrt(sum r^2 / N) over all corners with the double functor. */
 double orc_rmse(const orc_problem *p);
 
+
+/* ---- rig initialisation: MultiCalib::MultiCalib (multi_calib.cpp:6-153) -----------------------
+ * The step immediately before the joint LM: chains camera i to camera i-1 through every board
+ * both see, keeps the pose hypothesis with the smallest summed reprojection error
+ * (TS.h:58-69: SUM of Euclidean pixel errors, projection with skew terms), then does the same
+ * for every board pose.  Rt_to_R_t (multi_calib.h:130-137) builds R from FLOAT32 copies of the
+ * first two columns and their float cross product; MultiCalib_camera / _chessboard convert
+ * R to angle-axis with cv::Rodrigues (external, OpenCV calib3d: SVD orthonormalisation, then
+ * axis from the antisymmetric part), restated here from the published algorithm.            */
+typedef struct {
+    int n_cameras, n_boards, n_points;
+    const double *worlds;        /* [n_points*3]  board points x,y,z (z is used here: TS.h:63)  */
+    const double *intr;          /* [C*9]                                                       */
+    const unsigned char *has;    /* [C*B] has_chessboard                                        */
+    const double *Rt;            /* [C*B*9] row-major 3x3 [r1 r2 t] of TripleSphereCamera::Rt(j) */
+    const double *pix_u, *pix_v; /* [C*B*n_points] pixels()[j] (valid where has)                */
+} orc_rig_input;
+
+/* outputs: cam_R [C*9] row-major, cam_t [C*3], cam_rt [C*6]; board_R [B*9], board_t [B*3],
+ * board_rt [B*6], board_initial [B]; cam_choice [C] index of the winning hypothesis (among the
+ * common boards, in board order; -1 for camera 0), cam_min_error [C].
+ * returns 0, or -1 where the reference has undefined behaviour (adjacent cameras share no board). */
+int orc_rig_init(const orc_rig_input *in, double *cam_R, double *cam_t, double *cam_rt,
+                 double *board_R, double *board_t, double *board_rt, unsigned char *board_initial,
+                 int *cam_choice, double *cam_min_error);
+/* multi_calib.cpp:52-78 for nj given hypotheses of camera i (Rs [nj*9], ts [nj*3]); (Rp, tp) = pose
+ * of camera i-1.  The inner loop of orc_rig_init, exported for bounded CPU-baseline samples. */
+void orc_rig_hypothesis_errors(const orc_rig_input *in, int i, const double *Rp, const double *tp,
+                               const double *Rs, const double *ts, int nj, double *errors);
+/* cv::Rodrigues(R -> rvec) restated (row-major 3x3 in, 3 out). */
+void orc_rodrigues_inverse(const double *R, double *rvec);
+/* Rt_to_R_t: row-major 3x3 [r1 r2 t] -> R (row-major, float32-rounded columns), t. */
+void orc_Rt_to_R_t(const double *Rt, double *R, double *t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,3 +82,62 @@ def mixed_visibility_rig(seed=5, n_frames=24, n_cameras=4, noise_px=0.05) -> Pro
                 base.cam_rt.copy(), base.intr.copy(), base.board_rt[:B].copy(), base.cam_pose_constant.copy(), False,
                 meta=dict(gt_intr=intr, gt_cam_rt=cam, gt_board_rt=brd))
     return p.normalised()
+
+
+# ----------------------------------------------------------------------------- rig initialisation
+def np_project_skew(I, P):
+    """TS.cpp:332-344 in numpy (with the skew terms b, c)."""
+    X, Y, Z = P[..., 0], P[..., 1], P[..., 2]
+    fx, fy, cx, cy, xi, lam, al, b, c = I
+    d1 = np.sqrt(X * X + Y * Y + Z * Z)
+    d2 = np.sqrt(X * X + Y * Y + (Z + xi * d1) ** 2)
+    d3 = np.sqrt(X * X + Y * Y + (Z + xi * d1 + lam * d2) ** 2)
+    ks = Z + xi * d1 + lam * d2 + al / (1 - al) * d3
+    return fx * X / ks + b * Y / ks + cx, c * X / ks + fy * Y / ks + cy
+
+
+def np_Rt_to_R_t(Rt):
+    """multi_calib.h:130-137 in numpy float32."""
+    r1 = Rt[..., :, 0].astype(np.float32)
+    r2 = Rt[..., :, 1].astype(np.float32)
+    r3 = np.cross(r1, r2).astype(np.float32)
+    return np.stack([r1, r2, r3], axis=-1).astype(np.float64), Rt[..., :, 2].copy()
+
+
+def np_rig_stage(inp, i, Rp, tp):
+    """multi_calib.cpp:25-85 for camera i in numpy: hypotheses and the full error matrix summed per
+    hypothesis (pairwise summation, so only ~1e-13 relative agreement with a sequential loop)."""
+    common = np.nonzero(inp.has[i - 1].astype(bool) & inp.has[i].astype(bool))[0]
+    Ri, ti = np_Rt_to_R_t(inp.Rt[i, common])
+    Rk, tk = np_Rt_to_R_t(inp.Rt[i - 1, common])
+    Rik = Ri @ np.swapaxes(Rk, 1, 2)
+    tik = ti - np.einsum("kij,kj->ki", Rik, tk)
+    Rs = Rik @ Rp
+    ts = Rik @ tp + tik
+    J = common.size
+    err = np.zeros(J)
+    W = inp.worlds
+    for j in range(J):
+        A1 = Rp @ Rs[j].T
+        a1 = tp - A1 @ ts[j]
+        Rv, tv = A1 @ Ri, ti @ A1.T + a1
+        P = np.einsum("kij,nj->kni", Rv, W) + tv[:, None, :]
+        u, v = np_project_skew(inp.intr[i - 1], P)
+        e = np.sqrt((inp.pix_u[i - 1, common] - u) ** 2 + (inp.pix_v[i - 1, common] - v) ** 2).sum()
+        A2 = Rs[j] @ Rp.T
+        a2 = ts[j] - A2 @ tp
+        Rv, tv = A2 @ Rk, tk @ A2.T + a2
+        P = np.einsum("kij,nj->kni", Rv, W) + tv[:, None, :]
+        u, v = np_project_skew(inp.intr[i], P)
+        e += np.sqrt((inp.pix_u[i, common] - u) ** 2 + (inp.pix_v[i, common] - v) ** 2).sum()
+        err[j] = e
+    return common, Rs, ts, err
+
+
+def rig_with_unseen_boards(p: Problem, extra: int = 2) -> Problem:
+    """Append `extra` boards no camera sees (is_initial() stays false: multi_calib.cpp:98-103)."""
+    q = Problem(p.n_cameras, p.n_boards + extra, p.board_xy, p.view_camera, p.view_board, p.view_offset, p.view_count,
+                p.obs_u, p.obs_v, p.cam_rt, p.intr, np.concatenate([p.board_rt, np.zeros((extra, 6))]),
+                p.cam_pose_constant, False,
+                meta=dict(p.meta, gt_board_rt=np.concatenate([p.meta["gt_board_rt"], np.zeros((extra, 6))])))
+    return q.normalised()

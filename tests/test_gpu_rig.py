@@ -1,0 +1,103 @@
+"""GPU parity tests of tscm_rig_init (MultiCalib::MultiCalib, multi_calib.cpp:6-153) against the
+CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from tscm_calib_amd import api, lib, rig, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(inp, g, o):
+    assert o["rc"] == 0
+    assert np.array_equal(g["cam_choice"], o["cam_choice"])
+    assert np.array_equal(g["board_initial"], o["board_initial"])
+    assert H.rel_err(g["cam_min_error"][1:], o["cam_min_error"][1:]) < 1e-12
+    assert np.max(np.abs(g["cam_R"] - o["cam_R"])) < 1e-14
+    assert np.max(np.abs(g["cam_t"] - o["cam_t"])) < 1e-11            # mm, |t| ~ 600
+    assert np.max(np.abs(g["cam_rt"] - o["cam_rt"])) < 1e-9
+    assert np.max(np.abs(g["board_R"] - o["board_R"])) < 1e-13
+    assert np.max(np.abs(g["board_t"] - o["board_t"])) < 1e-10
+    ang = np.linalg.norm(o["board_rt"][:, :3], axis=1)
+    ok = (ang < np.pi - 1e-3) | (o["board_initial"] == 0)              # the axis sign flips at pi
+    assert np.max(np.abs(g["board_rt"][ok] - o["board_rt"][ok])) < 1e-9
+
+
+@pytest.mark.parametrize("C,V,seed", [(4, 12, 7), (2, 30, 3), (8, 10, 21), (4, 300, 17)])
+def test_rig_init_matches_oracle(hip_device, C, V, seed):
+    inp = synth.make_rig_input(synth.make_problem(C, V, seed))
+    g = rig.rig_init(inp, hip_device)
+    _compare(inp, g, orc.rig_init(inp))
+    assert g["n_projections"] > 0 and g["seconds_hypotheses"] > 0
+
+
+def test_rig_init_mixed_visibility_and_unseen_boards(hip_device):
+    p = H.rig_with_unseen_boards(H.mixed_visibility_rig(seed=9), extra=3)
+    inp = synth.make_rig_input(p)
+    g = rig.rig_init(inp, hip_device)
+    _compare(inp, g, orc.rig_init(inp))
+    seen = inp.has.sum(axis=0)
+    assert np.all(g["board_rt"][seen == 0] == 0.0) and not g["board_initial"][seen == 0].any()
+
+
+def test_rig_init_88_corner_board(hip_device):
+    inp = synth.make_rig_input(synth.make_problem(4, 16, 31, cols=11, rows=8, pitch=30.0))
+    _compare(inp, rig.rig_init(inp, hip_device), orc.rig_init(inp))
+
+
+def test_rig_init_rejects_reference_undefined_behaviour(hip_device):
+    inp = synth.make_rig_input(synth.make_problem(4, 8, 2))
+    drop = inp.has[1].astype(bool) & inp.has[2].astype(bool)
+    inp.has[2, drop] = 0
+    with pytest.raises(lib.TscmError) as e:
+        rig.rig_init(inp, hip_device)
+    assert e.value.code == -1 and "share no board" in str(e.value)
+
+
+def test_rig_init_then_calibrate_matches_oracle_chain(hip_device):
+    """constructor -> calibrate(): both chains (HIP, oracle) end at the same optimum."""
+    p = synth.make_problem(4, 16, 13)
+    inp = synth.make_rig_input(p)
+    g = rig.rig_init(inp, hip_device)
+    o = orc.rig_init(inp)
+    pg = rig.problem_from_rig(inp, g)
+    po = rig.problem_from_rig(inp, o)
+    sg = api.calibrate(pg, hip_device)
+    so = orc.solve(po)
+    assert sg["termination_type"] == so["termination_type"] == 0
+    assert abs(sg["final_cost"] - so["final_cost"]) < 1e-6 * so["final_cost"]
+    assert sg["rmse"] < 0.2                                                    # 0.1 px noise
+    d = H.param_rel_err(pg, po)
+    assert max(d.values()) < 1e-6, d
+
+
+def test_rig_init_full_size_properties(hip_device):
+    """BASELINE config 4 (4 cameras x 10k views: 5000 common boards per camera pair, 2.7e9
+    projections per pair): the winning hypothesis' error equals the oracle's for that hypothesis,
+    and no hypothesis in an oracle-scored sample beats it."""
+    p = synth.make_config(4)
+    inp = synth.make_rig_input(p)
+    g = rig.rig_init(inp, hip_device)
+    assert g["n_projections"] >= 3 * 2 * 54 * 5000 * 5000
+    rng = np.random.default_rng(0)
+    for i in range(1, 4):
+        Rp, tp = g["cam_R"][i - 1], g["cam_t"][i - 1]
+        common = np.nonzero(inp.has[i - 1].astype(bool) & inp.has[i].astype(bool))[0]
+        assert common.size == 5000
+        # hypotheses (multi_calib.cpp:29-48) in numpy for the winner and a random sample
+        js = np.concatenate([[g["cam_choice"][i]], rng.choice(common.size, size=12, replace=False)])
+        Ri, ti = H.np_Rt_to_R_t(inp.Rt[i, common[js]])
+        Rk, tk = H.np_Rt_to_R_t(inp.Rt[i - 1, common[js]])
+        Rik = Ri @ np.swapaxes(Rk, 1, 2)
+        Rs = Rik @ Rp
+        ts = Rik @ tp + ti - np.einsum("kij,kj->ki", Rik, tk)
+        err = orc.rig_hypothesis_errors(inp, i, Rp, tp, Rs, ts)
+        assert abs(err[0] - g["cam_min_error"][i]) < 1e-11 * err[0]
+        assert np.all(err[1:] >= err[0])
+        assert np.max(np.abs(g["cam_R"][i] - Rs[0])) < 1e-13
+    assert g["board_initial"].all()
+    # boards: each is seen by two cameras; the chosen pose is one of the two hypotheses
+    gt = p.meta["gt_board_rt"]
+    assert np.median(np.abs(g["board_rt"][:, 3:] - gt[:, 3:])) < 30.0          # mm: an initial guess

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Measurement of the rig-initialisation path (tscm_rig_init) on one MI355X.
+
+Workload: BASELINE config 4 (4 cameras x 10k views -> 5000 common boards per adjacent camera
+pair, 3 pairs, 2*54*5000^2 point projections per pair).  Prints ONE JSON line with the device
+rate of the hypothesis-scoring kernels, a roofline entry and the CPU oracle timed on a bounded
+sample of the hypotheses of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tscm_calib_amd import rig, synth  # noqa: E402
+
+# algorithmic flops of one point projection + pixel error (rig initialisation):
+# P = R w + t 18, d1/d2/d3 radicands 13, ksai 6, u/v with skew 10, error 6, 4 sqrt + 3 div counted as 1
+FLOP_PER_PROJECTION = 60
+PEAK_FP64_VALU_TFLOPS = 78.6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--cpu-hypotheses", type=int, default=8)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    p = synth.make_config(a.config)
+    inp = synth.make_rig_input(p)
+    rig.rig_init(inp)                       # warm-up (module load, allocator)
+    best = None
+    for _ in range(a.repeats):
+        g = rig.rig_init(inp)
+        if best is None or g["seconds_hypotheses"] < best["seconds_hypotheses"]:
+            best = g
+    K = int((inp.has[0].astype(bool) & inp.has[1].astype(bool)).sum())
+    pairs = inp.n_cameras - 1
+    hyp_proj = 2 * inp.n_points * K * K * pairs
+    rate = hyp_proj / best["seconds_hypotheses"]
+    out = dict(metric="rig_init_projections_per_second", value=rate, unit="projections/s", n_gpus=1,
+               higher_is_better=True, dtype="f64", data="synthetic",
+               config=dict(workload=f"config {a.config}: {inp.n_cameras} cameras, {inp.n_boards} boards, "
+                                    f"{K} common boards per adjacent pair, {inp.n_points} corners"),
+               seconds_hypotheses=best["seconds_hypotheses"], seconds_total=best["seconds_total"],
+               roofline=dict(bound="fp64-valu", achieved=rate * FLOP_PER_PROJECTION / 1e12, peak=PEAK_FP64_VALU_TFLOPS,
+                             unit="TFLOP/s", frac=rate * FLOP_PER_PROJECTION / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                             traffic=None))
+    if not a.no_cpu:
+        from oracle import pyoracle as orc   # cpu_baseline leg only
+        from tests import helpers as H
+        Rp, tp = best["cam_R"][0], best["cam_t"][0]
+        common = np.nonzero(inp.has[0].astype(bool) & inp.has[1].astype(bool))[0][: a.cpu_hypotheses]
+        Ri, ti = H.np_Rt_to_R_t(inp.Rt[1, common])
+        Rk, tk = H.np_Rt_to_R_t(inp.Rt[0, common])
+        Rik = Ri @ np.swapaxes(Rk, 1, 2)
+        Rs = Rik @ Rp
+        ts = Rik @ tp + ti - np.einsum("kij,kj->ki", Rik, tk)
+        t0 = time.perf_counter()
+        orc.rig_hypothesis_errors(inp, 1, Rp, tp, Rs, ts)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=2 * inp.n_points * K * len(common) / dt, unit="projections/s", cores=1,
+                                   kind="port", sample=f"{len(common)} of {K} hypotheses of camera pair (0,1), all {K} boards")
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

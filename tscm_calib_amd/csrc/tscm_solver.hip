@@ -27,6 +27,7 @@ using namespace tscm;
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+int tscm_set_error(int code, const std::string &msg) { return fail(code, msg); }   // for tscm_rig.hip
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \

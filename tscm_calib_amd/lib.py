@@ -68,6 +68,23 @@ class CSummary(C.Structure):
     ]
 
 
+class CRigInput(C.Structure):
+    _fields_ = [
+        ("n_cameras", C.c_int), ("n_boards", C.c_int), ("n_points", C.c_int),
+        ("worlds", C.c_void_p), ("intr", C.c_void_p), ("has", C.c_void_p), ("Rt", C.c_void_p),
+        ("pix_u", C.c_void_p), ("pix_v", C.c_void_p),
+    ]
+
+
+class CRigResult(C.Structure):
+    _fields_ = [
+        ("cam_R", C.c_void_p), ("cam_t", C.c_void_p), ("cam_rt", C.c_void_p),
+        ("board_R", C.c_void_p), ("board_t", C.c_void_p), ("board_rt", C.c_void_p),
+        ("board_initial", C.c_void_p), ("cam_choice", C.c_void_p), ("cam_min_error", C.c_void_p),
+        ("seconds_hypotheses", C.c_double), ("seconds_total", C.c_double), ("n_projections", C.c_longlong),
+    ]
+
+
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_default_options",
@@ -76,13 +93,13 @@ EXPORTS = [
     "tscm_solver_kernel_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
-    "tscm_shard_frames",
+    "tscm_shard_frames", "tscm_rig_init",
 ]
 
 
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("tscm_solver.hip", "tscm_kernels.h", "tscm_math.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("tscm_solver.hip", "tscm_rig.hip", "tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "tscm", "tscm.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
     if force or stale:
@@ -128,6 +145,7 @@ def lib():
     L.tscm_comm_destroy.argtypes = [vp]
     L.tscm_comm_destroy.restype = None
     L.tscm_shard_frames.argtypes = [C.POINTER(CProblem), C.c_int, ip]
+    L.tscm_rig_init.argtypes = [C.POINTER(CRigInput), C.c_int, C.POINTER(CRigResult)]
     _lib = L
     return L
 

@@ -308,3 +308,43 @@ def make_config(index: int, **kw) -> Problem:
     p = make_problem(C, V, 20240 + index, **kw)
     p.meta["config"] = index
     return p
+
+
+def make_rig_input(p: Problem, *, rot_sigma: float = 0.01, t_sigma: float = 3.0, seed: int | None = None):
+    """What MultiCalib::MultiCalib reads from the mono-calibrated cameras (multi_calib.cpp:6-153)
+    for the synthetic rig `p`: per-camera board poses Rt(j) = [r1 r2 t] of the ground-truth
+    view pose perturbed by `rot_sigma` rad / `t_sigma` mm (a mono calibration is only that good),
+    the (perturbed) intrinsics p.intr and the observed pixels."""
+    from .rig import RigInput
+    if p.mono:
+        raise ValueError("rig initialisation needs a multi-camera problem")
+    rng = CounterRNG((p.meta.get("seed", 0) if seed is None else seed) + 7919)
+    C, B, n = p.n_cameras, p.n_boards, p.n_points
+    gt_cam, gt_board = p.meta["gt_cam_rt"], p.meta["gt_board_rt"]
+    cam_R, cam_t = rodrigues(gt_cam[:, :3]), gt_cam[:, 3:]
+    vc, vb = p.view_camera.astype(np.int64), p.view_board.astype(np.int64)
+    V = vc.shape[0]
+    Rb, tb = rodrigues(gt_board[vb, :3]), gt_board[vb, 3:]
+    R = cam_R[vc] @ Rb
+    t = np.einsum("vij,vj->vi", cam_R[vc], tb) + cam_t[vc]
+    k = np.arange(V)
+    pert = rodrigues(rot_sigma * np.stack([rng.normal(40, k), rng.normal(41, k), rng.normal(42, k)], axis=1))
+    R = pert @ R
+    t = t + t_sigma * np.stack([rng.normal(43, k), rng.normal(44, k), rng.normal(45, k)], axis=1)
+    has = np.zeros((C, B), dtype=np.uint8)
+    Rt = np.zeros((C, B, 3, 3))
+    pu = np.zeros((C, B, n))
+    pv = np.zeros((C, B, n))
+    full = p.view_count == n
+    if not full.all():
+        raise ValueError("rig initialisation needs complete boards (cv::findChessboardCorners is all-or-nothing)")
+    has[vc, vb] = 1
+    Rt[vc, vb, :, 0] = R[:, :, 0]
+    Rt[vc, vb, :, 1] = R[:, :, 1]
+    Rt[vc, vb, :, 2] = t
+    idx = p.view_offset.astype(np.int64)[:, None] + np.arange(n)[None, :]
+    pu[vc, vb] = p.obs_u[idx]
+    pv[vc, vb] = p.obs_v[idx]
+    worlds = np.concatenate([p.board_xy, np.zeros((n, 1))], axis=1)
+    return RigInput(worlds, p.intr.copy(), has, Rt, pu, pv,
+                    meta=dict(p.meta, rot_sigma=rot_sigma, t_sigma=t_sigma)).normalised()
