@@ -251,6 +251,22 @@ typedef struct tscm_rig_result {
 
 int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_result *out);
 
+
+/* ------------------------------------------------------------------ result I/O
+ * The YAML main.cpp:305-319 writes through cv::FileStorage -- "cam{i}": 1x9 intrinsic_matrix_,
+ * "Twc{i}": 3x4 [R | t] -- and EpipolarRectify/rectify.cpp:262-270 reads.  Host-only (no device).
+ * tscm_yaml_format   renders the file into buf (NULL buf: only *needed, incl. the final NUL).
+ * tscm_yaml_write    = FileStorage(path, WRITE) + the loop of main.cpp:306-318.
+ * tscm_yaml_parse / tscm_yaml_read  = FileStorage(path, READ)["cam{i}"], ["Twc{i}"]: fills
+ *                    intr [max_cameras*9] and Twc [max_cameras*12, row-major 3x4] (either may be
+ *                    NULL) and returns the number of cameras found in *n_cameras.             */
+int tscm_yaml_format(int n_cameras, const double *intr, const double *cam_R, const double *cam_t,
+                     char *buf, size_t buf_size, size_t *needed);
+int tscm_yaml_write(const char *path, int n_cameras, const double *intr, const double *cam_R,
+                    const double *cam_t);
+int tscm_yaml_parse(const char *text, int max_cameras, int *n_cameras, double *intr, double *Twc);
+int tscm_yaml_read(const char *path, int max_cameras, int *n_cameras, double *intr, double *Twc);
+
 #ifdef __cplusplus
 }
 #endif

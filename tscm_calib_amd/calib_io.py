@@ -1,0 +1,51 @@
+"""Result I/O: the calibration YAML of main.cpp:305-319 (cv::FileStorage layout), read back by
+EpipolarRectify/rectify.cpp:262-270.  ctypes mirror of tscm_yaml_* (host-only entry points)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def _arrays(intr, cam_R, cam_t):
+    intr = np.ascontiguousarray(intr, dtype=np.float64).reshape(-1, 9)
+    cam_R = np.ascontiguousarray(cam_R, dtype=np.float64).reshape(-1, 3, 3)
+    cam_t = np.ascontiguousarray(cam_t, dtype=np.float64).reshape(-1, 3)
+    if not (intr.shape[0] == cam_R.shape[0] == cam_t.shape[0]):
+        raise ValueError("intr, cam_R, cam_t disagree on the number of cameras")
+    return intr, cam_R, cam_t
+
+
+def format_calib_yaml(intr, cam_R, cam_t) -> str:
+    intr, cam_R, cam_t = _arrays(intr, cam_R, cam_t)
+    L = _lib.lib()
+    need = C.c_size_t(0)
+    _lib.check(L.tscm_yaml_format(intr.shape[0], _lib.dptr(intr), _lib.dptr(cam_R), _lib.dptr(cam_t), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _lib.check(L.tscm_yaml_format(intr.shape[0], _lib.dptr(intr), _lib.dptr(cam_R), _lib.dptr(cam_t), buf, need.value, None))
+    return buf.value.decode()
+
+
+def write_calib_yaml(path: str, intr, cam_R, cam_t) -> None:
+    intr, cam_R, cam_t = _arrays(intr, cam_R, cam_t)
+    _lib.check(_lib.lib().tscm_yaml_write(path.encode(), intr.shape[0], _lib.dptr(intr), _lib.dptr(cam_R), _lib.dptr(cam_t)))
+
+
+def _parse(call, arg):
+    L = _lib.lib()
+    n = C.c_int(0)
+    _lib.check(call(arg, 0, C.byref(n), None, None))
+    intr, Twc = np.zeros((n.value, 9)), np.zeros((n.value, 3, 4))
+    _lib.check(call(arg, n.value, C.byref(n), _lib.dptr(intr), _lib.dptr(Twc)))
+    return intr, Twc
+
+
+def parse_calib_yaml(text: str):
+    """-> intr [C,9], Twc [C,3,4]"""
+    return _parse(_lib.lib().tscm_yaml_parse, text.encode())
+
+
+def read_calib_yaml(path: str):
+    return _parse(_lib.lib().tscm_yaml_read, path.encode())
