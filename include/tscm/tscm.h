@@ -267,6 +267,42 @@ int tscm_yaml_write(const char *path, int n_cameras, const double *intr, const d
 int tscm_yaml_parse(const char *text, int max_cameras, int *n_cameras, double *intr, double *Twc);
 int tscm_yaml_read(const char *path, int max_cameras, int *n_cameras, double *intr, double *Twc);
 
+
+/* ------------------------------------------------------------------ remap tables
+ * The per-pixel map builders TripleSphereCamera::undistort (TS.cpp:284-306), the map part of
+ * undistort_chessboard (TS.cpp:308-330, before cv::remap) and the eight 400x400 tables of
+ * EpipolarRectify/rectify.cpp:86-199 are one loop:
+ *     ray = R * ((j - cx)/fx, (i - cy)/fy, 1);  (u, v) = project(ray)  [TS.cpp:332-344, skew terms]
+ *     mapx(i, j) = (float)(u + offset_x);  mapy(i, j) = (float)(v + offset_y)
+ *   undistort:             R = I, (fx, fy, cx, cy) = the pinhole arguments
+ *   undistort_chessboard:  R = Rt_[index] (3x3 [r1 r2 t]), fx = fy = 1, cx = cy = chessboard_size
+ *   rectify init_remap:    R = R_cam^T * R_pair, fx = fy = cx = cy = 200, offsets = the mosaic
+ *                          origin of the sampled camera (0 | 1280, 0 | 1080); its TScamera::project
+ *                          returns (-1, -1) when Z <= -w2 * d1, w2 = 0.42399 (rectify.cpp:7,27):
+ *                          check_w2 = 1
+ * A batch of maps is one launch; map m writes rows of `out_stride` floats starting at element
+ * `out_offset` of mapx / mapy (so the 400x1600 left/right tables of rectify.cpp are 4 maps each).
+ * exact != 0: IEEE sqrt / divide and unfused multiply-add in the reference's operation order
+ * (bit-identical floats); exact == 0: hardware reciprocal / rsqrt seeds with one correction step
+ * (fp64 values within ~2 ulp, i.e. identical floats except when within 1e-15 relative of a
+ * float32 rounding boundary).                                                                */
+typedef struct tscm_map_desc {
+    double intr[9];              /* fx fy cx cy xi lambda alpha b c of the camera that is sampled */
+    double R[9];                 /* row-major 3x3                                                  */
+    double fx, fy, cx, cy;       /* pinhole of the output image                                    */
+    double offset_x, offset_y;
+    int width, height;           /* output size: j < width, i < height                             */
+    int out_stride;              /* floats per output row (>= width)                               */
+    int check_w2;                /* 1: (u, v) = (-1, -1) when Z <= -w2 * d1 (rectify.cpp:27)       */
+    long long out_offset;        /* first element of this map inside mapx / mapy                   */
+    double w2;
+} tscm_map_desc;
+
+/* mapx / mapy: host arrays of n_elems floats (caller-owned); seconds_kernel (may be NULL) returns
+ * the device time of the map kernel alone (HIP events), without the copy back to the host.     */
+int tscm_build_maps(const tscm_map_desc *maps, int n_maps, int device, int exact, float *mapx,
+                    float *mapy, size_t n_elems, double *seconds_kernel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("tscm_oracle.c", "tscm_oracle_rig.c", "tscm_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("tscm_oracle.c", "tscm_oracle_rig.c", "tscm_oracle_maps.c", "tscm_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in srcs)
     if force or stale:
@@ -71,6 +71,14 @@ class OrcRigInput(C.Structure):
     ]
 
 
+class OrcMapDesc(C.Structure):
+    _fields_ = [
+        ("intr", C.c_double * 9), ("R", C.c_double * 9), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+        ("cy", C.c_double), ("offset_x", C.c_double), ("offset_y", C.c_double), ("width", C.c_int), ("height", C.c_int),
+        ("out_stride", C.c_int), ("check_w2", C.c_int), ("out_offset", C.c_longlong), ("w2", C.c_double),
+    ]
+
+
 _lib = None
 
 
@@ -103,6 +111,10 @@ def lib():
         L.orc_rig_hypothesis_errors.argtypes = [C.POINTER(OrcRigInput), C.c_int, dp, dp, dp, dp, C.c_int, dp]
         L.orc_rig_hypothesis_errors.restype = None
         L.orc_Rt_to_R_t.argtypes = [dp, dp, dp]
+        L.orc_build_map.argtypes = [C.POINTER(OrcMapDesc), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_build_map.restype = None
+        L.orc_rectify_pair_rotation.argtypes = [dp, dp, dp]
+        L.orc_rectify_pair_rotation.restype = None
         _lib = L
     return _lib
 
@@ -290,3 +302,24 @@ def rig_init(inp) -> dict:
                             _dp(out["cam_min_error"]))
     out["rc"] = rc
     return out
+
+
+def build_maps(descs, n_elems: int):
+    """TS.cpp:284-330 / rectify.cpp:86-199 for a list of tscm_calib_amd.maps.MapDesc -> mapx, mapy (float32)."""
+    mapx, mapy = np.zeros(n_elems, dtype=np.float32), np.zeros(n_elems, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    for d in descs:
+        m = OrcMapDesc()
+        m.intr[:] = list(np.asarray(d.intr, dtype=np.float64).ravel())
+        m.R[:] = list(np.asarray(d.R, dtype=np.float64).ravel())
+        for k in ("fx", "fy", "cx", "cy", "offset_x", "offset_y", "width", "height", "out_stride", "check_w2", "out_offset", "w2"):
+            setattr(m, k, getattr(d, k))
+        lib().orc_build_map(C.byref(m), mapx.ctypes.data_as(fp), mapy.ctypes.data_as(fp))
+    return mapx, mapy
+
+
+def rectify_pair_rotation(t1, t2) -> np.ndarray:
+    t1, t2 = _f(t1), _f(t2)
+    R = np.zeros(9)
+    lib().orc_rectify_pair_rotation(_dp(t1), _dp(t2), _dp(R))
+    return R.reshape(3, 3)

@@ -178,6 +178,22 @@ void orc_rodrigues_inverse(const double *R, double *rvec);
 /* Rt_to_R_t: row-major 3x3 [r1 r2 t] -> R (row-major, float32-rounded columns), t. */
 void orc_Rt_to_R_t(const double *Rt, double *R, double *t);
 
+/* ---- remap tables (TS.cpp:284-330, EpipolarRectify/rectify.cpp:86-199); same layout as tscm_map_desc */
+typedef struct {
+    double intr[9];
+    double R[9];
+    double fx, fy, cx, cy;
+    double offset_x, offset_y;
+    int width, height;
+    int out_stride;
+    int check_w2;
+    long long out_offset;
+    double w2;
+} orc_map_desc;
+void orc_build_map(const orc_map_desc *m, float *mapx, float *mapy);
+/* Remap::calc_R (rectify.cpp:234-248), R row-major */
+void orc_rectify_pair_rotation(const double *t1, const double *t2, double *R);
+
 #ifdef __cplusplus
 }
 #endif

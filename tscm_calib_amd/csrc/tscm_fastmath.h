@@ -1,6 +1,8 @@
 // tscm_fastmath.h -- fp64 reciprocal / reciprocal square root from the gfx950 hardware seeds.
 #pragma once
 
+#include <hip/hip_runtime.h>
+
 namespace tscm {
 
 // 1/sqrt(x) and 1/x to full fp64 accuracy from the hardware seeds (v_rsq_f64 / v_rcp_f64, measured
