@@ -303,6 +303,22 @@ typedef struct tscm_map_desc {
 int tscm_build_maps(const tscm_map_desc *maps, int n_maps, int device, int exact, float *mapx,
                     float *mapy, size_t n_elems, double *seconds_kernel);
 
+
+/* ------------------------------------------------------------------ mono initialisation pieces
+ * tscm_estimate_focal = TripleSphereCamera::estimate_focal (TS.cpp:110-168): one circle fit
+ *   (cv::SVD::solveZ of a board_w x 4 matrix) per board row of every image with a board; *focal is
+ *   the mean of the accepted samples, *n_used their number (0: "focal estimation failed", fx_ = 0).
+ *   pix_u / pix_v: [n_views][board_w * board_h] host arrays, count[k] = pixels[k].size() (0 = no
+ *   board in image k); (cx, cy) = the principal point guess of TS.cpp:43-44.
+ * tscm_poses_from_r1r2t = the loop TS.cpp:62-74: Rt_[i] (row-major 3x3 [r1 r2 t]) -> rt_[i] =
+ *   [cv::Rodrigues(R), t] with R built from float32 r1, r2 and their float cross product
+ *   (has[i] == 0: rt left untouched).  Host-only.
+ * estimate_extrinsic (TS.cpp:170-203) is cv::solvePnPRansac and stays with OpenCV.             */
+int tscm_estimate_focal(const double *pix_u, const double *pix_v, const int *count, int n_views,
+                        int board_w, int board_h, double cx, double cy, int device, double *focal,
+                        int *n_used);
+int tscm_poses_from_r1r2t(const double *Rt, const unsigned char *has, int n, double *rt);
+
 #ifdef __cplusplus
 }
 #endif

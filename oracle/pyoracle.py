@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("tscm_oracle.c", "tscm_oracle_rig.c", "tscm_oracle_maps.c", "tscm_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("tscm_oracle.c", "tscm_oracle_rig.c", "tscm_oracle_maps.c", "tscm_oracle_focal.c", "tscm_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in srcs)
     if force or stale:
@@ -111,6 +111,13 @@ def lib():
         L.orc_rig_hypothesis_errors.argtypes = [C.POINTER(OrcRigInput), C.c_int, dp, dp, dp, dp, C.c_int, dp]
         L.orc_rig_hypothesis_errors.restype = None
         L.orc_Rt_to_R_t.argtypes = [dp, dp, dp]
+        L.orc_estimate_focal.argtypes = [dp, dp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp,
+                                         C.POINTER(C.c_int)]
+        L.orc_estimate_focal.restype = C.c_int
+        L.orc_focal_sample.argtypes = [dp, dp, C.c_int, C.c_double, C.c_double, dp]
+        L.orc_focal_sample.restype = C.c_int
+        L.orc_Rt_to_rt.argtypes = [dp, dp]
+        L.orc_Rt_to_rt.restype = None
         L.orc_build_map.argtypes = [C.POINTER(OrcMapDesc), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_build_map.restype = None
         L.orc_rectify_pair_rotation.argtypes = [dp, dp, dp]
@@ -323,3 +330,27 @@ def rectify_pair_rotation(t1, t2) -> np.ndarray:
     R = np.zeros(9)
     lib().orc_rectify_pair_rotation(_dp(t1), _dp(t2), _dp(R))
     return R.reshape(3, 3)
+
+
+def estimate_focal(pix_u, pix_v, count, width, height, cx, cy):
+    """TS.cpp:110-168 -> focal, number of accepted rows, rc"""
+    pix_u, pix_v = _f(pix_u), _f(pix_v)
+    count = np.ascontiguousarray(count, dtype=np.int32)
+    focal, total = C.c_double(0.0), C.c_int(0)
+    rc = lib().orc_estimate_focal(_dp(pix_u), _dp(pix_v), count.ctypes.data_as(C.POINTER(C.c_int)), count.shape[0], width, height,
+                                  cx, cy, C.cast(C.byref(focal), C.POINTER(C.c_double)), C.byref(total))
+    return focal.value, total.value, rc
+
+
+def focal_sample(pu, pv, cx, cy):
+    pu, pv = _f(pu), _f(pv)
+    g = C.c_double(0.0)
+    ok = lib().orc_focal_sample(_dp(pu), _dp(pv), pu.shape[0], cx, cy, C.cast(C.byref(g), C.POINTER(C.c_double)))
+    return (g.value if ok else None)
+
+
+def Rt_to_rt(Rt) -> np.ndarray:
+    Rt = _f(Rt)
+    out = np.zeros(6)
+    lib().orc_Rt_to_rt(_dp(Rt), _dp(out))
+    return out

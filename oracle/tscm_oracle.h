@@ -178,6 +178,14 @@ void orc_rodrigues_inverse(const double *R, double *rvec);
 /* Rt_to_R_t: row-major 3x3 [r1 r2 t] -> R (row-major, float32-rounded columns), t. */
 void orc_Rt_to_R_t(const double *Rt, double *R, double *t);
 
+/* ---- mono initialisation pieces (TS.cpp:62-74, 110-168) ------------------------------------*/
+/* estimate_focal: pix_u/pix_v [n_views][width*height], count[k] = pixels[k].size(); returns -1 for
+ * width < 4 (solveZ of a wide matrix is not restated) */
+int orc_estimate_focal(const double *pix_u, const double *pix_v, const int *count, int n_views, int width, int height,
+                       double cx, double cy, double *focal, int *total_num);
+int orc_focal_sample(const double *pu, const double *pv, int width, double cx, double cy, double *gamma);
+void orc_Rt_to_rt(const double *Rt, double *rt);
+
 /* ---- remap tables (TS.cpp:284-330, EpipolarRectify/rectify.cpp:86-199); same layout as tscm_map_desc */
 typedef struct {
     double intr[9];

@@ -285,6 +285,19 @@ double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::
 
 }  // namespace
 
+extern "C" int tscm_poses_from_r1r2t(const double *Rt, const unsigned char *has, int n, double *rt)
+{
+    if (n < 0 || (n > 0 && (!Rt || !rt))) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    for (int i = 0; i < n; ++i) {
+        if (has && !has[i]) continue;                       // TS.cpp:64-65
+        M3 R; V3 t;
+        Rt_to_R_t(Rt + 9 * (size_t)i, R, t);                // the same float32 construction (TS.cpp:66-69)
+        rodrigues_inverse(R, rt + 6 * (size_t)i);
+        std::memcpy(rt + 6 * (size_t)i + 3, t.a, sizeof(t.a));
+    }
+    return 0;
+}
+
 extern "C" int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_result *out)
 {
     if (!in || !out) return tscm_set_error(TSCM_E_INVALID, "NULL argument");

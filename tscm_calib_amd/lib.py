@@ -102,13 +102,13 @@ EXPORTS = [
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
     "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
-    "tscm_yaml_read", "tscm_build_maps",
+    "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
 ]
 
 
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("tscm_solver.hip", "tscm_rig.hip", "tscm_maps.hip", "tscm_io.cpp", "tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("tscm_solver.hip", "tscm_rig.hip", "tscm_maps.hip", "tscm_init.hip", "tscm_io.cpp", "tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "tscm", "tscm.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
     if force or stale:
@@ -157,6 +157,8 @@ def lib():
     L.tscm_rig_init.argtypes = [C.POINTER(CRigInput), C.c_int, C.POINTER(CRigResult)]
     L.tscm_build_maps.argtypes = [C.POINTER(CMapDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                   C.c_size_t, dp]
+    L.tscm_estimate_focal.argtypes = [dp, dp, ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, ip]
+    L.tscm_poses_from_r1r2t.argtypes = [dp, C.c_void_p, C.c_int, dp]
     L.tscm_yaml_format.argtypes = [C.c_int, dp, dp, dp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tscm_yaml_write.argtypes = [C.c_char_p, C.c_int, dp, dp, dp]
     L.tscm_yaml_parse.argtypes = [C.c_char_p, C.c_int, ip, dp, dp]

@@ -84,3 +84,26 @@ def problem_from_rig(inp: RigInput, init: dict) -> Problem:
                 inp.pix_u[cams, boards].ravel().copy(), inp.pix_v[cams, boards].ravel().copy(),
                 init["cam_rt"].copy(), inp.intr.copy(), init["board_rt"].copy(), const, False, meta=dict(inp.meta))
     return p.normalised()
+
+
+def estimate_focal(pix_u, pix_v, count, board_w: int, board_h: int, cx: float, cy: float, device: int = 0):
+    """tscm_estimate_focal (TripleSphereCamera::estimate_focal, TS.cpp:110-168) -> focal, accepted rows."""
+    pix_u = np.ascontiguousarray(pix_u, dtype=np.float64)
+    pix_v = np.ascontiguousarray(pix_v, dtype=np.float64)
+    count = np.ascontiguousarray(count, dtype=np.int32)
+    if pix_u.size != count.shape[0] * board_w * board_h or pix_v.size != pix_u.size:
+        raise ValueError("pix_u / pix_v must hold n_views * board_w * board_h values")
+    focal, used = C.c_double(0.0), C.c_int(0)
+    _lib.check(_lib.lib().tscm_estimate_focal(_lib.dptr(pix_u), _lib.dptr(pix_v), count.ctypes.data_as(C.POINTER(C.c_int)),
+                                              count.shape[0], board_w, board_h, cx, cy, device,
+                                              C.cast(C.byref(focal), C.POINTER(C.c_double)), C.byref(used)))
+    return focal.value, used.value
+
+
+def poses_from_Rt(Rt, has=None) -> np.ndarray:
+    """tscm_poses_from_r1r2t (TS.cpp:62-74): [n,3,3] [r1 r2 t] -> [n,6] angle-axis + t (host-only)."""
+    Rt = np.ascontiguousarray(Rt, dtype=np.float64).reshape(-1, 3, 3)
+    rt = np.zeros((Rt.shape[0], 6))
+    h = None if has is None else np.ascontiguousarray(has, dtype=np.uint8)
+    _lib.check(_lib.lib().tscm_poses_from_r1r2t(_lib.dptr(Rt), None if h is None else h.ctypes.data, Rt.shape[0], _lib.dptr(rt)))
+    return rt
