@@ -41,17 +41,18 @@ ITERS_PER_SOLVE = 10
 FLOP_PER_CORNER = 836 + 600          # Gram contraction 2P(P+1)+4P with P=19, + hand-structured geometry
 BYTES_PER_CORNER = 16.0 + 168.0 / 54.0
 FP64_PEAK_TFLOPS = 78.6              # MI355X FP64 vector = matrix peak (AMD datasheet; not in MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3             # MI355X FP32 vector (packed) = FP32 matrix peak, same datasheet
 HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
 
 
-def run_iterations(solver, n_iter):
+def run_iterations(solver, n_iter, **extra):
     """Run exactly n_iter LM iterations as solves of <= ITERS_PER_SOLVE iterations."""
     done = 0
     while done < n_iter:
         k = min(ITERS_PER_SOLVE, n_iter - done)
-        s = solver.solve_resident(reset=True, max_num_iterations=k, **BENCH_OPTS)
+        s = solver.solve_resident(reset=True, max_num_iterations=k, **BENCH_OPTS, **extra)
         if s["lm_iterations"] != k:
             raise RuntimeError(f"expected {k} LM iterations, device ran {s['lm_iterations']} ({s['message']})")
         done += k
@@ -94,6 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config index (4 = headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--jacobian-fp32", action="store_true",
+                    help="north_star's 1e-3 tier: fp32 derivatives + fp32 MFMA contraction (default: all fp64, the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,14 +133,15 @@ def main():
             dist.barrier()
 
     # natural solve (reference options, termination tests on): untimed, doubles as warmup
-    natural = solver.solve_resident(reset=True)
+    extra = dict(jacobian_fp32=1) if args.jacobian_fp32 else {}
+    natural = solver.solve_resident(reset=True, **extra)
     # warmup (untimed)
     if args.warmup > 0:
-        run_iterations(solver, args.warmup)
+        run_iterations(solver, args.warmup, **extra)
     solver.kernel_time(enable=os.environ.get("TSCM_BENCH_NO_EVENTS") is None)
     barrier()
     t0 = time.perf_counter()
-    last = run_iterations(solver, args.steps)
+    last = run_iterations(solver, args.steps, **extra)
     barrier()
     elapsed = time.perf_counter() - t0
     launches, kms = solver.kernel_time(enable=False)
@@ -168,7 +172,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 (fp32 Jacobian + fp32 MFMA contraction)" if args.jacobian_fp32 else "f64",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: {full.n_cameras} cams x "
                                    f"{full.meta['views_per_cam']} views/cam, {full.n_boards} frames, "
@@ -178,8 +182,10 @@ def main():
                               "rmse_px": natural["rmse"], "seconds": natural["seconds_solve"],
                               "create_seconds_incl_H2D_of_observations": t_create},
             "roofline": {
-                "kernel": "k_eval_gram", "bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else "k_eval_gram", "bound": "mfma",
+                "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved_tf / (FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS),
+                "traffic": None if args.jacobian_fp32 else traffic,
                 "launches": launches, "avg_launch_ms": avg_ms,
                 "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
                 "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,

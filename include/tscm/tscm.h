@@ -91,6 +91,11 @@ typedef struct tscm_options {
     int jacobi_scaling;                  /* 1                                          */
     int check_every;                     /* host polls the device-resident LM loop     */
                                          /* every this many iterations (default 4)     */
+    int jacobian_fp32;                   /* 0 (default): everything fp64, 1e-6 tier.   */
+                                         /* 1: derivatives and the J^T J contraction in */
+                                         /* fp32 (packed VALU + fp32 MFMA), projection, */
+                                         /* residuals, cost and the whole linear solve  */
+                                         /* stay fp64: north_star's 1e-3 tier          */
 } tscm_options;
 
 /* ceres::IterationSummary subset */

@@ -1,0 +1,245 @@
+// tscm_eval_f32.h -- mixed-precision variant of k_eval_gram (north_star's "fp32 Jacobian" tier).
+//
+// Same data flow, tile columns, record layout and fp64 epilogue as k_eval_gram (tscm_kernels.h);
+// what changes is the arithmetic type of the Jacobian:
+//   fp64  board -> camera transform, triple-sphere projection, residual and the cost r^T r
+//   fp32  every derivative (the 2 x 15 tile row of a corner), computed two at a time (u-row, v-row)
+//         with packed fp32 math, staged in a float LDS tile and contracted with
+//         v_mfma_f32_16x16x4_f32 (half the issue cycles of the fp64 MFMA); one view's Gram
+//         (<= 2 x 64 rows) accumulates in fp32, is converted once and everything downstream
+//         (records, camera tiles, Schur elimination, reduced solve) stays fp64.
+// The fp32 MFMA returns rows 4*(lane>>4)+reg per lane, the fp64 one rows (lane>>4)+4*reg; feeding
+// the A operand with tile column pi(i) = (i>>2) + 4*(i&3) makes the fp32 result land exactly where
+// the fp64 epilogue expects it.
+#pragma once
+// (included from tscm_kernels.h inside namespace tscm)
+
+constexpr int kRP32 = 68;          // float pitch of the fp32 tile: 68 = 4 (mod 64) -> 16 columns x 4 k-rows hit 64 distinct banks
+constexpr int kTile32 = 16 * kRP32 * 4 / 8;   // the tile, in doubles (544): also covers the 512-double camera-tile exchange
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int eval_f32_lds_doubles(int n_points) { return kTile32 + kCst + 2 * n_points + kCst / 2; }
+
+__global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState S, int cand)
+{
+    if (S.ctrl->done) return;
+    const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lds_wave = eval_f32_lds_doubles(P.n_points);
+    double *lds = lds_all + (size_t)wave * lds_wave;
+    float *Fl = reinterpret_cast<float *>(lds);            // [16][kRP32]: the u-rows, then the v-rows
+    double *cst = lds + kTile32;                            // [kCst] fp64 constants (projection chain)
+    double *bxy = cst + kCst;
+    float *cs = reinterpret_cast<float *>(bxy + 2 * P.n_points);   // [kCst] fp32 copy (derivatives)
+    constexpr int RP = kRP32;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + wave;
+    const int cam = P.chunk_cam[chunk];
+    for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
+    if (lane < kCConst) { const double v = S.cconst[kCConst * cam + lane]; cst[kVConst + lane] = v; cs[kVConst + lane] = (float)v; }
+    const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
+    const int col = lane & 15, kq = lane >> 4;
+    d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
+    double rr = 0.0;                               // this lane's share of r^T r, fp64
+    const double *cc = cst + kVConst;
+    const float *cf = cs + kVConst;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Fl[c * RP + lane] = 0.f;  // all 64 rows incl. the all-zero 16th tile column
+    int prev_nv = 0;
+    const unsigned oA = 8u * (unsigned)(col <= 2 ? kRecEE + 6 * kq + col
+                                      : col <= 8 ? 16 * kq + col - 3
+                                      : col == 9 ? 16 * kq + 6 : col == 10 ? 16 * kq + 8
+                                      : col <= 14 ? 16 * kq + col - 1 : 16 * kq + 14);
+    const unsigned oB = 8u * (unsigned)(kRecEE + 6 * kq + 3);
+    double pf_c = 0.0, pf_u = 0.0, pf_v = 0.0;
+    if (vb < ve) {
+        if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + vb];
+        if (lane < P.view_count[vb]) { pf_u = P.obs_u[P.view_obs[vb] + lane]; pf_v = P.obs_v[P.view_obs[vb] + lane]; }
+    }
+    const float *fpB = Fl + col * RP + kq;                              // B operand: tile column col
+    const float *fpA = Fl + ((col >> 2) + 4 * (col & 3)) * RP + kq;     // A operand: tile column pi(col)
+    for (int view = vb; view < ve; ++view) {
+        const int cnt = P.view_count[view];
+        const int off = P.view_obs[view];
+        wave_lds_fence();
+        if (lane < kVConst) { cst[lane] = pf_c; cs[lane] = (float)pf_c; }
+        const double ou0 = pf_u, ov0 = pf_v;
+        if (view + 1 < ve) {
+            if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + view + 1];
+            if (lane < P.view_count[view + 1]) { pf_u = P.obs_u[P.view_obs[view + 1] + lane]; pf_v = P.obs_v[P.view_obs[view + 1] + lane]; }
+        }
+        wave_lds_fence();
+        d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int j = c0 + lane;
+            const bool valid = j < cnt;
+            float *fu = Fl + lane;
+            float fv[kTcols];
+            if (valid) {
+                const double x = bxy[2 * j], y = bxy[2 * j + 1];
+                const double ou = c0 ? P.obs_u[off + j] : ou0, ov = c0 ? P.obs_v[off + j] : ov0;
+                // ---- fp64: board -> world -> camera, triple sphere, residual (multi_calib.h:158-193) ----
+                const double Pw0 = x * cst[0] + y * cst[3] + cst[6];
+                const double Pw1 = x * cst[1] + y * cst[4] + cst[7];
+                const double Pw2 = x * cst[2] + y * cst[5] + cst[8];
+                const double X = cc[0] * Pw0 + cc[1] * Pw1 + cc[2] * Pw2 + cc[9];
+                const double Y = cc[3] * Pw0 + cc[4] * Pw1 + cc[5] * Pw2 + cc[10];
+                const double Z = cc[6] * Pw0 + cc[7] * Pw1 + cc[8] * Pw2 + cc[11];
+                const double rho2 = X * X + Y * Y;
+                const double s1 = rho2 + Z * Z;
+                const double id1 = fast_rsqrt(s1), d1 = s1 * id1;
+                const double z1 = Z + cc[43] * d1;
+                const double s2 = rho2 + z1 * z1;
+                const double id2 = fast_rsqrt(s2), d2 = s2 * id2;
+                const double z2 = z1 + cc[44] * d2;
+                const double s3 = rho2 + z2 * z2;
+                const double id3 = fast_rsqrt(s3), d3 = s3 * id3;
+                const double ik = fast_rcp(z2 + cc[45] * d3);
+                const double mx = X * ik, my = Y * ik;
+                const double ru = ou - (cc[39] * mx + cc[41]);
+                const double rv = ov - (cc[40] * my + cc[42]);
+                rr += ru * ru + rv * rv;
+                // ---- fp32: derivatives, (u-row, v-row) pairs ---------------------------------------------
+                const float xf = (float)x, yf = (float)y;
+                const float Xf = (float)X, Yf = (float)Y, Zf = (float)Z, z1f = (float)z1, z2f = (float)z2;
+                const float i1 = (float)id1, i2 = (float)id2, i3 = (float)id3, ikf = (float)ik;
+                const float e1 = (float)d1, e2 = (float)d2, e3 = (float)d3;
+                const float mxf = (float)mx, myf = (float)my;
+                const float P0 = (float)Pw0, P1 = (float)Pw1, P2 = (float)Pw2;
+                const float xi = cf[43], lam = cf[44], beta = cf[45];
+                const float c1 = 1.f + xi * Zf * i1;
+                const float c2 = 1.f + lam * z1f * i2;
+                const float c3 = 1.f + beta * z2f * i3;
+                const float q = beta * i3 + c3 * (lam * i2 + c2 * xi * i1);
+                const float kz = c1 * c2 * c3;
+                const f2 fk = { cf[39] * ikf, cf[40] * ikf };              // (fx/k, fy/k)
+                const f2 HM = { fk.x * mxf, fk.y * myf };                  // (fx mx / k, fy my / k)
+                const f2 N0 = HM * (Xf * q) - (f2){ fk.x, 0.f };           // -d(u,v)/dX
+                const f2 N1 = HM * (Yf * q) - (f2){ 0.f, fk.y };           // -d(u,v)/dY
+                const f2 N2 = HM * kz;                                     // -d(u,v)/dZ
+                fu[6 * RP] = N0.x; fv[6] = N0.y;
+                fu[7 * RP] = N1.x; fv[7] = N1.y;
+                fu[8 * RP] = N2.x; fv[8] = N2.y;
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {                           // w_b: -A (x e_k0 + y e_k1)
+                    const float h0 = xf * cs[9 + 6 * kk] + yf * cs[12 + 6 * kk];
+                    const float h1 = xf * cs[10 + 6 * kk] + yf * cs[13 + 6 * kk];
+                    const float h2 = xf * cs[11 + 6 * kk] + yf * cs[14 + 6 * kk];
+                    const f2 w = N0 * h0 + N1 * h1 + N2 * h2;
+                    fu[kk * RP] = w.x; fv[kk] = w.y;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {                           // w_c: -A (dR_c/dw_k Pw)
+                    const float *D = cf + 12 + 9 * kk;
+                    const float g0 = D[0] * P0 + D[1] * P1 + D[2] * P2;
+                    const float g1 = D[3] * P0 + D[4] * P1 + D[5] * P2;
+                    const float g2 = D[6] * P0 + D[7] * P1 + D[8] * P2;
+                    const f2 w = N0 * g0 + N1 * g1 + N2 * g2;
+                    fu[(3 + kk) * RP] = w.x; fv[3 + kk] = w.y;
+                }
+                fu[9 * RP] = -mxf;  fv[9] = -myf;
+                fu[10 * RP] = -1.f; fv[10] = -1.f;
+                const float kxi = c3 * c2 * e1, klam = c3 * e2, kal = e3 * cf[46];
+                const f2 a = HM * kxi, b = HM * klam, c = HM * kal;
+                fu[11 * RP] = a.x; fv[11] = a.y;
+                fu[12 * RP] = b.x; fv[12] = b.y;
+                fu[13 * RP] = c.x; fv[13] = c.y;
+                fu[14 * RP] = (float)ru; fv[14] = (float)rv;
+            } else if (lane < prev_nv) {
+#pragma unroll
+                for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.f;
+            }
+            wave_lds_fence();
+            const int nv = min(64, cnt - c0);
+            prev_nv = nv;
+            const int ksteps = (nv + 3) >> 2;
+            f4 aU = { 0.f, 0.f, 0.f, 0.f }, aV = { 0.f, 0.f, 0.f, 0.f };
+            {
+                float a0 = fpA[0], b0 = fpB[0], a1 = fpA[4], b1 = fpB[4];
+                for (int t = 0; t < ksteps; t += 2) {
+                    const int tn = min(t + 2, 14);
+                    const float na0 = fpA[4 * tn], nb0 = fpB[4 * tn], na1 = fpA[4 * tn + 4], nb1 = fpB[4 * tn + 4];
+                    aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, aU, 0, 0, 0);
+                    aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, aU, 0, 0, 0);
+                    a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+                }
+            }
+            wave_lds_fence();
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < kTcols; ++c) fu[c * RP] = fv[c];
+            }
+            wave_lds_fence();
+            {
+                float a0 = fpA[0], b0 = fpB[0], a1 = fpA[4], b1 = fpB[4];
+                for (int t = 0; t < ksteps; t += 2) {
+                    const int tn = min(t + 2, 14);
+                    const float na0 = fpA[4 * tn], nb0 = fpB[4 * tn], na1 = fpA[4 * tn + 4], nb1 = fpB[4 * tn + 4];
+                    aV = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, aV, 0, 0, 0);
+                    aV = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, aV, 0, 0, 0);
+                    a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+                }
+            }
+            wave_lds_fence();
+            // one pass (<= 64 corners) of fp32 accumulation, then fp64
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accU[r] += (double)aU[r]; accV[r] += (double)aV[r]; }
+        }
+        camU += accU; camV += accV;
+        // ---- epilogue: identical to k_eval_gram (fp64, registers + shuffles) ----------------------------
+        {
+            const d4 sT = accU + accV;
+            const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
+            const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
+            const int l = kq < 3 ? kq : 0;
+            const double r0 = cc[l], r1 = cc[3 + l], r2 = cc[6 + l];
+            const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;
+            const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8;
+            const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
+            const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
+            char *rec = reinterpret_cast<char *>(S.rec[tgt] + (size_t)kRec * P.view_slot[view]);
+            auto st = [&](unsigned byte_off, double v) { *reinterpret_cast<double *>(rec + byte_off) = v; };
+            if (kq < 3) {
+                if (col >= 3 && col <= 8) { st(oA, mT_lo); st(oA + 384, mT_hi); }
+                else if (col == 9 || col == 10) {
+                    st(oA, mU_lo); st(oA + 8, mT_lo - mU_lo); st(oA + 384, mU_hi); st(oA + 392, mT_hi - mU_hi);
+                } else if (col >= 11 && col <= 14) { st(oA, mT_lo); st(oA + 384, mT_hi); }
+                else if (col == 15) { st(oA, 0.0); st(oA + 8, 0.0); st(oA + 384, 0.0); st(oA + 392, 0.0); }
+                else {
+                    st(oA, mT_lo); st(oA + 144, mT_hi);
+                    if (col == kq) st(8 * (kRecG + 6) + 8 * kq, mT_lo);
+                }
+                if (col == 6) {
+#pragma unroll
+                    for (int lp = 0; lp < 3; ++lp) {
+                        const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
+                        const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
+                        st(oB + 8 * lp, vlo);
+                        st(oB + 144 + 8 * lp, vhi);
+                        if (lp == kq) st(8 * (kRecG + 9) + 8 * kq, vhi);
+                    }
+                }
+                if (col == 14) { st(8 * kRecG + 8 * kq, mT_lo); st(8 * (kRecG + 3) + 8 * kq, mT_hi); }
+            }
+        }
+    }
+    // r^T r of the camera tile (entry [14][14] = lane (col 14, kq 2), reg 3) comes from the fp64 sum
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
+    if (col == 14 && kq == 2) { camU[3] = rr; camV[3] = 0.0; }
+    wave_lds_fence();
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { lds[(kq + 4 * rg) * 16 + col] = camU[rg]; lds[256 + (kq + 4 * rg) * 16 + col] = camV[rg]; }
+    __syncthreads();
+    {
+        const int t = threadIdx.x;
+        const size_t st = lds_wave;
+        double *part = S.campart + (size_t)512 * blockIdx.x;
+        part[t] = (lds_all[t] + lds_all[st + t]) + (lds_all[2 * st + t] + lds_all[3 * st + t]);
+        part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
+    }
+}
+

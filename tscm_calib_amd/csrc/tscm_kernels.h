@@ -221,6 +221,9 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 // LDS, Jacobian columns transposed through LDS (column-major, pitch 130: conflict-free
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
 // dynamic LDS: 16*rp + kCst + 2*n_points doubles.
+
+#include "tscm_eval_f32.h"
+
 // ---------------------------------------------------------------------------------------------
 template <int RPC>   // RPC > 0: compile-time LDS pitch (HV = RPC - 2): all tile offsets become immediates
 __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)

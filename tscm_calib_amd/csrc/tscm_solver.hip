@@ -68,7 +68,8 @@ struct tscm_solver {
     double *d_init_cam = nullptr, *d_init_intr = nullptr, *d_init_board = nullptr;
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
-    size_t lds_eval = 0, lds_solve = 0;
+    size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0;
+    bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     int ablate = 0;                     // TSCM_ABLATE: profiling aid (skips parts of k_eval_gram; results invalid)
     // dominant-kernel timing
     bool timing = false;
@@ -124,6 +125,7 @@ extern "C" void tscm_default_options(tscm_options *o, int mono)
     o->max_num_consecutive_invalid_steps = 5;
     o->jacobi_scaling = 1;
     o->check_every = 4;
+    o->jacobian_fp32 = 0;
 }
 
 static int validate(const tscm_problem *p)
@@ -423,6 +425,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
     s->lds_eval = 4 * lds_eval_bytes;
+    s->lds_eval32 = 4 * sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points);
     { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 5 * NN); }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
@@ -472,7 +475,8 @@ static int launch_eval(tscm_solver *s, int cand)
         HIP_TRY(hipEventRecord(e0, s->stream));
     }
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
-    if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
+    if (s->f32_jacobian) hipLaunchKernelGGL(k_eval_gram_f32, dim3(P.n_chunks / 4), dim3(256), s->lds_eval32, s->stream, P, s->S, cand);
+    else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
     else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
     if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
@@ -556,6 +560,8 @@ extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *op
     HIP_TRY(hipSetDevice(s->device));
     DevState &S = s->S;
     std::memset(sum, 0, sizeof(*sum));
+    s->f32_jacobian = opt.jacobian_fp32 != 0;
+    if (s->f32_jacobian && s->lds_eval32 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
 
     // control block
     Ctrl *h = s->h_ctrl;
@@ -598,6 +604,7 @@ extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *op
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     const double t1 = wall();
+    s->f32_jacobian = false;            // the other entry points (functor / normal-equation evaluation) are always fp64
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(h, S.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
     if ((rc = collect_timing(s))) return rc;

@@ -46,6 +46,7 @@ class COptions(C.Structure):
         ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
         ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
         ("max_num_consecutive_invalid_steps", C.c_int), ("jacobi_scaling", C.c_int), ("check_every", C.c_int),
+        ("jacobian_fp32", C.c_int),
     ]
 
 
