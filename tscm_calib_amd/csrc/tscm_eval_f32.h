@@ -24,8 +24,9 @@ __host__ __device__ inline int eval_f32_lds_doubles(int n_points) { return kTile
 
 __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState S, int cand)
 {
-    if (S.ctrl->done) return;
-    const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
+    // the control block is read together with the static chunk tables (one memory round trip, not two);
+    // the early exit is taken right before the first view
+    const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lds_wave = eval_f32_lds_doubles(P.n_points);
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     }
     const float *fpB = Fl + col * RP + kq;                              // B operand: tile column col
     const float *fpA = Fl + ((col >> 2) + 4 * (col & 3)) * RP + kq;     // A operand: tile column pi(col)
+    if (ctrl_done) return;
+    const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     for (int view = vb; view < ve; ++view) {
         const int cnt = P.view_count[view];
         const int off = P.view_obs[view];

@@ -96,6 +96,8 @@ struct DevProblem {
     int n_bchunks, n_tiles;
     const unsigned char *cam_const, *cam_active;
     const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
+    const int *act_map;                // [n_pad] compact index -> padded column (first n_act entries)
+    int n_act;
 };
 
 struct DevState {
@@ -222,14 +224,13 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
 // dynamic LDS: 16*rp + kCst + 2*n_points doubles.
 
-#include "tscm_eval_f32.h"
-
 // ---------------------------------------------------------------------------------------------
 template <int RPC>   // RPC > 0: compile-time LDS pitch (HV = RPC - 2): all tile offsets become immediates
 __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
 {
-    if (S.ctrl->done) return;
-    const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
+    // the control block is read together with the static chunk tables (one memory round trip, not two);
+    // the early exit is taken right before the first view
+    const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps chunk/view/cnt in SGPRs
     double *lds = lds_all + (size_t)wave * P.lds_wave;     // every wave works in its own LDS region
@@ -265,6 +266,8 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + vb];
         if (lane < P.view_count[vb]) { pf_u = P.obs_u[P.view_obs[vb] + lane]; pf_v = P.obs_v[P.view_obs[vb] + lane]; }
     }
+    if (ctrl_done) return;
+    const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     for (int view = vb; view < ve; ++view) {
         const int cnt = P.view_count[view];
         const int off = P.view_obs[view];
@@ -444,6 +447,8 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
     }
 }
+
+#include "tscm_eval_f32.h"
 
 // per-camera raw tile (GU | GV) reduction, level 1: one block per (camera, group)
 __device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int blk)
@@ -869,18 +874,25 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     const double *H = S.H[cur];
     if (tid == 0) s_fail = S.ctrl->lin_fail;
-    for (int i = tid; i < N; i += 256) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; }
+    __shared__ int s_map[N];          // compact index -> padded column, -1 past the last free column
+    for (int i = tid; i < N; i += 256) {
+        s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0;
+        s_map[i] = i < P.n_act ? P.act_map[i] : -1;
+        yv[i] = 0.0;
+    }
+    const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
     __syncthreads();
     // ---- build my tile (lower tiles only); the diagonal thread also owns its slice of the rhs ----
     double a[TS][TS], bd[TS];
-    if (tj <= ti) {
+    if (tj <= ti && ti < NP) {
 #pragma unroll
         for (int r = 0; r < TS; ++r) {
 #pragma unroll
             for (int c = 0; c < TS; ++c) {
-                const int i = ti * TS + r, j = tj * TS + c;
-                double v = (i == j) ? 1.0 : 0.0;
-                if (s_act[i] && s_act[j]) {
+                const int ci = ti * TS + r, cj = tj * TS + c;
+                const int i = s_map[ci], j = s_map[cj];
+                double v = (ci == cj) ? 1.0 : 0.0;
+                if (i >= 0 && j >= 0) {
                     const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
                     const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
                     // T holds the upper camera-pair blocks; (i, j) with mi > mj is block (mj, mi) transposed
@@ -892,12 +904,12 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
             }
         }
     }
-    if (ti == tj) {
+    if (ti == tj && ti < NP) {
 #pragma unroll
         for (int r = 0; r < TS; ++r) {
-            const int i = ti * TS + r;
+            const int i = s_map[ti * TS + r];
             bd[r] = 0.0;
-            if (s_act[i]) { const int mj = i >> 4, b = i & 15; bd[r] = s_sc[i] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)i * n + mj * 16 + kFR]); }
+            if (i >= 0) { const int mj = i >> 4, b = i & 15; bd[r] = s_sc[i] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)i * n + mj * 16 + kFR]); }
         }
     }
     // ---- factorisation: ONE barrier per panel ------------------------------------------------------
@@ -905,11 +917,11 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     // the diagonal thread factors its tile, inverts the 4x4 / 8x8 factor and forward-substitutes its
     // rhs slice; after it every trailing thread forms X_i = A_i L_kk^{-T}, X_j itself and applies the
     // rank-TS update (LDS buffers alternate between panels, so no second barrier is needed).
-    for (int tk = 0; tk < 16; ++tk) {
+    for (int tk = 0; tk < NP; ++tk) {
         double *Ar = Xb + (tk & 1) * (N * TS);          // raw panel column  [N][TS]
         double *Li = Ld + (tk & 1) * (TS * TS);         // inverse of the diagonal factor (lower)
         double *wk = wq + (tk & 1) * TS;                // w slice of the panel
-        if (tj == tk && ti > tk) {
+        if (tj == tk && ti > tk && ti < NP) {
 #pragma unroll
             for (int r = 0; r < TS; ++r)
 #pragma unroll
@@ -963,7 +975,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
                 for (int c = 0; c < TS; ++c) Li[r * TS + c] = inv[r][c];
         }
         __syncthreads();
-        if (ti > tk && tj >= tk && tj <= ti) {
+        if (ti > tk && ti < NP && tj >= tk && tj <= ti) {
             // X_i = A_i L_kk^{-T}:  X[r][c] = sum_{q <= c} A[r][q] * inv[c][q]
             double xi[TS][TS];
 #pragma unroll
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
         }
     }
     // ---- publish L, back-substitute L^T y = w with one wave -----------------------------------------
-    if (tj <= ti) {
+    if (tj <= ti && ti < NP) {
 #pragma unroll
         for (int r = 0; r < TS; ++r)
 #pragma unroll
@@ -1034,8 +1046,8 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
         constexpr int R = N / 64;
         double w[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) w[q] = wp[tid + 64 * q];
-        for (int tk = 15; tk >= 0; --tk) {
+        for (int q = 0; q < R; ++q) w[q] = tid + 64 * q < NP * TS ? wp[tid + 64 * q] : 0.0;
+        for (int tk = NP - 1; tk >= 0; --tk) {
             const int k0 = tk * TS;
             double y[TS];
 #pragma unroll
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) yv[tid + 64 * q] = w[q];
+        for (int q = 0; q < R; ++q) { const int pi = s_map[tid + 64 * q]; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
     }
     __syncthreads();
     // ---- yhat, candidate camera parameters, camera part of model cost change / step norm --------

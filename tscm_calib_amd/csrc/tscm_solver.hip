@@ -383,6 +383,13 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
         std::vector<unsigned char> col_active((size_t)s->n_pad, 0);
         for (int i = 0; i < s->n_pad; ++i) { const int m = i >> 4, a = i & 15; col_active[i] = (a < kFA && cam_active[m] && !(a < 6 && cam_const[m])) ? 1 : 0; }
         if ((rc = dev_upload(s, &P.col_active, col_active))) return rc;
+        // compact numbering of the free camera-side columns: the reduced system is factored without the
+        // identity rows of constant / padding columns
+        std::vector<int> act_map((size_t)s->n_pad, -1);
+        int n_act = 0;
+        for (int i = 0; i < s->n_pad; ++i) if (col_active[i]) act_map[n_act++] = i;
+        P.n_act = n_act;
+        if ((rc = dev_upload(s, &P.act_map, act_map))) return rc;
     }
 
     for (int k = 0; k < 2; ++k) {
