@@ -98,3 +98,13 @@ def test_synthetic_generator_is_deterministic_and_valid():
     assert np.array_equal(p.view_camera[:4], [0, 1, 1, 2])
     p8 = synth.make_problem(8, 4, 6)
     assert p8.n_cameras == 8 and p8.cam_pose_constant[0] == 1
+
+
+@pytest.mark.parametrize("src", ["dropin_demo.cpp", "multicalib_demo.cpp"])
+def test_cpp_hosts_compile_and_link_against_the_abi(tmp_path, src):
+    """The C++11 hosts (the reference's language) -- the raw C ABI one and the class mirror
+    include/tscm/tscm_calib.hpp -- build with plain g++ against libtscm_hip.so."""
+    import subprocess
+    csrc = os.path.join(ROOT, "tscm_calib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", src),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", str(tmp_path / "a.out")])

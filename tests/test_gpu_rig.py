@@ -101,3 +101,51 @@ def test_rig_init_full_size_properties(hip_device):
     # boards: each is seen by two cameras; the chosen pose is one of the two hypotheses
     gt = p.meta["gt_board_rt"]
     assert np.median(np.abs(g["board_rt"][:, 3:] - gt[:, 3:])) < 30.0          # mm: an initial guess
+
+
+def test_cpp_class_mirror_runs_the_reference_flow(hip_device, tmp_path):
+    """examples/multicalib_demo.cpp: the reference's main.cpp flow (MultiCalib(cameras, worlds);
+    calibrate(); YAML) written against include/tscm/tscm_calib.hpp, compared with the oracle chain."""
+    import os, struct, subprocess
+    from tscm_calib_amd import calib_io, maps
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "multicalib_demo")
+    csrc = os.path.join(root, "tscm_calib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "multicalib_demo.cpp"),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", exe])
+    p = synth.make_problem(4, 16, 13)
+    inp = synth.make_rig_input(p)
+    C, B, n = inp.n_cameras, inp.n_boards, inp.n_points
+    with open(tmp_path / "rig.bin", "wb") as f:
+        f.write(struct.pack("5i", C, B, n, 9, 6))
+        for a in (inp.worlds, inp.intr, inp.has, inp.Rt, inp.pix_u, inp.pix_v):
+            f.write(np.ascontiguousarray(a).tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "rig.bin"), str(tmp_path / "result.bin"), str(tmp_path / "calib.yaml")]).decode()
+    assert "average reproject error" in out
+    raw = open(tmp_path / "result.bin", "rb").read()
+    nd = 6 * C + 9 * C + 6 * B + C + 2
+    vals = np.frombuffer(raw[:8 * nd], dtype=np.float64)
+    cam_rt, intr, board_rt = vals[:6 * C].reshape(C, 6), vals[6 * C:15 * C].reshape(C, 9), vals[15 * C:15 * C + 6 * B].reshape(B, 6)
+    cam_err, mean_err, focal0 = vals[15 * C + 6 * B:15 * C + 6 * B + C], vals[nd - 2], vals[nd - 1]
+    term, iters = struct.unpack("2i", raw[8 * nd:8 * nd + 8])
+    # oracle chain: constructor -> calibrate -> error report
+    o = orc.rig_init(inp)
+    po = rig.problem_from_rig(inp, o)
+    so = orc.solve(po)
+    assert term == so["termination_type"] == 0 and iters == so["num_iterations"]
+    assert np.max(np.abs(intr[:, :7] - po.intr[:, :7]) / np.abs(po.intr[:, :7])) < 1e-6
+    assert np.max(np.abs(cam_rt - po.cam_rt)) < 1e-6 * np.max(np.abs(po.cam_rt))
+    assert np.max(np.abs(board_rt[:, 3:] - po.board_rt[:, 3:])) < 1e-6 * np.max(np.abs(po.board_rt[:, 3:]))
+    g, per = orc.mean_reprojection_error(po)
+    assert abs(mean_err - g) < 1e-6 * g and np.max(np.abs(cam_err - per)) < 1e-6 * g
+    count = np.full(B, n, dtype=np.int32) * inp.has[0]
+    fo, _, _ = orc.estimate_focal(inp.pix_u[0], inp.pix_v[0], count, 9, 6, 639.5, 539.5)
+    assert abs(focal0 - fo) < 1e-9 * fo
+    # the YAML holds the calibrated intrinsics and Twc = [R(cam_rt) | t]
+    yi, yT = calib_io.read_calib_yaml(str(tmp_path / "calib.yaml"))
+    assert np.array_equal(yi, intr)
+    assert np.max(np.abs(yT[:, :, :3] - synth.rodrigues(cam_rt[:, :3]))) < 1e-12 and np.array_equal(yT[:, :, 3], cam_rt[:, 3:])
+    # first 16 entries of camera 0's undistortion table
+    mx = np.frombuffer(raw[8 * nd + 8:8 * nd + 8 + 64], dtype=np.float32)
+    ox, _ = orc.build_maps([maps.undistort_desc(intr[0], 300.0, 300.0, 639.5, 539.5, 64, 48)], 64 * 48)
+    assert np.array_equal(mx, ox[:16])
