@@ -2,7 +2,7 @@
 // MultiCalib::calibrate() / TripleSphereCamera::refinement() would, with
 // std::vector parameter blocks instead of the OpenCV-backed classes.
 //
-//   g++ -std=c++11 -I include examples/dropin_demo.cpp -L tscm_calib_amd/csrc -ltscm_hip \
+//   g++ -std=c++11 -I include examples/dropin_demo.cpp -L tscm_calib_amd/csrc -ltscm_hip
 //       -Wl,-rpath,$PWD/tscm_calib_amd/csrc -o examples/dropin_demo
 //   examples/dropin_demo problem.bin result.bin
 //
