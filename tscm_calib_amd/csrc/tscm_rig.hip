@@ -216,6 +216,27 @@ __global__ __launch_bounds__(64) void k_rig_hyp_errors(StageArgs s)
     if ((int)(blockIdx.x * 64 + threadIdx.x) < s.J) s.partial[(size_t)blockIdx.y * s.J + j] = error;
 }
 
+// prepared points of one stage: thread per (common board h, corner c)
+__global__ void k_rig_points(int K, int n, int B, int i, const int *__restrict__ common, const double *__restrict__ pose,
+                             const double *__restrict__ pu, const double *__restrict__ pv, const double *__restrict__ worlds,
+                             HypPoint *__restrict__ pts)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= K * n) return;
+    const int h = t / n, c = t - h * n, j = common[h];
+    const size_t vi = (size_t)i * B + j, vp = (size_t)(i - 1) * B + j;
+    const double *Pi = pose + 12 * vi, *Pp = pose + 12 * vp;
+    const double x = worlds[3 * c], y = worlds[3 * c + 1], z = worlds[3 * c + 2];
+    HypPoint a, b;
+    a.qx = Pi[0] * x + Pi[1] * y + Pi[2] * z + Pi[9];  a.qy = Pi[3] * x + Pi[4] * y + Pi[5] * z + Pi[10]; a.qz = Pi[6] * x + Pi[7] * y + Pi[8] * z + Pi[11];
+    b.qx = Pp[0] * x + Pp[1] * y + Pp[2] * z + Pp[9];  b.qy = Pp[3] * x + Pp[4] * y + Pp[5] * z + Pp[10]; b.qz = Pp[6] * x + Pp[7] * y + Pp[8] * z + Pp[11];
+    a.pu = pu[vp * n + c]; a.pv = pv[vp * n + c];       // seen by camera i, scored against camera i-1's pixels
+    b.pu = pu[vi * n + c]; b.pv = pv[vi * n + c];
+    a.pad[0] = a.pad[1] = a.pad[2] = b.pad[0] = b.pad[1] = b.pad[2] = 0.0;
+    pts[((size_t)h * 2) * n + c] = a;
+    pts[((size_t)h * 2 + 1) * n + c] = b;
+}
+
 __global__ void k_rig_hyp_reduce(const double *partial, int J, int ksplit, double *err)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +299,7 @@ struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T)); }
+    hipError_t upload(const T *h, size_t n) { hipError_t e = alloc(n); if (e != hipSuccess || n == 0) return e; return hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice); }
     hipError_t upload(const std::vector<T> &h) { hipError_t e = alloc(h.size()); if (e != hipSuccess || h.empty()) return e; return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice); }
 };
 
@@ -325,10 +347,15 @@ extern "C" int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_resu
             std::memcpy(&pose[12 * ((size_t)m * B + j)], R.a, sizeof(R.a));
             std::memcpy(&pose[12 * ((size_t)m * B + j) + 9], t.a, sizeof(t.a));
         }
-    std::vector<double> worlds(in->worlds, in->worlds + 3 * (size_t)n), intr(in->intr, in->intr + 9 * (size_t)C);
-    DevBuf<double> d_worlds, d_intr;
-    RIG_TRY(d_worlds.upload(worlds));
-    RIG_TRY(d_intr.upload(intr));
+    // everything the two selection loops read goes to the device once
+    DevBuf<double> d_worlds, d_intr, d_pose, d_pu, d_pv;
+    DevBuf<unsigned char> d_has;
+    RIG_TRY(d_worlds.upload(in->worlds, 3 * (size_t)n));
+    RIG_TRY(d_intr.upload(in->intr, 9 * (size_t)C));
+    RIG_TRY(d_pose.upload(pose));
+    RIG_TRY(d_pu.upload(in->pix_u, (size_t)C * B * n));
+    RIG_TRY(d_pv.upload(in->pix_v, (size_t)C * B * n));
+    RIG_TRY(d_has.upload(in->has, (size_t)C * B));
 
     std::vector<M3> camR(C); std::vector<V3> camt(C);
     for (int i = 0; i < C; ++i) {
@@ -342,9 +369,8 @@ extern "C" int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_resu
         for (int j = 0; j < B; ++j) if (in->has[(size_t)(i - 1) * B + j] && in->has[(size_t)i * B + j]) common.push_back(j);
         const int K = (int)common.size();
         if (K == 0) return tscm_set_error(TSCM_E_INVALID, "adjacent cameras " + std::to_string(i - 1) + " and " + std::to_string(i) + " share no board");
-        // hypotheses (:29-48) and the prepared points of the stage
+        // hypotheses (:29-48) on the host, the prepared points of the stage on the device
         std::vector<double> Rs(9 * (size_t)K), ts(3 * (size_t)K);
-        std::vector<HypPoint> pts((size_t)K * 2 * n);
         for (int h = 0; h < K; ++h) {
             const int j = common[h];
             M3 Ri, Rk; V3 ti, tk;
@@ -355,18 +381,14 @@ extern "C" int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_resu
             const M3 Rh = mul(Rik, camR[i - 1]);
             const V3 th = add(mul(Rik, camt[i - 1]), tik);
             std::memcpy(&Rs[9 * (size_t)h], Rh.a, sizeof(Rh.a)); std::memcpy(&ts[3 * (size_t)h], th.a, sizeof(th.a));
-            const size_t bi = (size_t)n * ((size_t)i * B + j), bp = (size_t)n * ((size_t)(i - 1) * B + j);
-            HypPoint *d0 = &pts[(size_t)h * 2 * n], *d1 = d0 + n;
-            for (int c = 0; c < n; ++c) {
-                const V3 w{ { in->worlds[3 * c], in->worlds[3 * c + 1], in->worlds[3 * c + 2] } };
-                const V3 qi = add(mul(Ri, w), ti), qk = add(mul(Rk, w), tk);
-                d0[c] = HypPoint{ qi.a[0], qi.a[1], qi.a[2], in->pix_u[bp + c], in->pix_v[bp + c], { 0, 0, 0 } };
-                d1[c] = HypPoint{ qk.a[0], qk.a[1], qk.a[2], in->pix_u[bi + c], in->pix_v[bi + c], { 0, 0, 0 } };
-            }
         }
         DevBuf<double> dRs, dts, dpart, derr;
         DevBuf<HypPoint> dpts;
-        RIG_TRY(dRs.upload(Rs)); RIG_TRY(dts.upload(ts)); RIG_TRY(dpts.upload(pts));
+        DevBuf<int> dcommon;
+        RIG_TRY(dRs.upload(Rs)); RIG_TRY(dts.upload(ts)); RIG_TRY(dcommon.upload(common));
+        RIG_TRY(dpts.alloc((size_t)K * 2 * n));
+        hipLaunchKernelGGL(k_rig_points, dim3((unsigned)(((size_t)K * n + 255) / 256)), dim3(256), 0, 0, K, n, B, i, dcommon.p, d_pose.p, d_pu.p, d_pv.p,
+                           d_worlds.p, dpts.p);
         const bool skew = in->intr[9 * i + 7] != 0.0 || in->intr[9 * i + 8] != 0.0 || in->intr[9 * (i - 1) + 7] != 0.0 || in->intr[9 * (i - 1) + 8] != 0.0;
         auto kern = skew ? k_rig_hyp_errors<true> : k_rig_hyp_errors<false>;
         // one round of resident waves: slices of the boards so that (hypothesis groups x slices) fills the chip once
@@ -413,16 +435,13 @@ extern "C" int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_resu
     }
     // boards (:90-151)
     if (B > 0) {
-        std::vector<unsigned char> has(in->has, in->has + (size_t)C * B);
-        std::vector<double> pu(in->pix_u, in->pix_u + (size_t)C * B * n), pv(in->pix_v, in->pix_v + (size_t)C * B * n);
         std::vector<double> cR(9 * (size_t)C), ct(3 * (size_t)C);
         for (int i = 0; i < C; ++i) { std::memcpy(&cR[9 * (size_t)i], camR[i].a, sizeof(camR[i].a)); std::memcpy(&ct[3 * (size_t)i], camt[i].a, sizeof(camt[i].a)); }
-        DevBuf<unsigned char> dhas, dinit;
-        DevBuf<double> dpose, dpu, dpv, dcR, dct, dbR, dbt;
-        RIG_TRY(dhas.upload(has)); RIG_TRY(dpose.upload(pose)); RIG_TRY(dpu.upload(pu)); RIG_TRY(dpv.upload(pv));
+        DevBuf<unsigned char> dinit;
+        DevBuf<double> dcR, dct, dbR, dbt;
         RIG_TRY(dcR.upload(cR)); RIG_TRY(dct.upload(ct));
         RIG_TRY(dbR.alloc(9 * (size_t)B)); RIG_TRY(dbt.alloc(3 * (size_t)B)); RIG_TRY(dinit.alloc((size_t)B));
-        hipLaunchKernelGGL(k_rig_boards, dim3((B + 127) / 128), dim3(128), 0, 0, C, B, n, dhas.p, dpose.p, dpu.p, dpv.p, d_worlds.p, d_intr.p,
+        hipLaunchKernelGGL(k_rig_boards, dim3((B + 127) / 128), dim3(128), 0, 0, C, B, n, d_has.p, d_pose.p, d_pu.p, d_pv.p, d_worlds.p, d_intr.p,
                            dcR.p, dct.p, dbR.p, dbt.p, dinit.p);
         RIG_TRY(hipDeviceSynchronize());
         RIG_TRY(hipGetLastError());
