@@ -51,7 +51,14 @@ def main():
         out[key] = dict(seconds_kernel=sec, pixels_per_second=off / sec, seconds_call_incl_pcie=wall)
     out["value"] = out["fast"]["pixels_per_second"]
     gbs = out["value"] * BYTES_PER_PIXEL / 1e9
-    out["roofline"] = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_side_kernels.json")))["k_build_maps"]
+        if a.views == 2000:
+            traffic = pm["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    out["roofline"] = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
                            exact_variant_GBs=out["exact"]["pixels_per_second"] * BYTES_PER_PIXEL / 1e9)
     if not a.no_cpu:
         from oracle import pyoracle as orc   # cpu_baseline leg only

@@ -25,6 +25,14 @@ FLOP_PER_PROJECTION = 60
 PEAK_FP64_VALU_TFLOPS = 78.6
 
 
+def _traffic(config):
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_side_kernels.json")))["k_rig_hyp_errors"]
+        return pm["hbm_bytes_per_launch"] if config == 4 else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=4)
@@ -51,7 +59,7 @@ def main():
                seconds_hypotheses=best["seconds_hypotheses"], seconds_total=best["seconds_total"],
                roofline=dict(bound="fp64-valu", achieved=rate * FLOP_PER_PROJECTION / 1e12, peak=PEAK_FP64_VALU_TFLOPS,
                              unit="TFLOP/s", frac=rate * FLOP_PER_PROJECTION / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                             traffic=None))
+                             traffic=_traffic(a.config)))
     if not a.no_cpu:
         from oracle import pyoracle as orc   # cpu_baseline leg only
         from tests import helpers as H
