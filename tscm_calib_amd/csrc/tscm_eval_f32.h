@@ -50,31 +50,37 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
 #pragma unroll
     for (int c = 0; c < 16; ++c) Fl[c * RP + lane] = 0.f;  // all 64 rows incl. the all-zero 16th tile column
     int prev_nv = 0;
-    const unsigned oA = 8u * (unsigned)(col <= 2 ? kRecEE + 6 * kq + col
-                                      : col <= 8 ? 16 * kq + col - 3
-                                      : col == 9 ? 16 * kq + 6 : col == 10 ? 16 * kq + 8
-                                      : col <= 14 ? 16 * kq + col - 1 : 16 * kq + 14);
-    const unsigned oB = 8u * (unsigned)(kRecEE + 6 * kq + 3);
     double pf_c = 0.0, pf_u = 0.0, pf_v = 0.0;
-    if (vb < ve) {
-        if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + vb];
-        if (lane < P.view_count[vb]) { pf_u = P.obs_u[P.view_obs[vb] + lane]; pf_v = P.obs_v[P.view_obs[vb] + lane]; }
-    }
     const float *fpB = Fl + col * RP + kq;                              // B operand: tile column col
     const float *fpA = Fl + ((col >> 2) + 4 * (col & 3)) * RP + kq;     // A operand: tile column pi(col)
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
-    for (int view = vb; view < ve; ++view) {
-        const int cnt = P.view_count[view];
-        const int off = P.view_obs[view];
+    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
+    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVConst * P.V);
+    const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
+    const unsigned vc_off = 8u * (unsigned)lane * (unsigned)P.V;       // lane k reads vconst[k][view]
+    // Per-view metadata (corner count, record slot) of a block of <= 64 views sits in lane registers and is
+    // read with v_readlane; the observations of a camera's views are contiguous, so the offset is a running
+    // sum.  No dependent global load -- and therefore no in-order vmcnt wait behind the previous view's
+    // record stores -- is left inside the view loop.
+    int off_next = vb < ve ? P.view_obs[vb] : 0;
+    for (int vbase = vb; vbase < ve; vbase += 64) {
+    const int vend = min(ve, vbase + 64);
+    int m_cnt = 0, m_slot = 0;
+    if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
+    asm volatile("" : "+v"(m_cnt), "+v"(m_slot), "+s"(off_next));       // the loads complete here, outside the view loop
+    {
+        const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
+        if (lane < kVConst) pf_c = buf_load_f64(r_vc, vc_off, 8u * (unsigned)vbase);
+        if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
         wave_lds_fence();
-        if (lane < kVConst) { cst[lane] = pf_c; cs[lane] = (float)pf_c; }
-        const double ou0 = pf_u, ov0 = pf_v;
-        if (view + 1 < ve) {
-            if (lane < kVConst) pf_c = S.vconst[(size_t)lane * P.V + view + 1];
-            if (lane < P.view_count[view + 1]) { pf_u = P.obs_u[P.view_obs[view + 1] + lane]; pf_v = P.obs_v[P.view_obs[view + 1] + lane]; }
-        }
-        wave_lds_fence();
+        if (lane < kVConst) { cst[lane] = pf_c; cs[lane] = (float)pf_c; }   // first view of the block
+    }
+    for (int view = vbase; view < vend; ++view) {
+        const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
+        const int off = off_next;
+        off_next = off + cnt;
+        wave_lds_fence();                       // previous view's epilogue has finished with LDS; cst / cs hold this view's constants
         d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
             float fv[kTcols];
             if (valid) {
                 const double x = bxy[2 * j], y = bxy[2 * j + 1];
-                const double ou = c0 ? P.obs_u[off + j] : ou0, ov = c0 ? P.obs_v[off + j] : ov0;
+                const double ou = c0 ? buf_load_f64(r_u, 8u * j, 8u * (unsigned)off) : pf_u, ov = c0 ? buf_load_f64(r_v, 8u * j, 8u * (unsigned)off) : pf_v;
                 // ---- fp64: board -> world -> camera, triple sphere, residual (multi_calib.h:158-193) ----
                 const double Pw0 = x * cst[0] + y * cst[3] + cst[6];
                 const double Pw1 = x * cst[1] + y * cst[4] + cst[7];
@@ -155,6 +161,18 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.f;
             }
+            if (c0 == 0) {
+                // Prefetch of the next view, issued once the current view's observations have been consumed: the
+                // loads reuse the same registers (no copy that would have to wait for them), and everything
+                // between here and their use at the top of the next view is 13 unconditional stores.
+                // Always issued (the block's last view re-reads itself; lanes past the corner count read past
+                // the end of the buffer, i.e. zero): unconditional loads keep the vmcnt bookkeeping exact.
+                const int vn = min(view + 1, vend - 1);
+                const int cn = view + 1 < vend ? __builtin_amdgcn_readlane(m_cnt, vn - vbase) : 0;
+                pf_c = buf_load_f64(r_vc, lane < kVConst ? vc_off : 0xffffe000u, 8u * (unsigned)vn);
+                pf_u = buf_load_f64(r_u, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
+                pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
+            }
             wave_lds_fence();
             const int nv = min(64, cnt - c0);
             prev_nv = nv;
@@ -191,9 +209,21 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
 #pragma unroll
             for (int r = 0; r < 4; ++r) { accU[r] += (double)aU[r]; accV[r] += (double)aV[r]; }
         }
+        // next view's constants: written here, before this view's record stores (see k_eval_gram)
+        if (lane < kVConst) { cst[lane] = pf_c; cs[lane] = (float)pf_c; }
         camU += accU; camV += accV;
         // ---- epilogue: identical to k_eval_gram (fp64, registers + shuffles) ----------------------------
         {
+            // lane-constant record offsets are rebuilt per view from an opaque copy of the lane id: ~15 integer
+            // instructions instead of registers that stay live (and get spilled) across the whole view loop
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int col = le & 15, kq = le >> 4;
+            const unsigned oA = 8u * (unsigned)(col <= 2 ? kRecEE + 6 * kq + col
+                                              : col <= 8 ? 16 * kq + col - 3
+                                              : col == 9 ? 16 * kq + 6 : col == 10 ? 16 * kq + 8
+                                              : col <= 14 ? 16 * kq + col - 1 : 16 * kq + 14);
+            const unsigned oB = 8u * (unsigned)(kRecEE + 6 * kq + 3);
             const d4 sT = accU + accV;
             const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
             const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
@@ -203,32 +233,38 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
             const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8;
             const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
             const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
-            char *rec = reinterpret_cast<char *>(S.rec[tgt] + (size_t)kRec * P.view_slot[view]);
-            auto st = [&](unsigned byte_off, double v) { *reinterpret_cast<double *>(rec + byte_off) = v; };
-            if (kq < 3) {
-                if (col >= 3 && col <= 8) { st(oA, mT_lo); st(oA + 384, mT_hi); }
-                else if (col == 9 || col == 10) {
-                    st(oA, mU_lo); st(oA + 8, mT_lo - mU_lo); st(oA + 384, mU_hi); st(oA + 392, mT_hi - mU_hi);
-                } else if (col >= 11 && col <= 14) { st(oA, mT_lo); st(oA + 384, mT_hi); }
-                else if (col == 15) { st(oA, 0.0); st(oA + 8, 0.0); st(oA + 384, 0.0); st(oA + 392, 0.0); }
-                else {
-                    st(oA, mT_lo); st(oA + 144, mT_hi);
-                    if (col == kq) st(8 * (kRecG + 6) + 8 * kq, mT_lo);
-                }
-                if (col == 6) {
+            const unsigned rec_off = 8u * (unsigned)kRec * (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase);   // wave-uniform
+            // Thirteen UNCONDITIONAL buffer stores: a lane without an entry for a slot stores to an offset past
+            // the end of the record array, which the buffer bounds check drops.  No divergent branch around a
+            // memory instruction is left in the view loop, so the compiler knows exactly how many stores follow
+            // the prefetch loads and waits for those loads with vmcnt(13) -- not for the stores themselves.
+            constexpr unsigned BAD = 0xffffe000u;
+            auto st = [&](bool ok, unsigned byte_off, double v) { buf_store_f64(r_rec, ok ? byte_off : BAD, rec_off, v); };
+            const bool k3 = kq < 3, split = col == 9 || col == 10, zero = col == 15, c6 = k3 && col == 6, c14 = k3 && col == 14;
+            // main entries: rows kq (lo) and 3 + kq (hi) of this lane's column; fx|fy and cx|cy store their u-part here
+            st(k3, oA, split ? mU_lo : (zero ? 0.0 : mT_lo));
+            st(k3, oA + (col <= 2 ? 144u : 384u), split ? mU_hi : (zero ? 0.0 : mT_hi));
+            // ... and their v-part (= total - u-part) next to it; column 15 zeroes the two padding columns
+            st(k3 && (split || zero), oA + 8, zero ? 0.0 : mT_lo - mU_lo);
+            st(k3 && (split || zero), oA + 392, zero ? 0.0 : mT_hi - mU_hi);
+            // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]   (lanes of tile column 6)
+            double vhi_kq = 0.0;
 #pragma unroll
-                    for (int lp = 0; lp < 3; ++lp) {
-                        const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
-                        const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
-                        st(oB + 8 * lp, vlo);
-                        st(oB + 144 + 8 * lp, vhi);
-                        if (lp == kq) st(8 * (kRecG + 9) + 8 * kq, vhi);
-                    }
-                }
-                if (col == 14) { st(8 * kRecG + 8 * kq, mT_lo); st(8 * (kRecG + 3) + 8 * kq, mT_hi); }
+            for (int lp = 0; lp < 3; ++lp) {
+                const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
+                const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
+                st(c6, oB + 8 * lp, vlo);
+                st(c6, oB + 144 + 8 * lp, vhi);
+                if (lp == kq) vhi_kq = vhi;
             }
+            // diag(E^T E): w_b part from the lanes (col == kq), t_b part from the lanes of column 6
+            st((k3 && col == kq) || c6, 8u * (unsigned)(kRecG + (col == 6 ? 9 : 6)) + 8u * (unsigned)kq, col == 6 ? vhi_kq : mT_lo);
+            // compact E^T r
+            st(c14, 8u * (unsigned)kRecG + 8u * (unsigned)kq, mT_lo);
+            st(c14, 8u * (unsigned)(kRecG + 3) + 8u * (unsigned)kq, mT_hi);
         }
     }
+    }   // block of <= 64 views
     // r^T r of the camera tile (entry [14][14] = lane (col 14, kq 2), reg 3) comes from the fp64 sum
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
