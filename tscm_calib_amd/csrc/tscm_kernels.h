@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     const int vend = min(ve, vbase + 64);
     int m_cnt = 0, m_slot = 0;
     if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
-    asm volatile("" : "+v"(m_cnt), "+v"(m_slot), "+s"(off_next));       // the loads complete here, outside the view loop
+    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));       // the loads complete here, outside the view loop
     {
         const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
         if (lane < kVConst) pf_c = buf_load_f64(r_vc, vc_off, 8u * (unsigned)vbase);
