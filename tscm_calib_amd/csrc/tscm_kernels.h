@@ -60,6 +60,19 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, (int)voff, (int)soff, 0);
 }
 
+// Wave-uniform constants are kept one per LANE of a VGPR and fetched with v_readlane into an SGPR pair:
+// a VALU-latency operation whose result feeds the next VALU instruction as a scalar operand, instead of
+// an LDS broadcast read with its ~100-cycle round trip (k_eval_gram had 35 of those, each followed by
+// s_waitcnt lgkmcnt(0), in the geometry of every view).
+__device__ __forceinline__ double lane_const(double v, int k)
+{
+    const v2i b = __builtin_bit_cast(v2i, v);
+    v2i r;
+    r.x = __builtin_amdgcn_readlane(b.x, k);
+    r.y = __builtin_amdgcn_readlane(b.y, k);
+    return __builtin_bit_cast(double, r);
+}
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -258,11 +271,11 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     const int chunk = blockIdx.x * 4 + wave;
     const int cam = P.chunk_cam[chunk];
     for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
-    if (lane < kCConst) cst[kVConst + lane] = S.cconst[kCConst * cam + lane];
+    const double ccam = lane < kCConst ? S.cconst[kCConst * cam + lane] : 0.0;      // camera constant k in lane k
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
-    const double *cc = cst + kVConst;          // camera constants
+    auto CC = [&](int k) { return lane_const(ccam, k); };                            // camera constants (see k_view_prep)
     // rows of lanes without a corner are kept at zero instead of being re-written every pass
     if (lane < HV) {
 #pragma unroll
@@ -292,14 +305,15 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
         if (lane < kVConst) pf_c = buf_load_f64(r_vc, vc_off, 8u * (unsigned)vbase);
         if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
-        wave_lds_fence();
-        if (lane < kVConst) cst[lane] = pf_c;   // first view of the block: the one exposed load latency per <= 64 views
+        asm volatile("" : "+v"(pf_c));         // first view of the block: the one exposed load latency per <= 64 views
     }
     for (int view = vbase; view < vend; ++view) {
         const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
         const int off = off_next;
         off_next = off + cnt;
-        wave_lds_fence();                       // previous view's epilogue has finished with LDS; cst holds this view's constants
+        wave_lds_fence();                       // previous view's epilogue has finished with LDS
+        const double vcur = pf_c;               // view constant k in lane k (complete: see below)
+        auto VC = [&](int k) { return lane_const(vcur, k); };
         d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
@@ -313,13 +327,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 const bool later_pass = RPC == 0 && c0 != 0;
                 const double ou = later_pass ? buf_load_f64(r_u, 8u * j, 8u * (unsigned)off) : pf_u, ov = later_pass ? buf_load_f64(r_v, 8u * j, 8u * (unsigned)off) : pf_v;
                 // board -> world -> camera (multi_calib.h:158-167)
-                const double Pw0 = x * cst[0] + y * cst[3] + cst[6];
-                const double Pw1 = x * cst[1] + y * cst[4] + cst[7];
-                const double Pw2 = x * cst[2] + y * cst[5] + cst[8];
-                const double X = cc[0] * Pw0 + cc[1] * Pw1 + cc[2] * Pw2 + cc[9];
-                const double Y = cc[3] * Pw0 + cc[4] * Pw1 + cc[5] * Pw2 + cc[10];
-                const double Z = cc[6] * Pw0 + cc[7] * Pw1 + cc[8] * Pw2 + cc[11];
-                const double fx = cc[39], fy = cc[40], xi = cc[43], lam = cc[44], beta = cc[45];
+                const double Pw0 = x * VC(0) + y * VC(3) + VC(6);
+                const double Pw1 = x * VC(1) + y * VC(4) + VC(7);
+                const double Pw2 = x * VC(2) + y * VC(5) + VC(8);
+                const double X = CC(0) * Pw0 + CC(1) * Pw1 + CC(2) * Pw2 + CC(9);
+                const double Y = CC(3) * Pw0 + CC(4) * Pw1 + CC(5) * Pw2 + CC(10);
+                const double Z = CC(6) * Pw0 + CC(7) * Pw1 + CC(8) * Pw2 + CC(11);
+                const double fx = CC(39), fy = CC(40), xi = CC(43), lam = CC(44), beta = CC(45);
                 // triple sphere (multi_calib.h:170-178)
                 const double rho2 = X * X + Y * Y;
                 double d1, id1, d2, id2, d3, id3;
@@ -346,19 +360,18 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 // w_b: -A (x e_k0 + y e_k1)
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
-                    const double h0 = x * cst[9 + 6 * kk] + y * cst[12 + 6 * kk];
-                    const double h1 = x * cst[10 + 6 * kk] + y * cst[13 + 6 * kk];
-                    const double h2 = x * cst[11 + 6 * kk] + y * cst[14 + 6 * kk];
+                    const double h0 = x * VC(9 + 6 * kk) + y * VC(12 + 6 * kk);
+                    const double h1 = x * VC(10 + 6 * kk) + y * VC(13 + 6 * kk);
+                    const double h2 = x * VC(11 + 6 * kk) + y * VC(14 + 6 * kk);
                     fu[kk * RP] = n00 * h0 + n01 * h1 + n02 * h2;
                     fv[kk] = n10 * h0 + n11 * h1 + n12 * h2;
                 }
                 // w_c: -A (dR_c/dw_k Pw)
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
-                    const double *D = cc + 12 + 9 * kk;
-                    const double g0 = D[0] * Pw0 + D[1] * Pw1 + D[2] * Pw2;
-                    const double g1 = D[3] * Pw0 + D[4] * Pw1 + D[5] * Pw2;
-                    const double g2 = D[6] * Pw0 + D[7] * Pw1 + D[8] * Pw2;
+                    const double g0 = CC(12 + 9 * kk + 0) * Pw0 + CC(12 + 9 * kk + 1) * Pw1 + CC(12 + 9 * kk + 2) * Pw2;
+                    const double g1 = CC(12 + 9 * kk + 3) * Pw0 + CC(12 + 9 * kk + 4) * Pw1 + CC(12 + 9 * kk + 5) * Pw2;
+                    const double g2 = CC(12 + 9 * kk + 6) * Pw0 + CC(12 + 9 * kk + 7) * Pw1 + CC(12 + 9 * kk + 8) * Pw2;
                     fu[(3 + kk) * RP] = n00 * g0 + n01 * g1 + n02 * g2;
                     fv[(3 + kk)] = n10 * g0 + n11 * g1 + n12 * g2;
                 }
@@ -367,13 +380,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 fu[10 * RP] = -1.0; fv[10] = -1.0;
                 // xi, lambda, alpha: -du/dk * dk/dparam
                 const double hu = fxk * mx, hv = fyk * my;
-                const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * cc[46];
+                const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * CC(46);
                 fu[11 * RP] = hu * kxi;  fv[11] = hv * kxi;
                 fu[12 * RP] = hu * klam; fv[12] = hv * klam;
                 fu[13 * RP] = hu * kal;  fv[13] = hv * kal;
                 // residual = observed - projected (multi_calib.h:192-193)
-                fu[14 * RP] = ou - (fx * mx + cc[41]);
-                fv[14] = ov - (fy * my + cc[42]);
+                fu[14 * RP] = ou - (fx * mx + CC(41));
+                fv[14] = ov - (fy * my + CC(42));
             } else if (lane < prev_nv) {
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.0;
@@ -426,11 +439,11 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
             }
             wave_lds_fence();
         }
-        // The next view's constants go to LDS HERE, a full MFMA phase after their load was issued and before
+        // The next view's constants are waited for HERE, a full MFMA phase after their load was issued and before
         // this view's record stores: on gfx9 loads and stores share vmcnt and may complete out of order, so any
         // wait for a load with stores in flight is a vmcnt(0) -- a wait placed right after the stores (the top
         // of the next view) would expose the whole store latency.  The geometry is done with cst by now.
-        if (lane < kVConst) cst[lane] = pf_c;
+        asm volatile("" : "+v"(pf_c));
         camU += accU; camV += accV;
         if (ablate & 2) continue;
         // ---- epilogue: tile -> record, entirely in registers (cross-lane shuffles, no LDS phases) ------
@@ -453,7 +466,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
             const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
             const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
             const int l = kq < 3 ? kq : 0;
-            const double r0 = cc[l], r1 = cc[3 + l], r2 = cc[6 + l];          // R_c[j][l], j = 0..2
+            // R_c[j][l], j = 0..2: three uniform candidates per entry, selected by the lane's l
+            const double r0 = l == 0 ? CC(0) : l == 1 ? CC(1) : CC(2);
+            const double r1 = l == 0 ? CC(3) : l == 1 ? CC(4) : CC(5);
+            const double r2 = l == 0 ? CC(6) : l == 1 ? CC(7) : CC(8);
             const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;   // rows kq and 3+kq (u+v)
             const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8; // their u-row parts
             const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
@@ -476,8 +492,8 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
             double vhi_kq = 0.0;
 #pragma unroll
             for (int lp = 0; lp < 3; ++lp) {
-                const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
-                const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
+                const double vlo = CC(lp) * mT_lo + CC(3 + lp) * a7_lo + CC(6 + lp) * a8_lo;
+                const double vhi = CC(lp) * mT_hi + CC(3 + lp) * a7_hi + CC(6 + lp) * a8_hi;
                 st(c6, oB + 8 * lp, vlo);
                 st(c6, oB + 144 + 8 * lp, vhi);
                 if (lp == kq) vhi_kq = vhi;
