@@ -92,7 +92,7 @@ struct IterLog {
 
 enum TermReason { kNone = 0, kMaxIter, kGradTol, kMinRadius, kParamTol, kFuncTol, kInvalidSteps };
 
-struct Ctrl {
+struct CtrlHead {
     // ---- header (polled by the host) ----
     int done, term_type, term_reason, iteration;
     int cur, lin_fail, num_successful, num_unsuccessful;
@@ -103,6 +103,9 @@ struct Ctrl {
     double se_min, se_cur, se_ref, se_cand, se_acc_ref, se_acc_cand;
     double initial_cost;
     Options opt;
+};
+
+struct Ctrl : CtrlHead {
     IterLog log[kMaxLog];
 };
 
@@ -547,25 +550,41 @@ __device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int bl
 }
 
 // deterministic block reductions (256 threads)
+// Block reductions (256 threads): xor-shuffle tree inside each wave, one LDS exchange between the four
+// waves -- two barriers per call, several quantities at once (the previous LDS tree cost ten barriers per
+// quantity: 1.5 us each on the single-block control paths).  Fixed order: bit-reproducible.
+template <int NS>
+__device__ __forceinline__ void block_reduce256(double (&sum)[NS], double &mx, double *sm)   // sm: >= 4 * (NS + 1) doubles
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sum[i] += __shfl_xor(sum[i], off);
+        mx = fmax(mx, __shfl_xor(mx, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) sm[wave * (NS + 1) + i] = sum[i];
+        sm[wave * (NS + 1) + NS] = mx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sum[i] = (sm[i] + sm[(NS + 1) + i]) + (sm[2 * (NS + 1) + i] + sm[3 * (NS + 1) + i]);
+    mx = fmax(fmax(sm[NS], sm[(NS + 1) + NS]), fmax(sm[2 * (NS + 1) + NS], sm[3 * (NS + 1) + NS]));
+    __syncthreads();
+}
 __device__ __forceinline__ double block_sum256(double v, double *sm)
 {
-    const int t = threadIdx.x;
-    sm[t] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) sm[t] += sm[t + s]; __syncthreads(); }
-    const double r = sm[0];
-    __syncthreads();
-    return r;
+    double s[1] = { v }, m = 0.0;
+    block_reduce256<1>(s, m, sm);
+    return s[0];
 }
 __device__ __forceinline__ double block_max256(double v, double *sm)
 {
-    const int t = threadIdx.x;
-    sm[t] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) sm[t] = fmax(sm[t], sm[t + s]); __syncthreads(); }
-    const double r = sm[0];
-    __syncthreads();
-    return r;
+    double s[1] = { 0.0 }, m = v;
+    block_reduce256<1>(s, m, sm);
+    return m;
 }
 
 // per-board gradient / norm statistics of the evaluation target (and, at iteration 0, the
@@ -593,9 +612,9 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
             for (int i = 0; i < 6; ++i) S.s_b[6 * b + i] = 1.0;
         }
     }
-    const double m = block_max256(gmax, sm);
-    const double s1 = block_sum256(gsq, sm);
-    const double s2 = block_sum256(xsq, sm);
+    double red[2] = { gsq, xsq }, m = gmax;
+    block_reduce256<2>(red, m, sm);
+    const double s1 = red[0], s2 = red[1];
     if (threadIdx.x == 0) { S.st_part[3 * blk] = m; S.st_part[3 * blk + 1] = s1; S.st_part[3 * blk + 2] = s2; }
 }
 
@@ -647,8 +666,9 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
         if (have_backsub) for (int i = t; i < S.n_bs_blocks; i += 256) { mb += S.bs_part[2 * i]; ss += S.bs_part[2 * i + 1]; }
         double gm = 0.0, gs = 0.0, xs = 0.0;
         for (int i = t; i < S.n_st_blocks; i += 256) { gm = fmax(gm, S.st_part[3 * i]); gs += S.st_part[3 * i + 1]; xs += S.st_part[3 * i + 2]; }
-        mb = block_sum256(mb, sm); ss = block_sum256(ss, sm); gs = block_sum256(gs, sm); xs = block_sum256(xs, sm);
-        gm = block_max256(gm, sm);
+        double red[4] = { mb, ss, gs, xs };
+        block_reduce256<4>(red, gm, sm);
+        mb = red[0]; ss = red[1]; gs = red[2]; xs = red[3];
         if (t == 0) {
             double *sc = S.H_stage + 256 * P.C;
             sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
@@ -1189,8 +1209,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
         for (int b = 0; b < kFA; ++b) hy += H[256 * m + ai * 16 + b] * s_yh[m * 16 + b];
         model += yi * (H[256 * m + ai * 16 + kFR] - 0.5 * hy);
     }
-    model = block_sum256(model, sred);
-    stepsq = block_sum256(stepsq, sred);
+    { double red[2] = { model, stepsq }, mdummy = 0.0; block_reduce256<2>(red, mdummy, sred); model = red[0]; stepsq = red[1]; }
     if (tid == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
 }
 
@@ -1265,7 +1284,11 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
 // ---------------------------------------------------------------------------------------------
 __device__ void control_step(const DevProblem &P, const DevState &S, int init, double *sm)
 {
-    Ctrl &c = *S.ctrl;
+    // The LM state is read ONCE (wide loads, one memory round trip), advanced in registers and written back
+    // once: as individual fields in global memory the ~40 dependent loads and stores of this function cost
+    // about half a microsecond each on the single thread that executes it.
+    Ctrl &g = *S.ctrl;
+    CtrlHead c = g;
     if (c.done) return;
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
@@ -1291,11 +1314,9 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
         }
         if (init && a == 15) S.s_c[t] = 1.0;
     }
-    gmax_c = block_max256(gmax_c, sm);
-    gsq_c = block_sum256(gsq_c, sm);
-    xsq_c = block_sum256(xsq_c, sm);
-    cost = block_sum256(cost, sm);
+    { double red[3] = { gsq_c, xsq_c, cost }; block_reduce256<3>(red, gmax_c, sm); gsq_c = red[0]; xsq_c = red[1]; cost = red[2]; }
     if (t != 0) return;
+    auto commit = [&]() { c.fin_count = 0; static_cast<CtrlHead &>(g) = c; };
     const double gmax_t = fmax(gmax_c, S.M_stage[0]);
     const double gnorm_t = sqrt(gsq_c + sc[3]);
     const double xnorm_t = sqrt(xsq_c + sc[2]);
@@ -1321,7 +1342,7 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
         it.gradient_max_norm = c.gmax; it.gradient_norm = c.gnorm;
         if (!valid) {
             // HandleInvalidStep
-            if (++c.num_invalid >= o.max_invalid) { c.done = 1; c.term_type = 2; c.term_reason = kInvalidSteps; return; }
+            if (++c.num_invalid >= o.max_invalid) { c.done = 1; c.term_type = 2; c.term_reason = kInvalidSteps; commit(); return; }
             c.radius = c.radius / c.decrease_factor; c.decrease_factor *= 2.0;
             it.cost = c.x_cost; it.cost_change = 0.0; it.step_norm = 0.0; it.relative_decrease = 0.0; it.step_is_successful = 0;
         } else {
@@ -1335,10 +1356,10 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
             it.step_is_successful = 0;
             // ParameterToleranceReached / FunctionToleranceReached: return before accepting
             if (step_norm <= o.parameter_tolerance * (c.x_norm + o.parameter_tolerance)) {
-                c.done = 1; c.term_type = 0; c.term_reason = kParamTol; return;
+                c.done = 1; c.term_type = 0; c.term_reason = kParamTol; commit(); return;
             }
             if (fabs(it.cost_change) <= o.function_tolerance * c.x_cost) {
-                c.done = 1; c.term_type = 0; c.term_reason = kFuncTol; return;
+                c.done = 1; c.term_type = 0; c.term_reason = kFuncTol; commit(); return;
             }
             double q;
             if (cand >= DBL_MAX) q = -DBL_MAX;
@@ -1354,7 +1375,7 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
                 c.x_cost = cand; c.x_norm = xnorm_t; c.gmax = gmax_t; c.gnorm = gnorm_t;
                 it.cost = cand; it.gradient_max_norm = gmax_t; it.gradient_norm = gnorm_t;
                 it.step_is_successful = 1;
-                c.radius = c.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * q - 1.0, 3.0));
+                { const double w = 2.0 * q - 1.0; c.radius = c.radius / fmax(1.0 / 3.0, 1.0 - w * w * w); }
                 c.radius = fmin(o.max_radius, c.radius);
                 c.decrease_factor = 2.0;
                 c.se_cur = cand; c.se_acc_cand += model; c.se_acc_ref += model;
@@ -1370,11 +1391,12 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (it.step_is_successful) ++c.num_successful; else ++c.num_unsuccessful;
     it.radius = c.radius;
-    if (c.n_log < kMaxLog) c.log[c.n_log] = it;
+    if (c.n_log < kMaxLog) g.log[c.n_log] = it;
     ++c.n_log;
-    if (it.iteration >= o.max_num_iterations) { c.done = 1; c.term_type = 1; c.term_reason = kMaxIter; return; }
-    if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { c.done = 1; c.term_type = 0; c.term_reason = kGradTol; return; }
-    if (c.radius <= o.min_radius) { c.done = 1; c.term_type = 0; c.term_reason = kMinRadius; return; }
+    if (it.iteration >= o.max_num_iterations) { c.done = 1; c.term_type = 1; c.term_reason = kMaxIter; commit(); return; }
+    if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { c.done = 1; c.term_type = 0; c.term_reason = kGradTol; commit(); return; }
+    if (c.radius <= o.min_radius) { c.done = 1; c.term_type = 0; c.term_reason = kMinRadius; commit(); return; }
+    commit();
 }
 
 __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int init)

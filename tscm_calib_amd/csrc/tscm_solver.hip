@@ -587,7 +587,7 @@ extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *op
     h->opt.max_lm_diagonal = opt.max_lm_diagonal;
     h->opt.max_invalid = opt.max_num_consecutive_invalid_steps;
     h->opt.jacobi_scaling = opt.jacobi_scaling;
-    const size_t header = offsetof(Ctrl, log);
+    const size_t header = sizeof(CtrlHead);
     HIP_TRY(hipMemcpyAsync(S.ctrl, h, header, hipMemcpyHostToDevice, s->stream));
     if (reset) {
         HIP_TRY(hipMemcpyAsync(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice, s->stream));
