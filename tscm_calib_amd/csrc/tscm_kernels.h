@@ -942,7 +942,9 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
 template <int TS>
 __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
 {
-    if (S.ctrl->done) return;
+    // control block and the static column tables are requested together (one memory round trip); the early
+    // exit is taken once they are there
+    const int ctrl_done = S.ctrl->done;
     constexpr int N = 16 * TS;
     constexpr int LD = N + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -965,13 +967,15 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     const double *H = S.H[cur];
-    if (tid == 0) s_fail = S.ctrl->lin_fail;
+    const int ctrl_fail = S.ctrl->lin_fail;
     __shared__ int s_map[N];          // compact index -> padded column, -1 past the last free column
     for (int i = tid; i < N; i += 256) {
         s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0;
         s_map[i] = i < P.n_act ? P.act_map[i] : -1;
         yv[i] = 0.0;
     }
+    if (ctrl_done) return;
+    if (tid == 0) s_fail = ctrl_fail;
     const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
     __syncthreads();
     // ---- build my tile (lower tiles only); the diagonal thread also owns its slice of the rhs ----
