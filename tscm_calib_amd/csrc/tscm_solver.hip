@@ -197,6 +197,10 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
         view_obs[i] = (int)N; N += p->view_count[v];
     }
     if (N > 0x7fffffffL) return fail(TSCM_E_UNSUPPORTED, "more than 2^31 corners");
+    // the Gram kernels address observations, per-view constants and records with 32-bit buffer offsets and
+    // park the stores of idle lanes at offset 0xffffe000, which must lie beyond the end of every buffer
+    if ((unsigned long long)N * sizeof(double) >= 0xffffe000ull || (unsigned long long)V * kRec * sizeof(double) >= 0xffffe000ull)
+        return fail(TSCM_E_UNSUPPORTED, "problem too large for 32-bit buffer offsets (more than 3.7 M views or 536 M corners on one GPU)");
     s->N = (int)N;
     s->h_view_obs = view_obs; s->h_view_count = view_count; s->h_view_cam = view_cam; s->h_view_board = view_board;
     std::vector<double> u((size_t)N), w((size_t)N);
