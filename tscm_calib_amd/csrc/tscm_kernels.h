@@ -11,7 +11,7 @@
 //   H_stage          per camera a 16x16 tile [F | r]^T [F | r]  (13x13 Gram, col 13 =
 //                    F^T r, [13][13] = r^T r) + 8 scalars; fixed address so that RCCL can
 //                    all-reduce it without knowing the device-side buffer index.
-//   Y[V][96], L[B][21], z[B][6], D2[B][6]   e-block factors kept for back-substitution.
+//   Y[V][96], L[B][21] (diagonal slots = 1/L_jj), z[B][6], D2[B][6]   e-block factors kept for back-substitution.
 //   T[n_pad^2]       Schur complement sum_b Y_b^T Y_b as dense 16x16 blocks per camera pair.
 // The LM control state (trust-region radius, accept/reject, termination, iteration log)
 // lives in `Ctrl` in device memory; every kernel starts with `if (ctrl->done) return`.
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool chol6(const double M[21], double L[21])
 {
-    // packed lower: idx(i,j) = i(i+1)/2 + j
+    // packed lower: idx(i,j) = i(i+1)/2 + j; the diagonal slots hold 1 / L_jj
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -711,9 +711,8 @@ __device__ __forceinline__ bool chol6(const double M[21], double L[21])
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
         if (!(d > 0.0)) { ok = false; d = 1.0; }
-        const double sd = sqrt(d);
-        const double inv = 1.0 / sd;
-        L[j * (j + 1) / 2 + j] = sd;
+        const double inv = fast_rsqrt(d);      // 1 / L_jj: only the inverse is ever used (forward and back substitution)
+        L[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double s = M[i * (i + 1) / 2 + j];
@@ -759,9 +758,6 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
     }
     double L[21];
     if (!chol6(M, L)) S.ctrl->lin_fail = 1;
-    double il[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) il[i] = 1.0 / L[i * (i + 1) / 2 + i];
     for (int q = q0; q < q1; ++q) {
         const int v = q;
         const double *rec = S.rec[cur] + (size_t)kRec * v;
@@ -771,7 +767,7 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
             double w = (a == kFR ? g[i] : rec[i * 16 + a]) * sb[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) w -= L[i * (i + 1) / 2 + k] * y[k];
-            y[i] = w * il[i];
+            y[i] = w * L[i * (i + 1) / 2 + i];
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) S.Y[(size_t)96 * v + i * 16 + a] = y[i];
@@ -1257,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
                 double w = t[i];
 #pragma unroll
                 for (int k = i + 1; k < 6; ++k) w -= L[k * (k + 1) / 2 + i] * y[k];
-                y[i] = w / L[i * (i + 1) / 2 + i];
+                y[i] = w * L[i * (i + 1) / 2 + i];      // diagonal slots hold 1 / L_ii
             }
             double m = 0.0, s = 0.0;
 #pragma unroll
