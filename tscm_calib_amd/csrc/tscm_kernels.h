@@ -251,10 +251,13 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 //   -> 15 tile columns, v_mfma_f64_16x16x4_f64 count per view = 2*ceil(n/4) (28 for 54 corners)
 //      instead of 3*ceil(2n/4) = 81 for the naive [E|F|r] padding.
 // One wave per chunk of consecutive views of ONE camera, four such waves (same camera) per workgroup;
-// lane = corner (coalesced SoA loads of u[], v[]), board points and all wave-uniform constants in
-// LDS, Jacobian columns transposed through LDS (column-major, pitch 130: conflict-free
+// lane = corner (coalesced SoA loads of u[], v[]); board points in LDS; the wave-uniform constants
+// (27 per view, 48 per camera) live one per lane in two VGPRs and are fetched with v_readlane;
+// Jacobian columns are transposed through LDS (column-major, pitch 2*odd: conflict-free
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
-// dynamic LDS: 16*rp + kCst + 2*n_points doubles.
+// All global traffic of the view loop uses buffer addressing; the record is written by 13
+// unconditional stores.
+// dynamic LDS: 16*rp + kCst + 2*n_points doubles (the kCst block is only used by k_eval_gram_f32).
 
 // ---------------------------------------------------------------------------------------------
 template <int RPC>   // RPC > 0: compile-time LDS pitch (HV = RPC - 2): all tile offsets become immediates
