@@ -251,8 +251,9 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 //   -> 15 tile columns, v_mfma_f64_16x16x4_f64 count per view = 2*ceil(n/4) (28 for 54 corners)
 //      instead of 3*ceil(2n/4) = 81 for the naive [E|F|r] padding.
 // One wave per chunk of consecutive views of ONE camera, four such waves (same camera) per workgroup;
-// lane = corner (coalesced SoA loads of u[], v[]); board points in LDS; the wave-uniform constants
-// (27 per view, 48 per camera) live one per lane in two VGPRs and are fetched with v_readlane;
+// lane = corner (coalesced SoA loads of u[], v[]); board points in LDS; the 27 per-view constants live
+// one per lane in a VGPR pair (prefetched a view ahead) and are fetched with v_readlane, the 48
+// per-camera constants come through the constant address space as scalar loads (SGPR operands);
 // Jacobian columns are transposed through LDS (column-major, pitch 2*odd: conflict-free
 // ds_read_b64) into MFMA operand layout.  The per-camera tile stays in registers for the chunk.
 // All global traffic of the view loop uses buffer addressing; the record is written by 13
@@ -277,11 +278,14 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     const int chunk = blockIdx.x * 4 + wave;
     const int cam = P.chunk_cam[chunk];
     for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
-    const double ccam = lane < kCConst ? S.cconst[kCConst * cam + lane] : 0.0;      // camera constant k in lane k
+    // camera constants: read through the constant address space (uniform address, written by an earlier
+    // kernel) -> scalar loads straight into SGPR operands, no v_readlane pair per use
+    typedef const double __attribute__((address_space(4))) *cptr4;
+    const cptr4 ccs = (cptr4)(S.cconst + kCConst * cam);
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
-    auto CC = [&](int k) { return lane_const(ccam, k); };                            // camera constants (see k_view_prep)
+    auto CC = [&](int k) { return ccs[k]; };                                          // camera constants (see k_view_prep)
     // rows of lanes without a corner are kept at zero instead of being re-written every pass
     if (lane < HV) {
 #pragma unroll
