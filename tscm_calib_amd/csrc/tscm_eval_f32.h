@@ -56,9 +56,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
-    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVConst * P.V);
+    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
     const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
-    const unsigned vc_off = 8u * (unsigned)lane * (unsigned)P.V;       // lane k reads vconst[k][view]
+    const unsigned vc_off = 8u * (unsigned)lane;                        // lane k reads vconst[view][k]
     // Per-view metadata (corner count, record slot) of a block of <= 64 views sits in lane registers and is
     // read with v_readlane; the observations of a camera's views are contiguous, so the offset is a running
     // sum.  No dependent global load -- and therefore no in-order vmcnt wait behind the previous view's
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     asm volatile("" : "+v"(m_cnt), "+v"(m_slot));       // the loads complete here, outside the view loop
     {
         const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
-        if (lane < kVConst) pf_c = buf_load_f64(r_vc, vc_off, 8u * (unsigned)vbase);
+        if (lane < kVConst) pf_c = buf_load_f64(r_vc, vc_off, 8u * (unsigned)kVStride * (unsigned)vbase);
         if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
         wave_lds_fence();
         if (lane < kVConst) { cst[lane] = pf_c; cs[lane] = (float)pf_c; }   // first view of the block
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                 // the end of the buffer, i.e. zero): unconditional loads keep the vmcnt bookkeeping exact.
                 const int vn = min(view + 1, vend - 1);
                 const int cn = view + 1 < vend ? __builtin_amdgcn_readlane(m_cnt, vn - vbase) : 0;
-                pf_c = buf_load_f64(r_vc, lane < kVConst ? vc_off : 0xffffe000u, 8u * (unsigned)vn);
+                pf_c = buf_load_f64(r_vc, lane < kVConst ? vc_off : 0xffffe000u, 8u * (unsigned)kVStride * (unsigned)vn);
                 pf_u = buf_load_f64(r_u, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
                 pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
             }

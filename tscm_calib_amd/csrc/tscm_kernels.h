@@ -186,18 +186,22 @@ __device__ __forceinline__ void load_view_const(const DevProblem &P, const DevSt
 
 // ---------------------------------------------------------------------------------------------
 // per-view / per-camera constants of the evaluation target in the form the hot kernel consumes.
-// grid ceil((V + C)/256) x 256.
-//   vconst[k][view]: r1(3) r2(3) t_b(3), then for k=0..2: R_c dR_b/dw_k[:,0] (3), R_c dR_b/dw_k[:,1] (3)
+// grid ceil((V + C)/128) x 128.
+//   vconst[view][32]: r1(3) r2(3) t_b(3), then for k=0..2: R_c dR_b/dw_k[:,0] (3), R_c dR_b/dw_k[:,1] (3); 5 pad
 //   cconst[cam] : R_c(9) t_c(3) dR_c/dw_k (27) fx fy cx cy xi lambda beta=alpha/(1-alpha) 1/(1-alpha)^2
 // ---------------------------------------------------------------------------------------------
-__global__ void k_view_prep(DevProblem P, DevState S, int cand)
+constexpr int kVStride = 32;      // doubles per view in vconst (27 used): one 256-byte record per view
+constexpr int kVPrepThreads = 128;
+
+__global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevState S, int cand)
 {
     if (S.ctrl->done) return;
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double st[kVPrepThreads][kVStride + 1];      // record of thread t in row t (pitch 33: conflict-free both ways)
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * kVPrepThreads + t;
     if (i < P.V) {
-        // self-contained (rotations recomputed per view: cheaper than a second launch + round trip);
-        // stored SoA ([k][view]) so that the 27 stores of a wave are coalesced
+        // self-contained (rotations recomputed per view: cheaper than a second launch + round trip)
         const int b = P.view_board[i], m = P.view_cam[i];
         double rt[6], bc[kBoardConst], Rc[9], dRc[27];
         for (int k = 0; k < 6; ++k) rt[k] = S.board_rt[tgt][6 * b + k];
@@ -205,14 +209,14 @@ __global__ void k_view_prep(DevProblem P, DevState S, int cand)
         double crt[3];
         for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);
-        double *o = S.vconst + i;
-        const size_t st = (size_t)P.V;
-        for (int k = 0; k < 6; ++k) o[k * st] = bc[k];
-        for (int k = 0; k < 3; ++k) o[(6 + k) * st] = rt[3 + k];
+        double *o = st[t];
+        for (int k = 0; k < 6; ++k) o[k] = bc[k];
+        for (int k = 0; k < 3; ++k) o[6 + k] = rt[3 + k];
         for (int k = 0; k < 6; ++k) {           // six 3-vectors d -> R_c d
             const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
-            for (int r = 0; r < 3; ++r) o[(9 + 3 * k + r) * st] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
+            for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
         }
+        for (int k = kVConst; k < kVStride; ++k) o[k] = 0.0;
     } else if (i < P.V + P.C) {
         const int m = i - P.V;
         double crt[3], Rc[9], dRc[27];
@@ -229,6 +233,11 @@ __global__ void k_view_prep(DevProblem P, DevState S, int cand)
         o[46] = 1.0 / (oma * oma);
         o[47] = 0.0;
     }
+    __syncthreads();
+    // the block's records leave as one contiguous, coalesced stream: vconst[view][32]
+    const int v0 = blockIdx.x * kVPrepThreads;
+    const int nv = min(kVPrepThreads, P.V - v0);
+    for (int e = t; e < nv * kVStride; e += kVPrepThreads) S.vconst[(size_t)kVStride * v0 + e] = st[e / kVStride][e % kVStride];
 }
 
 // tile column -> (parity mask) bookkeeping shared by the hot kernel's epilogue and k_finalize_eval.
@@ -294,13 +303,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     int prev_nv = 0;                           // lanes [nv, prev_nv) hold stale rows of the previous pass
     // software prefetch: the next view's constants and first 64 observations are loaded while
     // the current view computes (one wave per SIMD-slot cannot hide HBM latency otherwise)
-    double pf_c = 0.0, pf_u = 0.0, pf_v = 0.0;
+    double pf_u = 0.0, pf_v = 0.0;
+    int warm = 0;                              // see the prefetch below
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
-    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVConst * P.V);
+    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
     const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
-    const unsigned vc_off = 8u * (unsigned)lane * (unsigned)P.V;       // lane k reads vconst[k][view]
     // Per-view metadata (corner count, record slot) of a block of <= 64 views sits in lane registers and is
     // read with v_readlane; the observations of a camera's views are contiguous, so the offset is a running
     // sum.  No dependent global load -- and therefore no in-order vmcnt wait behind the previous view's
@@ -313,17 +322,15 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     asm volatile("" : "+v"(m_cnt), "+v"(m_slot));       // the loads complete here, outside the view loop
     {
         const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
-        if (lane < kVConst) pf_c = buf_load_f64(r_vc, vc_off, 8u * (unsigned)vbase);
         if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
-        asm volatile("" : "+v"(pf_c));         // first view of the block: the one exposed load latency per <= 64 views
     }
     for (int view = vbase; view < vend; ++view) {
         const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
         const int off = off_next;
         off_next = off + cnt;
         wave_lds_fence();                       // previous view's epilogue has finished with LDS
-        const double vcur = pf_c;               // view constant k in lane k (complete: see below)
-        auto VC = [&](int k) { return lane_const(vcur, k); };
+        const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);      // this view's 27 constants: scalar loads
+        auto VC = [&](int k) { return vcs[k]; };
         d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
@@ -409,7 +416,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 // the end of the buffer, i.e. zero): unconditional loads keep the vmcnt bookkeeping exact.
                 const int vn = min(view + 1, vend - 1);
                 const int cn = view + 1 < vend ? __builtin_amdgcn_readlane(m_cnt, vn - vbase) : 0;
-                pf_c = buf_load_f64(r_vc, lane < kVConst ? vc_off : 0xffffe000u, 8u * (unsigned)vn);
+                // pull the next view's 256-byte constant record into the L2 with one tracked vector load (lanes
+                // 0..3, one dword per 64-byte line): the scalar loads at the top of the next view then hit the L2
+                warm = __builtin_amdgcn_raw_buffer_load_b32(r_vc, lane < 4 ? 64 * lane : (int)0xffffe000u, (int)(8u * (unsigned)kVStride * (unsigned)vn), 0);
                 pf_u = buf_load_f64(r_u, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
                 pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
             }
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         // this view's record stores: on gfx9 loads and stores share vmcnt and may complete out of order, so any
         // wait for a load with stores in flight is a vmcnt(0) -- a wait placed right after the stores (the top
         // of the next view) would expose the whole store latency.  The geometry is done with cst by now.
-        asm volatile("" : "+v"(pf_c));
+        asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
         camU += accU; camV += accV;
         if (ablate & 2) continue;
         // ---- epilogue: tile -> record, entirely in registers (cross-lane shuffles, no LDS phases) ------
