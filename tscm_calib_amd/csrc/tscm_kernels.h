@@ -28,6 +28,7 @@ constexpr int kRecEE = 96;         // offset of E^T E inside a record
 constexpr int kTcols = 15;         // columns of the single MFMA Gram tile (see k_eval_gram)
 constexpr int kVConst = 27;        // per-view constants: r1, r2, t_b, R_c dR_b/dw_k [:,0:2]
 constexpr int kCConst = 48;        // per-camera constants: R_c, t_c, dR_c/dw_k, fx fy cx cy xi lambda beta 1/(1-alpha)^2
+constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 doubles, then the same 48 values as floats
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
 constexpr int kCamG1 = 16;         // first-level fan-in of the per-camera tile reduction
@@ -190,7 +191,9 @@ __device__ __forceinline__ void load_view_const(const DevProblem &P, const DevSt
 //   vconst[view][32]: r1(3) r2(3) t_b(3), then for k=0..2: R_c dR_b/dw_k[:,0] (3), R_c dR_b/dw_k[:,1] (3); 5 pad
 //   cconst[cam] : R_c(9) t_c(3) dR_c/dw_k (27) fx fy cx cy xi lambda beta=alpha/(1-alpha) 1/(1-alpha)^2
 // ---------------------------------------------------------------------------------------------
-constexpr int kVStride = 32;      // doubles per view in vconst (27 used): one 256-byte record per view
+constexpr int kVStride = 48;      // doubles per view record in vconst: 27 doubles (+5 pad), then at byte 256 the same 27 values as
+                                  // floats (read by the fp32-Jacobian kernel): 384 bytes
+constexpr int kVFloatOff = 32;    // offset of the float copy, in doubles
 constexpr int kVPrepThreads = 128;
 
 __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevState S, int cand)
@@ -216,13 +219,15 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
             const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
             for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
         }
-        for (int k = kVConst; k < kVStride; ++k) o[k] = 0.0;
+        for (int k = kVConst; k < kVFloatOff; ++k) o[k] = 0.0;
+        float *of = reinterpret_cast<float *>(o + kVFloatOff);          // float copy of the 27 constants (+ pad)
+        for (int k = 0; k < 2 * (kVStride - kVFloatOff); ++k) of[k] = k < kVConst ? (float)o[k] : 0.f;
     } else if (i < P.V + P.C) {
         const int m = i - P.V;
         double crt[3], Rc[9], dRc[27];
         for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);
-        double *o = S.cconst + kCConst * m;
+        double *o = S.cconst + kCStride * m;
         for (int k = 0; k < 9; ++k) o[k] = Rc[k];
         for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
         for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
@@ -232,6 +237,8 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
         o[45] = I[6] / oma;
         o[46] = 1.0 / (oma * oma);
         o[47] = 0.0;
+        float *of = reinterpret_cast<float *>(o + kCConst);
+        for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
     }
     __syncthreads();
     // the block's records leave as one contiguous, coalesced stream: vconst[view][32]
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     // camera constants: read through the constant address space (uniform address, written by an earlier
     // kernel) -> scalar loads straight into SGPR operands, no v_readlane pair per use
     typedef const double __attribute__((address_space(4))) *cptr4;
-    const cptr4 ccs = (cptr4)(S.cconst + kCConst * cam);
+    const cptr4 ccs = (cptr4)(S.cconst + kCStride * cam);
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };

@@ -409,7 +409,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_alloc(s, &S.board_pc, (size_t)kBoardConst * B))) return rc;
     if ((rc = dev_alloc(s, &S.cam_pc, (size_t)kCamConst * C))) return rc;
     if ((rc = dev_alloc(s, &S.vconst, (size_t)kVStride * V))) return rc;
-    if ((rc = dev_alloc(s, &S.cconst, (size_t)kCConst * C))) return rc;
+    if ((rc = dev_alloc(s, &S.cconst, (size_t)kCStride * C))) return rc;
     if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)(P.n_chunks / 4)))) return rc;
     if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C * kCamG1))) return rc;
     if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal))) return rc;
