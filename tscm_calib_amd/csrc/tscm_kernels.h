@@ -196,11 +196,11 @@ constexpr int kVStride = 48;      // doubles per view record in vconst: 27 doubl
 constexpr int kVFloatOff = 32;    // offset of the float copy, in doubles
 constexpr int kVPrepThreads = 128;
 
-__global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevState S, int cand)
+__global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevState S, int cand, int with_floats)
 {
     if (S.ctrl->done) return;
     const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
-    __shared__ double st[kVPrepThreads][kVStride + 1];      // record of thread t in row t (pitch 33: conflict-free both ways)
+    __shared__ double st[kVPrepThreads][kVFloatOff + 1];    // the 27 (+5 pad) doubles of thread t in row t (pitch 33: conflict-free both ways)
     const int t = threadIdx.x;
     const int i = blockIdx.x * kVPrepThreads + t;
     if (i < P.V) {
@@ -220,8 +220,6 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
             for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
         }
         for (int k = kVConst; k < kVFloatOff; ++k) o[k] = 0.0;
-        float *of = reinterpret_cast<float *>(o + kVFloatOff);          // float copy of the 27 constants (+ pad)
-        for (int k = 0; k < 2 * (kVStride - kVFloatOff); ++k) of[k] = k < kVConst ? (float)o[k] : 0.f;
     } else if (i < P.V + P.C) {
         const int m = i - P.V;
         double crt[3], Rc[9], dRc[27];
@@ -244,7 +242,22 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
     // the block's records leave as one contiguous, coalesced stream: vconst[view][32]
     const int v0 = blockIdx.x * kVPrepThreads;
     const int nv = min(kVPrepThreads, P.V - v0);
-    for (int e = t; e < nv * kVStride; e += kVPrepThreads) S.vconst[(size_t)kVStride * v0 + e] = st[e / kVStride][e % kVStride];
+    for (int e = t; e < nv * kVFloatOff; e += kVPrepThreads) {                 // compile-time divisors: shifts
+        const int v = e / kVFloatOff, k = e % kVFloatOff;
+        S.vconst[(size_t)kVStride * (v0 + v) + k] = st[v][k];
+    }
+    if (with_floats) {
+        // the float half of a record (the same 27 values as floats, two per double slot) is only written for
+        // the fp32-Jacobian kernel
+        constexpr int kF = kVStride - kVFloatOff;
+        for (int e = t; e < nv * kF; e += kVPrepThreads) {
+            const int v = e / kF, k = e % kF, j = 2 * k;
+            const float f[2] = { j < kVConst ? (float)st[v][j] : 0.f, j + 1 < kVConst ? (float)st[v][j + 1] : 0.f };
+            double out;
+            __builtin_memcpy(&out, f, sizeof(out));
+            S.vconst[(size_t)kVStride * (v0 + v) + kVFloatOff + k] = out;
+        }
+    }
 }
 
 // tile column -> (parity mask) bookkeeping shared by the hot kernel's epilogue and k_finalize_eval.

@@ -519,7 +519,7 @@ static int enqueue_eval(tscm_solver *s, int cand, int init, int have_backsub)
 {
     const DevProblem &P = s->P;
     DevState &S = s->S;
-    hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand);
+    hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
     if (int rc = launch_eval(s, cand)) return rc;
     hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1 + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
     hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub, s->comm ? -1 : init);
@@ -709,7 +709,7 @@ static int prepare_eval(tscm_solver *s)
     HIP_TRY(hipMemcpy(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
     if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(k_pose_prep, dim3((s->P.B + s->P.C + 255) / 256), dim3(256), 0, s->stream, s->P, S, 0);
-    hipLaunchKernelGGL(k_view_prep, dim3((s->P.V + s->P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, s->P, S, 0);
+    hipLaunchKernelGGL(k_view_prep, dim3((s->P.V + s->P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, s->P, S, 0, 0);
     HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
