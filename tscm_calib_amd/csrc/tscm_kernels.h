@@ -252,10 +252,8 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
         constexpr int kF = kVStride - kVFloatOff;
         for (int e = t; e < nv * kF; e += kVPrepThreads) {
             const int v = e / kF, k = e % kF, j = 2 * k;
-            const float f[2] = { j < kVConst ? (float)st[v][j] : 0.f, j + 1 < kVConst ? (float)st[v][j + 1] : 0.f };
-            double out;
-            __builtin_memcpy(&out, f, sizeof(out));
-            S.vconst[(size_t)kVStride * (v0 + v) + kVFloatOff + k] = out;
+            const float f0 = j < kVConst ? (float)st[v][j] : 0.f, f1 = j + 1 < kVConst ? (float)st[v][j + 1] : 0.f;
+            S.vconst[(size_t)kVStride * (v0 + v) + kVFloatOff + k] = __hiloint2double(__float_as_int(f1), __float_as_int(f0));
         }
     }
 }
