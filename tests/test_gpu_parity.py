@@ -339,3 +339,38 @@ def test_config4_properties(hip_device):
         qs = s.solve()
     assert qs["num_iterations"] == gs["num_iterations"]
     assert np.max(np.abs(q.intr - pg.intr) / np.maximum(np.abs(pg.intr), 1e-3)) < 1e-9
+
+
+def test_no_device_memory_leak_over_repeated_calls(hip_device):
+    """Every entry point that allocates device memory gives it back: 40 rounds of create / solve / destroy,
+    rig initialisation, remap tables, projection -- free device memory ends where it started."""
+    import ctypes
+    from tscm_calib_amd import maps, rig
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+    p = H.small_rig(4, 12, seed=3)
+    inp = synth.make_rig_input(p)
+    descs = [maps.undistort_desc(synth.CALIB_INTR[0], 300.0, 300.0, 319.5, 239.5, 640, 480)]
+    pts = np.random.default_rng(0).normal(size=(1000, 3)) + [0, 0, 5]
+
+    def one_round():
+        q = p.copy().normalised()
+        with api.Solver(q) as s:
+            s.solve()
+        api.calibrate(p.copy().normalised(), hip_device)
+        rig.rig_init(inp, hip_device)
+        maps.build_maps(descs, None, hip_device)
+        api.project(synth.CALIB_INTR[0], pts, hip_device)
+        api.normal_equations(p.copy().normalised(), hip_device)
+
+    one_round()                                  # warm-up: code objects, runtime pools
+    free0 = free_bytes()
+    for _ in range(40):
+        one_round()
+    free1 = free_bytes()
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 40 rounds"
