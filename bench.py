@@ -103,11 +103,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # TSCM_BENCH_FORCE_DIST=1 runs the multi-process code path (gloo side channel + RCCL communicator) with a
+    # single rank, so that it can be exercised on a one-GPU box
+    multi = world > 1 or os.environ.get("TSCM_BENCH_FORCE_DIST") == "1"
+    if multi:
+        # torch is used for the CPU-side rendezvous only (gloo).  torch.cuda is deliberately never touched:
+        # the torch wheel carries its own HIP runtime, and two HIP runtimes in one process do not mix with the
+        # library's (system) one -- device selection and fencing go through the C ABI instead.
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -118,8 +124,7 @@ def main():
     solver = api.Solver(prob, device=local_rank)          # H2D of the observations + layout build
     t_create = time.perf_counter() - t_create
     comm = None
-    if world > 1:
-        import torch
+    if multi:
         uid = [api.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = api.Comm(uid[0], rank, world, local_rank)
@@ -127,9 +132,10 @@ def main():
     solver.upload_params()
 
     def barrier():
-        if world > 1:
-            import torch
-            torch.cuda.synchronize()
+        # device fence (the job of torch.cuda.synchronize() in the contract) + process barrier
+        from tscm_calib_amd import lib as _lib
+        _lib.check(_lib.lib().tscm_device_synchronize(local_rank))
+        if multi:
             dist.barrier()
 
     # natural solve (reference options, termination tests on): untimed, doubles as warmup
@@ -145,7 +151,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launches, kms = solver.kernel_time(enable=False)
-    if world > 1:
+    if multi:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full, local_rank)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         solver.close()
         comm.close()

@@ -137,6 +137,9 @@ typedef struct tscm_comm tscm_comm;       /* opaque: RCCL communicator          
 int tscm_abi_version(void);
 const char *tscm_last_error(void);
 int tscm_device_count(void);
+/* hipSetDevice(device) + hipDeviceSynchronize(): lets a host (e.g. the multi-process benchmark) fence the
+ * GPU without loading a second HIP runtime of its own. */
+int tscm_device_synchronize(int device);
 
 void tscm_default_options(tscm_options *opt, int mono);
 

@@ -110,6 +110,15 @@ extern "C" int tscm_device_count(void)
     return n;
 }
 
+extern "C" int tscm_device_synchronize(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
 extern "C" void tscm_default_options(tscm_options *o, int mono)
 {
     o->max_num_iterations = mono ? 100 : 50;   // TS.cpp:274 ; Ceres default (multi_calib.cpp:212 is commented out)
