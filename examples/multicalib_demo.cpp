@@ -56,6 +56,12 @@ int main(int argc, char **argv)
         probe.intrinsic_[2] = 1280 / 2 - 0.5; probe.intrinsic_[3] = 1080 / 2 - 0.5;          // TS.cpp:43-44
         const double focal0 = probe.estimate_focal(probe.pixels_, board);
 
+        // ... and the whole mono calibration of camera 0 from its corner lists alone (main.cpp:222 -> TS.cpp:30-105)
+        tscm::TripleSphereCamera mono0;
+        const bool mono_ok = mono0.calibrate(cameras[0].pixels_, cameras[0].has_chessboard_, worlds, tscm::Size{ 1280, 1080 }, board);
+        printf("mono calibration of camera 0 from raw corners: %s, rmse %.4f px, fx %.2f (rig input %.2f)\n", mono_ok ? "converged" : "NOT converged",
+               mono0.summary.rmse, mono0.intrinsic_[0], cameras[0].intrinsic_[0]);
+
         tscm::MultiCalib mul_calib(cameras, worlds);           // main.cpp:233
         mul_calib.calibrate();                                 // main.cpp:234
         printf("%s  iterations %d  final cost %.6e\n", mul_calib.summary.message, mul_calib.summary.num_iterations - 1, mul_calib.summary.final_cost);

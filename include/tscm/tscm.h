@@ -321,11 +321,21 @@ int tscm_build_maps(const tscm_map_desc *maps, int n_maps, int device, int exact
  * tscm_poses_from_r1r2t = the loop TS.cpp:62-74: Rt_[i] (row-major 3x3 [r1 r2 t]) -> rt_[i] =
  *   [cv::Rodrigues(R), t] with R built from float32 r1, r2 and their float cross product
  *   (has[i] == 0: rt left untouched).  Host-only.
- * estimate_extrinsic (TS.cpp:170-203) is cv::solvePnPRansac and stays with OpenCV.             */
+ * tscm_estimate_extrinsic = TripleSphereCamera::estimate_extrinsic (TS.cpp:170-203): per image the
+ *   "look at the board" rotation (:175-187), the corners un-projected onto that plane (:188-191) and a
+ *   planar PnP.  The reference calls cv::solvePnPRansac there (external OpenCV routine, randomised);
+ *   this entry point runs the deterministic equivalent for an all-inlier detection -- DLT homography,
+ *   pose from its columns, polar orthonormalisation, Gauss-Newton on the 6 pose parameters -- so its
+ *   result is NOT comparable bit-wise with OpenCV's, only as an initial guess of the same quality.
+ *   Rt: [n_views*9] row-major 3x3 [r1 r2 t] = Rt_[k]; images with count[k] == 0 or a degenerate
+ *   configuration keep the caller's values; *n_estimated = number of poses written.            */
 int tscm_estimate_focal(const double *pix_u, const double *pix_v, const int *count, int n_views,
                         int board_w, int board_h, double cx, double cy, int device, double *focal,
                         int *n_used);
 int tscm_poses_from_r1r2t(const double *Rt, const unsigned char *has, int n, double *rt);
+int tscm_estimate_extrinsic(const double *intr9, const double *pix_u, const double *pix_v, const int *count,
+                            int n_views, const double *worlds, int n_points, int board_w, int device,
+                            double *Rt, int *n_estimated);
 
 #ifdef __cplusplus
 }

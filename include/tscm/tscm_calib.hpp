@@ -9,7 +9,9 @@
 //   reference                                              here
 //   TripleSphereCamera::refinement       TS.cpp:247-282    TripleSphereCamera::refinement      -> tscm_solve_mono
 //   TripleSphereCamera::estimate_focal   TS.cpp:110-168    TripleSphereCamera::estimate_focal  -> tscm_estimate_focal
+//   TripleSphereCamera::estimate_extrinsic TS.cpp:170-203  TripleSphereCamera::estimate_extrinsic -> tscm_estimate_extrinsic (*)
 //   loop Rt_ -> rt_                      TS.cpp:62-74      TripleSphereCamera::poses_from_Rt   -> tscm_poses_from_r1r2t
+//   TripleSphereCamera::calibrate        TS.cpp:30-105     TripleSphereCamera::calibrate       (the four calls above + refinement)
 //   TripleSphereCamera::project          TS.cpp:332-344    TripleSphereCamera::project (batch) -> tscm_project_points
 //   get_unit_sphere_coordinate           TS.h:39-57        get_unit_sphere_coordinate (batch)  -> tscm_unproject_pixels
 //   TripleSphereCamera::undistort        TS.cpp:284-306    TripleSphereCamera::undistort       -> tscm_build_maps
@@ -17,6 +19,7 @@
 //   MultiCalib::MultiCalib               multi_calib.cpp:6-153    MultiCalib::MultiCalib       -> tscm_rig_init
 //   MultiCalib::calibrate                multi_calib.cpp:155-283  MultiCalib::calibrate        -> tscm_solve_multi, tscm_reprojection_error
 //   YAML output                          main.cpp:305-319         MultiCalib::write_yaml       -> tscm_yaml_write
+// (*) deterministic planar PnP in place of cv::solvePnPRansac (see tscm.h)
 #ifndef TSCM_CALIB_HPP
 #define TSCM_CALIB_HPP
 
@@ -109,6 +112,52 @@ public:
         intrinsic_[0] = intrinsic_[1] = focal;
         return focal;
     }
+
+    // TS.cpp:170-203 (planar PnP per image with a board; fills Rt_)
+    int estimate_extrinsic(const std::vector<std::vector<Point2d> > &pixels, const std::vector<Point3d> &worlds, Size chessboard_num)
+    {
+        const int V = (int)pixels.size(), n = (int)worlds.size();
+        std::vector<double> u((size_t)V * n, 0.0), v((size_t)V * n, 0.0), W(3 * (size_t)n), M(9 * (size_t)V, 0.0);
+        std::vector<int> cnt(V);
+        for (int c = 0; c < n; ++c) { W[3 * c] = worlds[c].x; W[3 * c + 1] = worlds[c].y; W[3 * c + 2] = worlds[c].z; }
+        for (int k = 0; k < V; ++k) {
+            cnt[k] = has_chessboard_[k] ? (int)pixels[k].size() : 0;                // TS.cpp:174
+            for (size_t j = 0; j < pixels[k].size() && j < (size_t)n; ++j) { u[(size_t)k * n + j] = pixels[k][j].x; v[(size_t)k * n + j] = pixels[k][j].y; }
+        }
+        int done = 0;
+        check(tscm_estimate_extrinsic(intrinsic_.data(), u.data(), v.data(), cnt.data(), V, W.data(), n, chessboard_num.width, device_, M.data(), &done));
+        Rt_.resize(V);
+        for (int k = 0; k < V; ++k) if (cnt[k]) std::memcpy(Rt_[k].a, &M[9 * (size_t)k], sizeof(Rt_[k].a));
+        return done;
+    }
+
+    // TS.cpp:30-105: initial guess (unless a previous calibration succeeded), poses, refinement
+    bool calibrate(const std::vector<std::vector<Point2d> > &pixels, const std::vector<bool> &has_chessboard,
+                   const std::vector<Point3d> &worlds, Size img_size, Size chessboard_num)
+    {
+        pixels_ = pixels;
+        has_chessboard_ = has_chessboard;
+        Rt_.assign(pixels.size(), Mat33());
+        rt_.assign(pixels.size(), std::vector<double>());
+        if (!has_init_guess_) {
+            intrinsic_.assign(9, 0.0);
+            intrinsic_[2] = img_size.width / 2 - 0.5;                                // :43-47
+            intrinsic_[3] = img_size.height / 2 - 0.5;
+            intrinsic_[6] = 0.5;
+            if (estimate_focal(pixels, chessboard_num) == 0.0) return false;          // :48-50
+        }
+        estimate_extrinsic(pixels, worlds, chessboard_num);                           // :52
+        poses_from_Rt();                                                              // :62-74
+        const bool status = refinement(pixels, worlds);                               // :76-78
+        if (status) has_init_guess_ = true;
+        for (size_t i = 0; i < Rt_.size(); ++i) {                                     // :88-102: Rt_ from the refined rt_
+            if (!has_chessboard_[i]) continue;
+            const Mat33 R = rodrigues(rt_[i].data());
+            for (int r = 0; r < 3; ++r) { Rt_[i].a[3 * r] = R.a[3 * r]; Rt_[i].a[3 * r + 1] = R.a[3 * r + 1]; Rt_[i].a[3 * r + 2] = rt_[i][3 + r]; }
+        }
+        return status;
+    }
+    bool has_init_guess_ = false;
 
     // TS.cpp:62-74
     void poses_from_Rt()

@@ -118,6 +118,8 @@ def lib():
         L.orc_focal_sample.restype = C.c_int
         L.orc_Rt_to_rt.argtypes = [dp, dp]
         L.orc_Rt_to_rt.restype = None
+        L.orc_estimate_extrinsic.argtypes = [dp, dp, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, C.c_int, dp]
+        L.orc_estimate_extrinsic.restype = C.c_int
         L.orc_build_map.argtypes = [C.POINTER(OrcMapDesc), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_build_map.restype = None
         L.orc_rectify_pair_rotation.argtypes = [dp, dp, dp]
@@ -354,3 +356,14 @@ def Rt_to_rt(Rt) -> np.ndarray:
     out = np.zeros(6)
     lib().orc_Rt_to_rt(_dp(Rt), _dp(out))
     return out
+
+
+def estimate_extrinsic(intr, pix_u, pix_v, count, worlds, board_w):
+    """TS.cpp:170-203 (deterministic planar PnP) -> Rt [V,3,3] ([r1 r2 t]), number of poses"""
+    intr, pix_u, pix_v, worlds = _f(intr), _f(pix_u), _f(pix_v), _f(worlds)
+    count = np.ascontiguousarray(count, dtype=np.int32)
+    V, n = count.shape[0], worlds.shape[0]
+    Rt = np.zeros((V, 3, 3))
+    k = lib().orc_estimate_extrinsic(_dp(intr), _dp(pix_u), _dp(pix_v), count.ctypes.data_as(C.POINTER(C.c_int)), V,
+                                     _dp(worlds), n, board_w, _dp(Rt))
+    return Rt, k

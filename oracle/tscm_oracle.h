@@ -185,6 +185,10 @@ int orc_estimate_focal(const double *pix_u, const double *pix_v, const int *coun
                        double cx, double cy, double *focal, int *total_num);
 int orc_focal_sample(const double *pu, const double *pv, int width, double cx, double cy, double *gamma);
 void orc_Rt_to_rt(const double *Rt, double *rt);
+/* estimate_extrinsic (TS.cpp:170-203) with a deterministic planar PnP in place of cv::solvePnPRansac */
+int orc_planar_pnp(const double *worlds, const double *xn, const double *yn, int n, double *R, double *t);
+int orc_estimate_extrinsic(const double *intr, const double *pix_u, const double *pix_v, const int *count, int n_views,
+                           const double *worlds, int n, int board_w, double *Rt_out);
 
 /* ---- remap tables (TS.cpp:284-330, EpipolarRectify/rectify.cpp:86-199); same layout as tscm_map_desc */
 typedef struct {

@@ -122,6 +122,7 @@ def test_cpp_class_mirror_runs_the_reference_flow(hip_device, tmp_path):
             f.write(np.ascontiguousarray(a).tobytes())
     out = subprocess.check_output([exe, str(tmp_path / "rig.bin"), str(tmp_path / "result.bin"), str(tmp_path / "calib.yaml")]).decode()
     assert "average reproject error" in out
+    assert "mono calibration of camera 0 from raw corners: converged" in out
     raw = open(tmp_path / "result.bin", "rb").read()
     nd = 6 * C + 9 * C + 6 * B + C + 2
     vals = np.frombuffer(raw[:8 * nd], dtype=np.float64)

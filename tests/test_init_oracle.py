@@ -76,3 +76,54 @@ def test_poses_from_Rt_matches_oracle():
         assert np.max(np.abs(got[i] - want)) < 1e-9
         assert np.array_equal(got[i, 3:], t[i])
         assert np.max(np.abs(got[i, :3] - synth.rotmat_to_aa(R[i]))) < 1e-6      # float32 columns
+
+
+def _mono_views(seed, V=12, noise=0.0):
+    p = synth.make_problem(1, V, seed, noise_px=noise, perturb=False)
+    n = p.n_points
+    W = np.concatenate([p.board_xy, np.zeros((n, 1))], axis=1)
+    return p, p.obs_u.reshape(V, n), p.obs_v.reshape(V, n), W
+
+
+def test_estimate_extrinsic_recovers_exact_poses():
+    """Exact intrinsics + exact corners: the planar PnP returns the generating poses."""
+    p, pu, pv, W = _mono_views(5)
+    count = np.full(p.n_views, 54, dtype=np.int32)
+    count[4] = 0
+    Rt, k = orc.estimate_extrinsic(p.meta["gt_intr"][0], pu, pv, count, W, 9)
+    assert k == p.n_views - 1 and np.all(Rt[4] == 0.0)
+    gt = p.meta["gt_board_rt"]
+    R = synth.rodrigues(gt[:, :3])
+    ok = count > 0
+    assert np.max(np.abs(Rt[ok][:, :, 0] - R[ok][:, :, 0])) < 1e-10 and np.max(np.abs(Rt[ok][:, :, 1] - R[ok][:, :, 1])) < 1e-10
+    assert np.max(np.abs(Rt[ok][:, :, 2] - gt[ok][:, 3:])) < 1e-8
+
+
+def test_estimate_extrinsic_minimises_the_normalised_reprojection_error():
+    """With noisy corners and rough intrinsics the result is the least-squares planar pose in the rotated
+    normalised plane: perturbing it increases the error the reference's PnP minimises."""
+    p, pu, pv, W = _mono_views(8, V=6, noise=0.2)
+    I0 = np.array([470.0, 470.0, 639.5, 539.5, 0.0, 0.0, 0.5, 0.0, 0.0])      # TS.cpp:43-47 + a focal estimate
+    Rt, k = orc.estimate_extrinsic(I0, pu, pv, np.full(6, 54, dtype=np.int32), W, 9)
+    assert k == 6
+
+    def cost(Rt_k, u, v):
+        ref = 54 // 2 - 9 // 2 - 1
+        q = orc.unproject(I0, np.array([u[ref], v[ref]]))
+        a, b = np.arctan2(q[0], q[2]), np.arcsin(q[1])
+        R1 = np.array([[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]])
+        R2 = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        T = R2 @ R1
+        e = 0.0
+        for i in range(54):
+            ray = T @ orc.unproject(I0, np.array([u[i], v[i]]))
+            P = T @ (Rt_k[:, 0] * W[i, 0] + Rt_k[:, 1] * W[i, 1] + Rt_k[:, 2])
+            e += (P[0] / P[2] - ray[0] / ray[2]) ** 2 + (P[1] / P[2] - ray[1] / ray[2]) ** 2
+        return e
+    rng = np.random.default_rng(0)
+    for k in range(6):
+        base = cost(Rt[k], pu[k], pv[k])
+        for _ in range(5):
+            d = Rt[k].copy()
+            d[:, 2] += rng.normal(size=3) * 0.5                  # move the translation by ~0.5 mm
+            assert cost(d, pu[k], pv[k]) > base

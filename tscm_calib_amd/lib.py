@@ -104,6 +104,7 @@ EXPORTS = [
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
     "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
+    "tscm_estimate_extrinsic",
 ]
 
 
@@ -161,6 +162,7 @@ def lib():
                                   C.c_size_t, dp]
     L.tscm_estimate_focal.argtypes = [dp, dp, ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, ip]
     L.tscm_poses_from_r1r2t.argtypes = [dp, C.c_void_p, C.c_int, dp]
+    L.tscm_estimate_extrinsic.argtypes = [dp, dp, dp, ip, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, ip]
     L.tscm_yaml_format.argtypes = [C.c_int, dp, dp, dp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tscm_yaml_write.argtypes = [C.c_char_p, C.c_int, dp, dp, dp]
     L.tscm_yaml_parse.argtypes = [C.c_char_p, C.c_int, ip, dp, dp]

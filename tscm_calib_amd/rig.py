@@ -107,3 +107,22 @@ def poses_from_Rt(Rt, has=None) -> np.ndarray:
     h = None if has is None else np.ascontiguousarray(has, dtype=np.uint8)
     _lib.check(_lib.lib().tscm_poses_from_r1r2t(_lib.dptr(Rt), None if h is None else h.ctypes.data, Rt.shape[0], _lib.dptr(rt)))
     return rt
+
+
+def estimate_extrinsic(intr, pix_u, pix_v, count, worlds, board_w: int, device: int = 0):
+    """tscm_estimate_extrinsic (TripleSphereCamera::estimate_extrinsic, TS.cpp:170-203, with a deterministic
+    planar PnP in place of cv::solvePnPRansac) -> Rt [V,3,3] = [r1 r2 t] per image, number of poses."""
+    intr = np.ascontiguousarray(intr, dtype=np.float64).reshape(9)
+    pix_u = np.ascontiguousarray(pix_u, dtype=np.float64)
+    pix_v = np.ascontiguousarray(pix_v, dtype=np.float64)
+    count = np.ascontiguousarray(count, dtype=np.int32)
+    worlds = np.ascontiguousarray(worlds, dtype=np.float64).reshape(-1, 3)
+    V, n = count.shape[0], worlds.shape[0]
+    if pix_u.size != V * n or pix_v.size != V * n:
+        raise ValueError("pix_u / pix_v must hold n_views * n_points values")
+    Rt = np.zeros((V, 3, 3))
+    done = C.c_int(0)
+    _lib.check(_lib.lib().tscm_estimate_extrinsic(_lib.dptr(intr), _lib.dptr(pix_u), _lib.dptr(pix_v),
+                                                  count.ctypes.data_as(C.POINTER(C.c_int)), V, _lib.dptr(worlds), n, board_w,
+                                                  device, _lib.dptr(Rt), C.byref(done)))
+    return Rt, done.value
