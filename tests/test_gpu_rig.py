@@ -150,3 +150,46 @@ def test_cpp_class_mirror_runs_the_reference_flow(hip_device, tmp_path):
     mx = np.frombuffer(raw[8 * nd + 8:8 * nd + 8 + 64], dtype=np.float32)
     ox, _ = orc.build_maps([maps.undistort_desc(intr[0], 300.0, 300.0, 639.5, 539.5, 64, 48)], 64 * 48)
     assert np.array_equal(mx, ox[:16])
+
+
+def test_full_pipeline_from_raw_corner_lists(hip_device):
+    """main.cpp:196-319 after corner detection, with nothing but corner lists as input: per-camera mono
+    calibration (focal estimate, planar PnP, refinement), rig initialisation, joint calibration.  The result
+    must sit at the noise floor and reproduce the rig geometry the corners were generated from."""
+    from tscm_calib_amd.problem import Problem
+    p = synth.make_problem(4, 40, 77, noise_px=0.1)          # 80 frames, each seen by two adjacent cameras
+    C, B, n = p.n_cameras, p.n_boards, p.n_points
+    W = np.concatenate([p.board_xy, np.zeros((n, 1))], axis=1)
+    has = np.zeros((C, B), dtype=np.uint8)
+    pu, pv = np.zeros((C, B, n)), np.zeros((C, B, n))
+    idx = p.view_offset.astype(np.int64)[:, None] + np.arange(n)[None, :]
+    has[p.view_camera, p.view_board] = 1
+    pu[p.view_camera, p.view_board] = p.obs_u[idx]
+    pv[p.view_camera, p.view_board] = p.obs_v[idx]
+    intr = np.zeros((C, 9))
+    Rt = np.zeros((C, B, 3, 3))
+    for m in range(C):                                        # TripleSphereCamera::calibrate per camera (TS.cpp:30-105)
+        count = (has[m] * n).astype(np.int32)
+        I = np.array([0.0, 0.0, 1280 / 2 - 0.5, 1080 / 2 - 0.5, 0.0, 0.0, 0.5, 0.0, 0.0])
+        I[0] = I[1] = rig.estimate_focal(pu[m], pv[m], count, 9, 6, I[2], I[3], hip_device)[0]
+        Rt_m, k = rig.estimate_extrinsic(I, pu[m], pv[m], count, W, 9, hip_device)
+        assert k == int(has[m].sum())
+        boards = np.nonzero(has[m])[0]
+        V = boards.shape[0]
+        q = Problem(1, V, p.board_xy, np.zeros(V, dtype=np.int32), np.arange(V, dtype=np.int32), (np.arange(V) * n).astype(np.int32),
+                    np.full(V, n, dtype=np.int32), pu[m, boards].ravel().copy(), pv[m, boards].ravel().copy(),
+                    np.zeros((1, 6)), I[None, :].copy(), rig.poses_from_Rt(Rt_m[boards]), np.ones(1, dtype=np.uint8), True).normalised()
+        ok, s = api.refinement(q, hip_device)
+        assert ok and s["rmse"] < 0.2
+        intr[m] = q.intr[0]
+        R = synth.rodrigues(q.board_rt[:, :3])                # TS.cpp:88-102: Rt_ from the refined poses
+        Rt[m, boards] = np.stack([R[:, :, 0], R[:, :, 1], q.board_rt[:, 3:]], axis=2)
+    inp = rig.RigInput(W, intr, has, Rt, pu, pv).normalised()
+    g = rig.rig_init(inp, hip_device)                         # MultiCalib::MultiCalib
+    pj = rig.problem_from_rig(inp, g)
+    s = api.calibrate(pj, hip_device)                         # MultiCalib::calibrate
+    assert s["termination_type"] == 0 and s["rmse"] < 0.16    # sigma = 0.1 px per coordinate -> 0.141
+    gt = p.meta["gt_cam_rt"]
+    # rig geometry: camera centres within a few mm, rotations within a few mrad of the generating rig
+    assert np.max(np.abs(pj.cam_rt[:, :3] - gt[:, :3])) < 5e-3
+    assert np.max(np.abs(pj.cam_rt[:, 3:] - gt[:, 3:])) < 5.0
