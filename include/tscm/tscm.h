@@ -337,6 +337,31 @@ int tscm_estimate_extrinsic(const double *intr9, const double *pix_u, const doub
                             int n_views, const double *worlds, int n_points, int board_w, int device,
                             double *Rt, int *n_estimated);
 
+
+/* ------------------------------------------------------------------ corner lists
+ * The reference has no on-disk form of its input: corners go straight from findCorner() into
+ * TripleSphereCamera::calibrate (main.cpp:40-49, 196-222).  This is the library's own, minimal text
+ * format for them (fixtures, hand-over between a detector and the calibration), dense like the
+ * reference's vectors: pixels()[board] per camera, empty where the board was not detected.
+ *
+ *   TSCM-CORNERS 1
+ *   cameras <C> boards <B> cols <W> rows <H> pitch <mm> image <width> <height>
+ *   view <camera> <board>            -- followed by W*H lines "<u> <v>" (%.17g: exact round trip)
+ *   ...
+ * Board point j = (v*pitch, u*pitch, 0), j = u*W + v (main.cpp:12-18).
+ * tscm_corners_read allocates has / pix_u / pix_v (release with tscm_corners_free).  Host-only.  */
+typedef struct tscm_corner_set {
+    int n_cameras, n_boards, board_cols, board_rows;
+    double pitch;
+    int image_width, image_height;
+    unsigned char *has;            /* [C*B]                                   */
+    double *pix_u, *pix_v;         /* [C*B*cols*rows], zero where !has        */
+} tscm_corner_set;
+
+int tscm_corners_write(const char *path, const tscm_corner_set *set);
+int tscm_corners_read(const char *path, tscm_corner_set *set);
+void tscm_corners_free(tscm_corner_set *set);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,3 +65,37 @@ def test_parse_errors_are_reported():
         calib_io.read_calib_yaml("/nonexistent/calib.yaml")
     intr, Twc = calib_io.parse_calib_yaml("%YAML:1.0\n---\n")
     assert intr.shape == (0, 9)
+
+
+def test_corner_list_round_trip_is_exact(tmp_path):
+    p = synth.make_problem(4, 6, 12)
+    inp = synth.make_rig_input(p)
+    path = str(tmp_path / "corners.txt")
+    calib_io.write_corners(path, inp.has, inp.pix_u, inp.pix_v, 9, 6, 45.0)
+    d = calib_io.read_corners(path)
+    assert (d["board_cols"], d["board_rows"], d["pitch"], d["image_size"]) == (9, 6, 45.0, (1280, 1080))
+    assert np.array_equal(d["has"], inp.has)
+    assert np.array_equal(d["pix_u"], inp.pix_u) and np.array_equal(d["pix_v"], inp.pix_v)      # %.17g round-trips doubles
+    text = open(path).read().splitlines()
+    assert text[0] == "TSCM-CORNERS 1" and text[1].startswith("cameras 4 boards 12 cols 9 rows 6 pitch 45 image 1280 1080")
+    assert sum(1 for l in text if l.startswith("view ")) == int(inp.has.sum())
+
+
+def test_corner_list_errors(tmp_path):
+    bad = tmp_path / "bad.txt"
+    bad.write_text("TSCM-CORNERS 1\ncameras 1 boards 1 cols 2 rows 2 pitch 10 image 640 480\nview 0 0\n1 2\n3 4\n5 6\n")   # 3 of 4 corners
+    with pytest.raises(lib.TscmError) as e:
+        calib_io.read_corners(str(bad))
+    assert "expected 4 corners" in str(e.value)
+    bad.write_text("TSCM-CORNERS 1\ncameras 1 boards 1 cols 2 rows 2 pitch 10 image 640 480\nview 0 3\n")
+    with pytest.raises(lib.TscmError):
+        calib_io.read_corners(str(bad))
+    bad.write_text("something else\n")
+    with pytest.raises(lib.TscmError):
+        calib_io.read_corners(str(bad))
+    with pytest.raises(lib.TscmError):
+        calib_io.read_corners(str(tmp_path / "missing.txt"))
+    empty = tmp_path / "empty.txt"
+    calib_io.write_corners(str(empty), np.zeros((2, 3), dtype=np.uint8), np.zeros((2, 3, 54)), np.zeros((2, 3, 54)), 9, 6, 45.0)
+    d = calib_io.read_corners(str(empty))
+    assert d["has"].shape == (2, 3) and not d["has"].any()

@@ -200,3 +200,68 @@ extern "C" int tscm_yaml_read(const char *path, int max_cameras, int *n_cameras,
     ss << f.rdbuf();
     return tscm_yaml_parse(ss.str().c_str(), max_cameras, n_cameras, intr, Twc);
 }
+
+// ------------------------------------------------------------------------------------------------
+// corner lists (tscm.h: "TSCM-CORNERS 1")
+extern "C" void tscm_corners_free(tscm_corner_set *set)
+{
+    if (!set) return;
+    std::free(set->has); std::free(set->pix_u); std::free(set->pix_v);
+    set->has = nullptr; set->pix_u = set->pix_v = nullptr;
+}
+
+extern "C" int tscm_corners_write(const char *path, const tscm_corner_set *set)
+{
+    if (!path || !set) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    const int C = set->n_cameras, B = set->n_boards, n = set->board_cols * set->board_rows;
+    if (C < 0 || B < 0 || set->board_cols < 1 || set->board_rows < 1 || ((size_t)C * B > 0 && (!set->has || !set->pix_u || !set->pix_v)))
+        return tscm_set_error(TSCM_E_INVALID, "inconsistent corner set");
+    std::FILE *f = std::fopen(path, "w");
+    if (!f) return tscm_set_error(TSCM_E_INVALID, std::string("cannot open ") + path + " for writing");
+    std::fprintf(f, "TSCM-CORNERS 1\ncameras %d boards %d cols %d rows %d pitch %.17g image %d %d\n", C, B, set->board_cols, set->board_rows,
+                 set->pitch, set->image_width, set->image_height);
+    for (int m = 0; m < C; ++m)
+        for (int b = 0; b < B; ++b) {
+            if (!set->has[(size_t)m * B + b]) continue;
+            std::fprintf(f, "view %d %d\n", m, b);
+            const size_t o = ((size_t)m * B + b) * n;
+            for (int j = 0; j < n; ++j) std::fprintf(f, "%.17g %.17g\n", set->pix_u[o + j], set->pix_v[o + j]);
+        }
+    const bool ok = std::ferror(f) == 0;
+    return (std::fclose(f) == 0 && ok) ? 0 : tscm_set_error(TSCM_E_INVALID, std::string("write to ") + path + " failed");
+}
+
+extern "C" int tscm_corners_read(const char *path, tscm_corner_set *set)
+{
+    if (!path || !set) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    std::memset(set, 0, sizeof(*set));
+    std::FILE *f = std::fopen(path, "r");
+    if (!f) return tscm_set_error(TSCM_E_INVALID, std::string("cannot open ") + path);
+    auto bail = [&](const std::string &msg) { std::fclose(f); tscm_corners_free(set); return tscm_set_error(TSCM_E_INVALID, "corner list " + std::string(path) + ": " + msg); };
+    int version = 0;
+    if (std::fscanf(f, " TSCM-CORNERS %d", &version) != 1 || version != 1) return bail("not a TSCM-CORNERS 1 file");
+    if (std::fscanf(f, " cameras %d boards %d cols %d rows %d pitch %lf image %d %d", &set->n_cameras, &set->n_boards, &set->board_cols, &set->board_rows,
+                    &set->pitch, &set->image_width, &set->image_height) != 7) return bail("bad header");
+    const int C = set->n_cameras, B = set->n_boards;
+    if (C < 0 || B < 0 || set->board_cols < 1 || set->board_rows < 1 || (long long)C * B > (1LL << 28)) return bail("bad dimensions");
+    const int n = set->board_cols * set->board_rows;
+    const size_t cb = (size_t)C * B;
+    set->has = static_cast<unsigned char *>(std::calloc(cb ? cb : 1, 1));
+    set->pix_u = static_cast<double *>(std::calloc(cb * n ? cb * n : 1, sizeof(double)));
+    set->pix_v = static_cast<double *>(std::calloc(cb * n ? cb * n : 1, sizeof(double)));
+    if (!set->has || !set->pix_u || !set->pix_v) { std::fclose(f); tscm_corners_free(set); return tscm_set_error(TSCM_E_NOMEM, "out of memory"); }
+    for (;;) {
+        int m = 0, b = 0;
+        const int got = std::fscanf(f, " view %d %d", &m, &b);
+        if (got == EOF) break;
+        if (got != 2) return bail("expected 'view <camera> <board>'");
+        if (m < 0 || m >= C || b < 0 || b >= B) return bail("view index out of range");
+        if (set->has[(size_t)m * B + b]) return bail("view " + std::to_string(m) + " " + std::to_string(b) + " listed twice");
+        set->has[(size_t)m * B + b] = 1;
+        const size_t o = ((size_t)m * B + b) * n;
+        for (int j = 0; j < n; ++j)
+            if (std::fscanf(f, " %lf %lf", &set->pix_u[o + j], &set->pix_v[o + j]) != 2) return bail("view " + std::to_string(m) + " " + std::to_string(b) + ": expected " + std::to_string(n) + " corners");
+    }
+    std::fclose(f);
+    return 0;
+}

@@ -94,6 +94,13 @@ class CMapDesc(C.Structure):
     ]
 
 
+class CCornerSet(C.Structure):
+    _fields_ = [
+        ("n_cameras", C.c_int), ("n_boards", C.c_int), ("board_cols", C.c_int), ("board_rows", C.c_int), ("pitch", C.c_double),
+        ("image_width", C.c_int), ("image_height", C.c_int), ("has", C.c_void_p), ("pix_u", C.c_void_p), ("pix_v", C.c_void_p),
+    ]
+
+
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_default_options",
@@ -104,7 +111,7 @@ EXPORTS = [
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
     "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
-    "tscm_estimate_extrinsic",
+    "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
 ]
 
 
@@ -163,6 +170,10 @@ def lib():
     L.tscm_estimate_focal.argtypes = [dp, dp, ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, ip]
     L.tscm_poses_from_r1r2t.argtypes = [dp, C.c_void_p, C.c_int, dp]
     L.tscm_estimate_extrinsic.argtypes = [dp, dp, dp, ip, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, ip]
+    L.tscm_corners_write.argtypes = [C.c_char_p, C.POINTER(CCornerSet)]
+    L.tscm_corners_read.argtypes = [C.c_char_p, C.POINTER(CCornerSet)]
+    L.tscm_corners_free.argtypes = [C.POINTER(CCornerSet)]
+    L.tscm_corners_free.restype = None
     L.tscm_yaml_format.argtypes = [C.c_int, dp, dp, dp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tscm_yaml_write.argtypes = [C.c_char_p, C.c_int, dp, dp, dp]
     L.tscm_yaml_parse.argtypes = [C.c_char_p, C.c_int, ip, dp, dp]
