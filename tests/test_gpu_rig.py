@@ -193,3 +193,26 @@ def test_full_pipeline_from_raw_corner_lists(hip_device):
     # rig geometry: camera centres within a few mm, rotations within a few mrad of the generating rig
     assert np.max(np.abs(pj.cam_rt[:, :3] - gt[:, :3])) < 5e-3
     assert np.max(np.abs(pj.cam_rt[:, 3:] - gt[:, 3:])) < 5.0
+
+
+def test_cli_from_corner_file_to_yaml(hip_device, tmp_path):
+    """examples/calibrate_from_corners.cpp: corner file in, calibration YAML out -- the reference's main.cpp
+    without the detector and the viewer."""
+    import os, subprocess
+    from tscm_calib_amd import calib_io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "calibrate_from_corners")
+    csrc = os.path.join(root, "tscm_calib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "calibrate_from_corners.cpp"),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", exe])
+    p = synth.make_problem(4, 30, 99, noise_px=0.1)
+    inp = synth.make_rig_input(p)
+    calib_io.write_corners(str(tmp_path / "corners.txt"), inp.has, inp.pix_u, inp.pix_v, 9, 6, 45.0)
+    out = subprocess.check_output([exe, str(tmp_path / "corners.txt"), str(tmp_path / "calib.yaml")]).decode()
+    assert out.count("converged") >= 4 and "NOT converged" not in out and "average reproject error" in out
+    intr, Twc = calib_io.read_calib_yaml(str(tmp_path / "calib.yaml"))
+    assert intr.shape == (4, 9) and np.array_equal(Twc[0], np.eye(3, 4))
+    gt = p.meta["gt_cam_rt"]
+    assert np.max(np.abs(Twc[:, :, 3] - gt[:, 3:])) < 6.0                                 # mm
+    assert np.max(np.abs(Twc[:, :, :3] - synth.rodrigues(gt[:, :3]))) < 6e-3
+    assert np.max(np.abs(intr[:, 2:4] - p.meta["gt_intr"][:, 2:4])) < 1.0                 # principal points, px
