@@ -584,7 +584,7 @@ __device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int bl
 }
 
 // deterministic block reductions (256 threads)
-// Block reductions (256 threads): xor-shuffle tree inside each wave, one LDS exchange between the four
+// Block reductions (256 threads; any multiple of 64 works): xor-shuffle tree inside each wave, one LDS exchange between the
 // waves -- two barriers per call, several quantities at once (the previous LDS tree cost ten barriers per
 // quantity: 1.5 us each on the single-block control paths).  Fixed order: bit-reproducible.
 template <int NS>
@@ -596,16 +596,24 @@ __device__ __forceinline__ void block_reduce256(double (&sum)[NS], double &mx, d
         for (int i = 0; i < NS; ++i) sum[i] += __shfl_xor(sum[i], off);
         mx = fmax(mx, __shfl_xor(mx, off));
     }
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) sm[wave * (NS + 1) + i] = sum[i];
         sm[wave * (NS + 1) + NS] = mx;
     }
     __syncthreads();
+    if (nw == 4) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) sum[i] = (sm[i] + sm[(NS + 1) + i]) + (sm[2 * (NS + 1) + i] + sm[3 * (NS + 1) + i]);
-    mx = fmax(fmax(sm[NS], sm[(NS + 1) + NS]), fmax(sm[2 * (NS + 1) + NS], sm[3 * (NS + 1) + NS]));
+        for (int i = 0; i < NS; ++i) sum[i] = (sm[i] + sm[(NS + 1) + i]) + (sm[2 * (NS + 1) + i] + sm[3 * (NS + 1) + i]);
+        mx = fmax(fmax(sm[NS], sm[(NS + 1) + NS]), fmax(sm[2 * (NS + 1) + NS], sm[3 * (NS + 1) + NS]));
+    } else {                                    // other workgroup sizes (k_solve_reduced<4, 32>): waves in order
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { double t = 0.0; for (int w = 0; w < nw; ++w) t += sm[w * (NS + 1) + i]; sum[i] = t; }
+        double t = sm[NS];
+        for (int w = 1; w < nw; ++w) t = fmax(t, sm[w * (NS + 1) + NS]);
+        mx = t;
+    }
     __syncthreads();
 }
 __device__ __forceinline__ double block_sum256(double v, double *sm)
@@ -969,13 +977,16 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
 // yhat = S_c y (camera step = -yhat) and the candidate camera parameters.
 // grid 1 x 256, dynamic LDS N*(N+1) + 2*N*TS + 2*TS*TS + 2*TS + 5*N doubles.
 // ---------------------------------------------------------------------------------------------
-template <int TS>
-__global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
+// G x G threads, thread (ti, tj) owns the TS x TS tile (ti, tj) of the COMPACT system (N = G * TS >= n_act columns);
+// NPD >= n_pad is the capacity of the arrays indexed by padded column
+template <int TS, int G = 16, int NPD = 64>
+__global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S)
 {
+    constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
     // control block and the static column tables are requested together (one memory round trip); the early
     // exit is taken once they are there
     const int ctrl_done = S.ctrl->done;
-    constexpr int N = 16 * TS;
+    constexpr int N = G * TS;
     constexpr int LD = N + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Lm = lds;                 // [N][LD] lower factor (for the back-substitution)
@@ -983,27 +994,24 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     double *Ld = Xb + 2 * N * TS;     // [2][TS][TS] inverse of the diagonal factor
     double *wq = Ld + 2 * TS * TS;    // [2][TS] rhs slice of the panel
     double *wp = wq + 2 * TS;         // [N] forward-substituted rhs  w = L^{-1} b
-    double *yv = wp + N;              // [N]
-    double *s_sc = yv + N;            // [N]
-    double *s_yh = s_sc + N;          // [N]
-    double *idg = s_yh + N;           // [N] 1 / L_kk
+    double *idg = wp + N;             // [N] 1 / L_kk
+    double *yv = idg + N;             // [NPD] solution by padded column
+    double *s_sc = yv + NPD;          // [NPD]
+    double *s_yh = s_sc + NPD;        // [NPD]
     __shared__ int s_fail;
-    __shared__ unsigned char s_act[N];
+    __shared__ unsigned char s_act[NPD];
     __shared__ double sred[256];
     const int n = P.n_pad;            // <= N
     const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;
+    const int ti = tid / G, tj = tid % G;
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     const double *H = S.H[cur];
     const int ctrl_fail = S.ctrl->lin_fail;
     __shared__ int s_map[N];          // compact index -> padded column, -1 past the last free column
-    for (int i = tid; i < N; i += 256) {
-        s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0;
-        s_map[i] = i < P.n_act ? P.act_map[i] : -1;
-        yv[i] = 0.0;
-    }
+    for (int i = tid; i < NPD; i += NT) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; yv[i] = 0.0; }
+    for (int i = tid; i < N; i += NT) s_map[i] = i < P.n_act ? P.act_map[i] : -1;
     if (ctrl_done) return;
     if (tid == 0) s_fail = ctrl_fail;
     const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
@@ -1169,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     if (tid < 64) {
         // blocked back-substitution, TS unknowns per step: all lanes solve the TS x TS upper-triangular
         // diagonal system redundantly (operands by broadcast), then lane i applies the TS columns to w[i]
-        constexpr int R = N / 64;
+        constexpr int R = (N + 63) / 64;
         double w[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) w[q] = tid + 64 * q < NP * TS ? wp[tid + 64 * q] : 0.0;
@@ -1206,13 +1214,13 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) { const int pi = s_map[tid + 64 * q]; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
+        for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? s_map[tid + 64 * q] : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
     }
     __syncthreads();
     // ---- yhat, candidate camera parameters, camera part of model cost change / step norm --------
     double model = 0.0, stepsq = 0.0;
     const int fail = s_fail;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         const int m = i >> 4, ai = i & 15;
         const bool act = s_act[i] && !fail;
         const double yh = act ? s_sc[i] * yv[i] : 0.0;
@@ -1234,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_solve_reduced(DevProblem P, DevState S)
     }
     __syncthreads();
     // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         const int m = i >> 4, ai = i & 15;
         if (ai >= kFA) continue;
         const double yi = s_yh[i];

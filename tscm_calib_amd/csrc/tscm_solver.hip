@@ -69,6 +69,7 @@ struct tscm_solver {
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0;
+    int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     int ablate = 0;                     // TSCM_ABLATE: profiling aid (skips parts of k_eval_gram; results invalid)
     // dominant-kernel timing
@@ -446,9 +447,18 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
 
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = 4 * sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points);
-    { const size_t NN = s->n_pad <= 64 ? 64 : 128; const size_t TT = NN / 16; s->lds_solve = sizeof(double) * (NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 5 * NN); }
+    // reduced solve on the compact system: 4 x 4 tiles on 16 x 16 threads (<= 64 free columns), 4 x 4 tiles on 25 x 25
+    // threads (<= 100, e.g. 8 cameras with one constant pose: 98) or 4 x 4 tiles on 32 x 32 threads (<= 128)
+    {
+        auto lds_doubles = [](size_t NN, size_t TT, size_t NPD) { return NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 2 * NN + 3 * NPD; };
+        s->solve_variant = s->n_pad <= 64 ? 0 : (P.n_act <= 100 ? 1 : 2);
+        s->lds_solve = sizeof(double) * (s->solve_variant == 0 ? lds_doubles(64, 4, 64) : s->solve_variant == 1 ? lds_doubles(100, 4, 128) : lds_doubles(128, 4, 128));
+    }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
-    if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
+    if (s->lds_solve > 64 * 1024) {
+        if (s->solve_variant == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<4, 25, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
+        else HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<4, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
+    }
     HIP_TRY(hipDeviceSynchronize());
     *out = sp.release();
     return 0;
@@ -551,8 +561,9 @@ static int enqueue_iteration(tscm_solver *s)
     if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
     if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
     if (s->comm) NCCL_TRY(ncclAllReduce(S.T, S.T, (size_t)P.n_pad * P.n_pad, ncclDouble, ncclSum, s->comm->comm, s->stream));
-    if (P.n_pad <= 64) hipLaunchKernelGGL(k_solve_reduced<4>, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
-    else hipLaunchKernelGGL(k_solve_reduced<8>, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+    if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+    else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
+    else hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
     if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
     return enqueue_eval(s, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
