@@ -61,19 +61,6 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, (int)voff, (int)soff, 0);
 }
 
-// Wave-uniform constants are kept one per LANE of a VGPR and fetched with v_readlane into an SGPR pair:
-// a VALU-latency operation whose result feeds the next VALU instruction as a scalar operand, instead of
-// an LDS broadcast read with its ~100-cycle round trip (k_eval_gram had 35 of those, each followed by
-// s_waitcnt lgkmcnt(0), in the geometry of every view).
-__device__ __forceinline__ double lane_const(double v, int k)
-{
-    const v2i b = __builtin_bit_cast(v2i, v);
-    v2i r;
-    r.x = __builtin_amdgcn_readlane(b.x, k);
-    r.y = __builtin_amdgcn_readlane(b.y, k);
-    return __builtin_bit_cast(double, r);
-}
-
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
