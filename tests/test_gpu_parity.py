@@ -374,3 +374,22 @@ def test_no_device_memory_leak_over_repeated_calls(hip_device):
         one_round()
     free1 = free_bytes()
     assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 40 rounds"
+
+
+def test_results_are_bit_reproducible_run_to_run(hip_device):
+    """No atomics and fixed reduction orders anywhere on the path: repeated solves of the same problem give
+    bit-identical parameters, costs and iteration logs (also across solver instances)."""
+    p = synth.make_problem(4, 150, 20243)
+    ref = None
+    for rep in range(4):
+        q = p.copy().normalised()
+        if rep < 2:
+            s = api.calibrate(q, hip_device)
+        else:
+            with api.Solver(q) as sv:
+                s = sv.solve()
+        sig = (q.intr.tobytes(), q.cam_rt.tobytes(), q.board_rt.tobytes(), s["final_cost"], s["num_iterations"],
+               tuple(it["cost"] for it in s["iterations"]), tuple(it["gradient_norm"] for it in s["iterations"]))
+        if ref is None:
+            ref = sig
+        assert sig == ref, f"run {rep} differs from run 0"
