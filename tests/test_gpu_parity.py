@@ -393,3 +393,22 @@ def test_results_are_bit_reproducible_run_to_run(hip_device):
         if ref is None:
             ref = sig
         assert sig == ref, f"run {rep} differs from run 0"
+
+
+def test_config5_properties(hip_device):
+    """BASELINE config 5 (8 cameras x 20k views, 8.64 M corners): size-independent properties of the solve
+    (monotone accepted costs, RMSE at the noise floor, fp32-Jacobian tier within 1e-3 of the fp64 tier)."""
+    p = synth.make_config(5)
+    p64, p32 = p.copy().normalised(), p.copy().normalised()
+    s64 = api.calibrate(p64, hip_device)
+    assert s64["termination"] == "CONVERGENCE"
+    costs = [it["cost"] for it in s64["iterations"] if it["step_is_successful"]]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))
+    # sigma = 0.1 px per coordinate; the fit absorbs 6 parameters per board (+ 13 per camera) of the 2N residuals
+    dof = 1.0 - (6.0 * p.n_boards + 13.0 * p.n_cameras) / (2.0 * p.n_corners)
+    assert abs(s64["rmse"] - 0.1 * np.sqrt(2.0 * dof)) < 5e-4
+    s32 = api.calibrate(p32, hip_device, jacobian_fp32=1)
+    assert s32["termination"] == "CONVERGENCE"
+    assert abs(s32["rmse"] - s64["rmse"]) < 1e-3 * s64["rmse"]
+    d = H.param_rel_err(p32, p64)
+    assert max(d["cam_rt"], d["board_rt"]) < 1e-3, d
