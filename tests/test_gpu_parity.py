@@ -412,3 +412,19 @@ def test_config5_properties(hip_device):
     assert abs(s32["rmse"] - s64["rmse"]) < 1e-3 * s64["rmse"]
     d = H.param_rel_err(p32, p64)
     assert max(d["cam_rt"], d["board_rt"]) < 1e-3, d
+
+
+def test_chunks_longer_than_one_metadata_block(hip_device):
+    """560 k views (6-corner boards) put ~137 views into every chunk of the Gram kernel, i.e. more than the
+    64 whose metadata one lane block holds: the multi-block path of the view loop against the oracle."""
+    p = synth.make_problem(4, 140000, 4242, cols=3, rows=2, pitch=60.0)
+    assert p.n_views == 560000
+    pg, po = p.copy().normalised(), p.copy().normalised()
+    with api.Solver(pg) as s:
+        gs = s.solve(max_num_iterations=1)
+    os_ = orc.solve(po, max_num_iterations=1)
+    for a, b in zip(gs["iterations"], os_["iterations"]):
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-8 * b["gradient_max_norm"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(b["step_norm"], 1e-12)
+    assert np.max(np.abs(pg.intr[:, :7] - po.intr[:, :7]) / np.abs(po.intr[:, :7])) < 1e-7
