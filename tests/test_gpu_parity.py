@@ -428,3 +428,18 @@ def test_chunks_longer_than_one_metadata_block(hip_device):
         assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-8 * b["gradient_max_norm"]
         assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(b["step_norm"], 1e-12)
     assert np.max(np.abs(pg.intr[:, :7] - po.intr[:, :7]) / np.abs(po.intr[:, :7])) < 1e-7
+
+
+@pytest.mark.parametrize("cols,rows", [(7, 8), (8, 7), (9, 6), (10, 6), (8, 8), (13, 5), (5, 4), (3, 3), (5, 2), (7, 5), (4, 3), (9, 5),
+                                       (9, 7), (13, 4), (11, 9), (16, 8), (13, 10), (17, 12)])
+def test_board_shapes_around_the_tile_limits(hip_device, cols, rows):
+    """53..56 corners take the compile-time-pitch kernel, 57..64 the generic one in a single pass, 65 and more
+    several passes; corner counts of every residue mod 8 (the MFMA loops consume the tile in pairs of 4-row
+    k-steps: a tile with an odd number of k-steps used to read past its rows).  Every shape against the oracle."""
+    p = synth.make_problem(4, 10, 100 + cols * rows, cols=cols, rows=rows, pitch=40.0)
+    pg, po, gs, os_ = _solve_both(p, max_num_iterations=4)
+    assert gs["num_iterations"] == os_["num_iterations"]
+    for a, b in zip(gs["iterations"], os_["iterations"]):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
+    assert max(H.param_rel_err(pg, po).values()) < 1e-7

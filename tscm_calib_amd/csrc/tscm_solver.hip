@@ -225,10 +225,11 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
 
     // ---- chunks of views (one wave each), never straddling a camera ----------------------------
     // one round of resident waves: LDS admits floor(160 KiB / lds_eval) single-wave workgroups per CU
-    // Jacobian tile geometry: HV rows (multiple of 4 covering min(64, n) corners; u-rows and v-rows take turns), pitch HV + 2
+    // Jacobian tile geometry: HV rows (multiple of 8 covering min(64, n) corners -- the MFMA loops consume the k-steps
+    // of 4 rows in PAIRS, so the tile holds an even number of them; u-rows and v-rows take turns), pitch HV + 2
     // (= 2 * odd: the 16 columns x 2 rows of a 32-lane ds_read_b64 group then hit 32 distinct bank pairs)
-    const int half_rows = 4 * ((std::min(64, p->n_points) + 3) / 4);
-    const int rp = half_rows + 2;      // = 2 * odd (half_rows is a multiple of 4)
+    const int half_rows = 8 * ((std::min(64, p->n_points) + 7) / 8);
+    const int rp = half_rows + 2;      // = 2 * odd (half_rows is a multiple of 8)
     const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)16 * rp, 512) + kCst + 2 * (size_t)p->n_points);
     // k_eval_gram runs 4 single-chunk waves per workgroup (they share only the final camera-tile sum)
     if (4 * lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_eval_bytes)));
