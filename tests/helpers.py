@@ -53,10 +53,10 @@ def param_rel_err(p: Problem, q: Problem) -> dict:
     return d
 
 
-def mixed_visibility_rig(seed=5, n_frames=24, n_cameras=4, noise_px=0.05) -> Problem:
+def mixed_visibility_rig(seed=5, n_frames=24, n_cameras=4, noise_px=0.05, **board) -> Problem:
     """Rig whose frames are seen by 1..C cameras (random subsets).  Observations are exact
     projections of the ground truth (image bounds ignored: the solver does not care), plus noise."""
-    base = synth.make_problem(n_cameras, 2 * n_frames // n_cameras * 2, seed, noise_px=0.0)
+    base = synth.make_problem(n_cameras, 2 * n_frames // n_cameras * 2, seed, noise_px=0.0, **board)
     rng = np.random.default_rng(seed)
     C, B = n_cameras, min(n_frames, base.n_boards)
     intr, cam, brd = base.meta["gt_intr"], base.meta["gt_cam_rt"], base.meta["gt_board_rt"][:B]
