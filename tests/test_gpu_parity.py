@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as orc
-from tscm_calib_amd import api, synth
+from tscm_calib_amd import api, lib, synth
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -443,3 +443,24 @@ def test_board_shapes_around_the_tile_limits(hip_device, cols, rows):
         assert a["step_is_successful"] == b["step_is_successful"]
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
     assert max(H.param_rel_err(pg, po).values()) < 1e-7
+
+
+@pytest.mark.parametrize("C,views", [(9, 6), (12, 8), (16, 6), (20, 4), (32, 4)])
+def test_rigs_of_more_than_eight_cameras(hip_device, C, views):
+    """More than 8 cameras: the reduced camera system (up to 13 C - 6 columns) leaves the register/LDS solver and
+    is factored in global memory by k_solve_reduced_big; same iteration trace as the oracle."""
+    p = synth.make_problem(C, views, 900 + C)
+    pg, po, gs, os_ = _solve_both(p, max_num_iterations=4)
+    assert gs["num_iterations"] == os_["num_iterations"]
+    for a, b in zip(gs["iterations"], os_["iterations"]):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(b["step_norm"], 1e-12)
+    assert max(H.param_rel_err(pg, po).values()) < 1e-7
+
+
+def test_more_than_32_cameras_is_refused(hip_device):
+    p = synth.make_problem(33, 2, 5)
+    with pytest.raises(lib.TscmError) as e:
+        api.Solver(p.normalised())
+    assert e.value.code == -5

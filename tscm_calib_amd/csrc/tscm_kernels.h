@@ -32,7 +32,8 @@ constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 do
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
 constexpr int kCamG1 = 16;         // first-level fan-in of the per-camera tile reduction
-constexpr int kMaxCam = 8;         // n_pad = 16*C <= 128 (reduced system kept in LDS)
+constexpr int kMaxCamLds = 8;      // n_pad = 16*C <= 128: reduced system solved in registers/LDS (k_solve_reduced)
+constexpr int kMaxCam = 32;        // larger rigs: k_solve_reduced_big factors the system in global memory (n_pad <= 512)
 constexpr int kMaxLog = 256;
 
 // LDS hand-off inside ONE wave (64-thread workgroups): DS operations of a wave are serviced in
@@ -131,6 +132,7 @@ struct DevState {
     double *L, *z, *D2, *Y;
     double *pairpart, *T;
     double *yhat;
+    double *Abig;                      // [(N + 4)][N] compact reduced system + rhs row, rigs of more than kMaxCamLds cameras only
     double *bs_part, *st_part;
     int n_bs_blocks, n_st_blocks;
     Ctrl *ctrl;
@@ -951,6 +953,50 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
     }
 }
 
+// Common end of the reduced-system solvers: yhat = S_c y (camera step = -yhat), the candidate camera parameters, and
+// the camera part of the model cost change / step norm.  yv: solution by padded column (LDS); s_sc, s_yh, s_act: LDS
+// arrays of n_pad entries; NT = workgroup size.  Every thread of the workgroup calls it.
+template <int NT>
+__device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const DevState &S, int cur, const double *H, int fail,
+                                                      const double *yv, const double *s_sc, double *s_yh, const unsigned char *s_act, double *sred)
+{
+    const int n = P.n_pad, tid = threadIdx.x;
+    double model = 0.0, stepsq = 0.0;
+    for (int i = tid; i < n; i += NT) {
+        const int m = i >> 4, ai = i & 15;
+        const bool act = s_act[i] && !fail;
+        const double yh = act ? s_sc[i] * yv[i] : 0.0;
+        S.yhat[i] = yh;
+        s_yh[i] = yh;
+        if (ai < 6) {
+            const double x = S.cam_rt[cur][6 * m + ai];
+            const double xn = x + (-yh);
+            S.cam_rt[cur ^ 1][6 * m + ai] = xn;
+            const double d = x - xn; stepsq += d * d;
+        } else if (ai < kFA) {
+            const double x = S.intr[cur][9 * m + (ai - 6)];
+            const double xn = x + (-yh);
+            S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
+            const double d = x - xn; stepsq += d * d;
+        } else if (ai < 15) {
+            S.intr[cur ^ 1][9 * m + (ai - 6)] = S.intr[cur][9 * m + (ai - 6)];   // b, c are inert
+        }
+    }
+    __syncthreads();
+    // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
+    for (int i = tid; i < n; i += NT) {
+        const int m = i >> 4, ai = i & 15;
+        if (ai >= kFA) continue;
+        const double yi = s_yh[i];
+        if (yi == 0.0) continue;
+        double hy = 0.0;
+        for (int b = 0; b < kFA; ++b) hy += H[256 * m + ai * 16 + b] * s_yh[m * 16 + b];
+        model += yi * (H[256 * m + ai * 16 + kFR] - 0.5 * hy);
+    }
+    { double red[2] = { model, stepsq }, mdummy = 0.0; block_reduce256<2>(red, mdummy, sred); model = red[0]; stepsq = red[1]; }
+    if (tid == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reduced camera system (DenseSchurComplementSolver): one 256-thread workgroup.
 //   A = S_c (H_cc - T) S_c + D_c^2, rhs = S_c (g_c - t_r); inactive columns (tile padding,
@@ -1204,42 +1250,183 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? s_map[tid + 64 * q] : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
     }
     __syncthreads();
-    // ---- yhat, candidate camera parameters, camera part of model cost change / step norm --------
-    double model = 0.0, stepsq = 0.0;
-    const int fail = s_fail;
-    for (int i = tid; i < n; i += NT) {
-        const int m = i >> 4, ai = i & 15;
-        const bool act = s_act[i] && !fail;
-        const double yh = act ? s_sc[i] * yv[i] : 0.0;
-        S.yhat[i] = yh;
-        s_yh[i] = yh;
-        if (ai < 6) {
-            const double x = S.cam_rt[cur][6 * m + ai];
-            const double xn = x + (-yh);
-            S.cam_rt[cur ^ 1][6 * m + ai] = xn;
-            const double d = x - xn; stepsq += d * d;
-        } else if (ai < kFA) {
-            const double x = S.intr[cur][9 * m + (ai - 6)];
-            const double xn = x + (-yh);
-            S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
-            const double d = x - xn; stepsq += d * d;
-        } else if (ai < 15) {
-            S.intr[cur ^ 1][9 * m + (ai - 6)] = S.intr[cur][9 * m + (ai - 6)];   // b, c are inert
+    reduced_solution_tail<NT>(P, S, cur, H, s_fail, yv, s_sc, s_yh, s_act, sred);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduced camera system of rigs with more than kMaxCamLds cameras (up to kMaxCam: 496 free columns): the
+// compact system no longer fits registers + LDS, so ONE 1024-thread workgroup runs a blocked right-looking
+// Cholesky (16-column panels) on the matrix in global memory (S.Abig, L2-resident: <= 2 MB).  The right-hand
+// side rides along as row N of the matrix, so the forward substitution w = L^{-1} b falls out of the panel
+// solves and trailing updates.  Per panel: wave 0 factors the 16x16 diagonal block in LDS; one thread per row
+// solves its panel row (and parks it, transposed, in LDS); 4x4 register tiles apply the rank-16 update.
+// Same arithmetic as k_solve_reduced up to the summation order inside the updates.
+// grid 1 x 1024, dynamic LDS  16*(N+4) + 16*17 + 3*N + 3*n_pad doubles + N ints.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBigNT = 1024;
+__host__ __device__ inline size_t solve_big_lds_bytes(int N, int n_pad)
+{
+    return sizeof(double) * ((size_t)16 * (N + 4) + 16 * 17 + 3 * (size_t)N + 3 * (size_t)n_pad) + sizeof(int) * (size_t)N + (size_t)n_pad;
+}
+__global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevState S)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = P.n_pad, na = P.n_act;
+    const int N = (na + 15) & ~15, NP = N >> 4;     // compact columns rounded up to whole panels (identity padding)
+    const int XP = N + 4;                           // pitch of the transposed panel copy
+    double *Xt = lds;                 // [16][XP] panel rows k0+16 .. N (the rhs row), transposed
+    double *Ld = Xt + 16 * XP;        // [16][17] diagonal block
+    double *wv = Ld + 16 * 17;        // [N] w = L^{-1} b, then overwritten with y
+    double *idg = wv + N;             // [N] 1 / L_kk
+    double *yk = idg + N;             // [N] (only [16] used per panel)
+    double *yv = yk + N;              // [n_pad] solution by padded column
+    double *s_sc = yv + n;            // [n_pad]
+    double *s_yh = s_sc + n;          // [n_pad]
+    int *s_map = reinterpret_cast<int *>(s_yh + n);                         // [N]
+    unsigned char *s_act = reinterpret_cast<unsigned char *>(s_map + N);    // [n_pad]
+    __shared__ int s_fail;
+    __shared__ double sred[256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (S.ctrl->done) return;
+    const int cur = S.ctrl->cur;
+    const double radius = S.ctrl->radius;
+    const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
+    const double *H = S.H[cur];
+    double *A = S.Abig;               // [(N + 1)][N], row N = rhs
+    for (int i = tid; i < n; i += kBigNT) { s_sc[i] = S.s_c[i]; s_act[i] = P.col_active[i]; yv[i] = 0.0; }
+    for (int i = tid; i < N; i += kBigNT) s_map[i] = i < na ? P.act_map[i] : -1;
+    if (tid == 0) s_fail = S.ctrl->lin_fail;
+    __syncthreads();
+    // ---- build the lower triangle and the rhs row --------------------------------------------------
+    for (int r = wave; r <= N; r += kBigNT / 64) {
+        const int i = r < N ? s_map[r] : -1;
+        for (int c = lane; c < N && (c <= r); c += 64) {
+            const int j = s_map[c];
+            double v;
+            if (r == N) {
+                v = 0.0;
+                if (j >= 0) { const int mj = j >> 4, b = j & 15; v = s_sc[j] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)j * n + mj * 16 + kFR]); }
+            } else {
+                v = (r == c) ? 1.0 : 0.0;
+                if (i >= 0 && j >= 0) {
+                    const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
+                    const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
+                    const double t = (mi > mj) ? S.T[(size_t)j * n + i] : S.T[(size_t)i * n + j];
+                    v = s_sc[i] * s_sc[j] * (h - t);
+                    if (i == j) v += fmin(fmax(s_sc[i] * s_sc[i] * h, dmin), dmax) / radius;
+                }
+            }
+            A[(size_t)r * N + c] = v;
         }
     }
     __syncthreads();
-    // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
-    for (int i = tid; i < n; i += NT) {
-        const int m = i >> 4, ai = i & 15;
-        if (ai >= kFA) continue;
-        const double yi = s_yh[i];
-        if (yi == 0.0) continue;
-        double hy = 0.0;
-        for (int b = 0; b < kFA; ++b) hy += H[256 * m + ai * 16 + b] * s_yh[m * 16 + b];
-        model += yi * (H[256 * m + ai * 16 + kFR] - 0.5 * hy);
+    // ---- factorisation -------------------------------------------------------------------------------
+    for (int tk = 0; tk < NP; ++tk) {
+        const int k0 = tk * 16, m0 = k0 + 16;
+        if (wave == 0) {
+            for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; Ld[r * 17 + c] = c <= r ? A[(size_t)(k0 + r) * N + k0 + c] : 0.0; }
+            wave_lds_fence();
+            for (int c = 0; c < 16; ++c) {
+                double d = Ld[c * 17 + c];
+                if (!(d > 0.0)) { d = 1.0; if (lane == 0) s_fail = 1; }
+                const double isd = fast_rsqrt(d);
+                wave_lds_fence();
+                if (lane < 16 && lane > c) Ld[lane * 17 + c] *= isd;
+                if (lane == c) { Ld[c * 17 + c] = d * isd; idg[k0 + c] = isd; }
+                wave_lds_fence();
+                for (int e = lane; e < 256; e += 64) {
+                    const int r = e >> 4, q = e & 15;
+                    if (q > c && r >= q) Ld[r * 17 + q] -= Ld[r * 17 + c] * Ld[q * 17 + c];
+                }
+                wave_lds_fence();
+            }
+            for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; if (c <= r) A[(size_t)(k0 + r) * N + k0 + c] = Ld[r * 17 + c]; }
+        }
+        __syncthreads();
+        // panel rows m0 .. N: x = a L_kk^{-T}, one thread per row
+        for (int r = m0 + tid; r <= N; r += kBigNT) {
+            double *row = A + (size_t)r * N + k0;
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = row[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double v = x[c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= x[q] * Ld[c * 17 + q];
+                x[c] = v * idg[k0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { row[c] = x[c]; Xt[c * XP + (r - m0)] = x[c]; }
+        }
+        __syncthreads();
+        // trailing update A[i][j] -= sum_c X[i][c] X[j][c],  m0 <= j <= i <= N (j < N), 4x4 tiles
+        {
+            const int nb = (N - m0) >> 2, nr = nb + 1;         // column tiles; row tiles (the last holds only the rhs row)
+            const int ty = tid >> 5, tx = tid & 31;
+            for (int a = ty; a < nr; a += 32) {
+                for (int b = tx; b <= a && b < nb; b += 32) {
+                    double acc[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+#pragma unroll 4
+                    for (int q = 0; q < 16; ++q) {
+                        const d4 xi = *reinterpret_cast<const d4 *>(Xt + q * XP + 4 * a);
+                        const d4 xj = *reinterpret_cast<const d4 *>(Xt + q * XP + 4 * b);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[r][c] += xi[r] * xj[c];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = m0 + 4 * a + r;
+                        if (i > N) continue;
+                        d4 *dst = reinterpret_cast<d4 *>(A + (size_t)i * N + m0 + 4 * b);
+                        d4 v = *dst;
+                        v[0] -= acc[r][0]; v[1] -= acc[r][1]; v[2] -= acc[r][2]; v[3] -= acc[r][3];
+                        *dst = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    { double red[2] = { model, stepsq }, mdummy = 0.0; block_reduce256<2>(red, mdummy, sred); model = red[0]; stepsq = red[1]; }
-    if (tid == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
+    // ---- back-substitution L^T y = w (w = row N of the factor) -------------------------------------
+    for (int i = tid; i < N; i += kBigNT) wv[i] = A[(size_t)N * N + i];
+    __syncthreads();
+    for (int tk = NP - 1; tk >= 0; --tk) {
+        const int k0 = tk * 16;
+        if (wave == 0) {
+            for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; Ld[r * 17 + c] = c <= r ? A[(size_t)(k0 + r) * N + k0 + c] : 0.0; }
+            wave_lds_fence();
+            if (lane == 0) {
+                double y[16];
+#pragma unroll
+                for (int c = 15; c >= 0; --c) {
+                    double v = wv[k0 + c];
+#pragma unroll
+                    for (int q = c + 1; q < 16; ++q) v -= Ld[q * 17 + c] * y[q];
+                    y[c] = v * idg[k0 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { yk[c] = y[c]; wv[k0 + c] = y[c]; }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < k0; i += kBigNT) {
+            double v = wv[i];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v -= A[(size_t)(k0 + c) * N + i] * yk[c];
+            wv[i] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < na; i += kBigNT) yv[s_map[i]] = wv[i];          // back to padded columns
+    __syncthreads();
+    reduced_solution_tail<kBigNT>(P, S, cur, H, s_fail, yv, s_sc, s_yh, s_act, sred);
 }
 
 // back-substitution of the board steps (SchurEliminator::BackSubstitute), 16 lanes per board:
@@ -1328,20 +1515,20 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
     const double *sc = S.H_stage + 256 * P.C;
     // camera-side norms |x - Plus(x, -g)|_inf, its 2-norm, |x|^2 and the cost, one thread per parameter
     double gmax_c = 0.0, gsq_c = 0.0, xsq_c = 0.0, cost = 0.0;
-    if (t < 16 * P.C) {
-        const int m = t >> 4, a = t & 15;
+    for (int p = t; p < 16 * P.C; p += 256) {          // (one pass up to 16 cameras)
+        const int m = p >> 4, a = p & 15;
         if (a < 15 && P.cam_active[m] && !(a < 6 && P.cam_const[m])) {
             const double x = a < 6 ? S.cam_rt[tgt][6 * m + a] : S.intr[tgt][9 * m + (a - 6)];
             const double g = a < kFA ? H[256 * m + a * 16 + kFR] : 0.0;   // b, c: zero gradient
             const double d = x - (x + (-g));
-            gmax_c = fabs(d); gsq_c = d * d; xsq_c = x * x;
+            gmax_c = fmax(gmax_c, fabs(d)); gsq_c += d * d; xsq_c += x * x;
         }
-        if (a == 15) cost = 0.5 * H[256 * m + kFR * 16 + kFR];
+        if (a == 15) cost += 0.5 * H[256 * m + kFR * 16 + kFR];
         if (init && a < 15) {
             const double hii = (a < kFA) ? H[256 * m + a * 16 + a] : 0.0;
-            S.s_c[t] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
+            S.s_c[p] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
         }
-        if (init && a == 15) S.s_c[t] = 1.0;
+        if (init && a == 15) S.s_c[p] = 1.0;
     }
     { double red[3] = { gsq_c, xsq_c, cost }; block_reduce256<3>(red, gmax_c, sm); gsq_c = red[0]; xsq_c = red[1]; cost = red[2]; }
     if (t != 0) return;

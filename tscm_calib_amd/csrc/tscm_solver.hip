@@ -69,7 +69,7 @@ struct tscm_solver {
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0;
-    int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>
+    int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     int ablate = 0;                     // TSCM_ABLATE: profiling aid (skips parts of k_eval_gram; results invalid)
     // dominant-kernel timing
@@ -145,7 +145,7 @@ static int validate(const tscm_problem *p)
     if (p->mono && p->n_cameras != 1) return fail(TSCM_E_INVALID, "mono problem needs exactly one camera");
     if (!p->board_xy || !p->intr || (!p->board_rt && p->n_boards) || (!p->mono && !p->cam_rt)) return fail(TSCM_E_INVALID, "NULL parameter/board array");
     if (p->n_views && (!p->view_camera || !p->view_board || !p->view_offset || !p->view_count || !p->obs_u || !p->obs_v)) return fail(TSCM_E_INVALID, "NULL view/observation array");
-    if (p->n_cameras > kMaxCam) return fail(TSCM_E_UNSUPPORTED, "more than 8 cameras: reduced system does not fit the LDS-resident solver");
+    if (p->n_cameras > kMaxCam) return fail(TSCM_E_UNSUPPORTED, "more than 32 cameras");
     for (int v = 0; v < p->n_views; ++v) {
         if (p->view_camera[v] < 0 || p->view_camera[v] >= p->n_cameras) return fail(TSCM_E_INVALID, "view_camera out of range");
         if (p->view_board[v] < 0 || p->view_board[v] >= p->n_boards) return fail(TSCM_E_INVALID, "view_board out of range");
@@ -452,12 +452,19 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     // threads (<= 100, e.g. 8 cameras with one constant pose: 98) or 4 x 4 tiles on 32 x 32 threads (<= 128)
     {
         auto lds_doubles = [](size_t NN, size_t TT, size_t NPD) { return NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 2 * NN + 3 * NPD; };
-        s->solve_variant = s->n_pad <= 64 ? 0 : (P.n_act <= 100 ? 1 : 2);
+        s->solve_variant = s->n_pad <= 64 ? 0 : s->n_pad > 16 * kMaxCamLds ? 3 : (P.n_act <= 100 ? 1 : 2);
         s->lds_solve = sizeof(double) * (s->solve_variant == 0 ? lds_doubles(64, 4, 64) : s->solve_variant == 1 ? lds_doubles(100, 4, 128) : lds_doubles(128, 4, 128));
+        if (s->solve_variant == 3) {
+            // rigs of 9..32 cameras: the compact system (+ rhs row) lives in global memory
+            const int NN = (P.n_act + 15) & ~15;
+            s->lds_solve = solve_big_lds_bytes(NN, s->n_pad);
+            if ((rc = dev_alloc(s, &S.Abig, (size_t)(NN + 4) * NN + 16))) return rc;
+        }
     }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     if (s->lds_solve > 64 * 1024) {
         if (s->solve_variant == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<4, 25, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
+        else if (s->solve_variant == 3) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
         else HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<4, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -564,7 +571,8 @@ static int enqueue_iteration(tscm_solver *s)
     if (s->comm) NCCL_TRY(ncclAllReduce(S.T, S.T, (size_t)P.n_pad * P.n_pad, ncclDouble, ncclSum, s->comm->comm, s->stream));
     if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
     else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
-    else hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
+    else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
+    else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
     if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
     return enqueue_eval(s, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
