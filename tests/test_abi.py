@@ -59,7 +59,7 @@ def test_argument_validation_happens_before_device_use():
     assert lib.lib().tscm_solver_create(C.byref(cp), 0, C.byref(h)) == -1
     assert b"view_board" in lib.lib().tscm_last_error()
     big = synth.make_problem(4, 2, 3)
-    big.n_cameras = 9
+    big.n_cameras = 33                       # 9..32 cameras are served by k_solve_reduced_big
     cp = lib.c_problem(big)
     assert lib.lib().tscm_solver_create(C.byref(cp), 0, C.byref(h)) in (-1, -5)
 

@@ -132,7 +132,7 @@ struct DevState {
     double *L, *z, *D2, *Y;
     double *pairpart, *T;
     double *yhat;
-    double *Abig;                      // [(N + 4)][N] compact reduced system + rhs row, rigs of more than kMaxCamLds cameras only
+    double *Abig;                      // compact reduced system + rhs row in 16x16 blocks, rigs of more than kMaxCamLds cameras only
     double *bs_part, *st_part;
     int n_bs_blocks, n_st_blocks;
     Ctrl *ctrl;
@@ -949,7 +949,10 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
     __syncthreads();
     if (slice == 0) {
         const int mi = P.bid_mi[bid], mj = P.bid_mj[bid];
-        S.T[(size_t)(mi * 16 + (entry >> 4)) * P.n_pad + mj * 16 + (entry & 15)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const double v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        S.T[(size_t)(mi * 16 + (entry >> 4)) * P.n_pad + mj * 16 + (entry & 15)] = v;
+        // rigs of more than kMaxCamLds cameras: k_solve_reduced_big reads T row-wise, so the lower blocks are filled in too
+        if (P.n_pad > 16 * kMaxCamLds && mi != mj) S.T[(size_t)(mj * 16 + (entry & 15)) * P.n_pad + mi * 16 + (entry >> 4)] = v;
     }
 }
 
@@ -1254,32 +1257,56 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
 }
 
 // ---------------------------------------------------------------------------------------------
-// Reduced camera system of rigs with more than kMaxCamLds cameras (up to kMaxCam: 496 free columns): the
+// Reduced camera system of rigs with more than kMaxCamLds cameras (up to kMaxCam: 410 free columns): the
 // compact system no longer fits registers + LDS, so ONE 1024-thread workgroup runs a blocked right-looking
-// Cholesky (16-column panels) on the matrix in global memory (S.Abig, L2-resident: <= 2 MB).  The right-hand
+// Cholesky (16-column panels) on the matrix in global memory (S.Abig, L2-resident: <= 1.4 MB).  The right-hand
 // side rides along as row N of the matrix, so the forward substitution w = L^{-1} b falls out of the panel
-// solves and trailing updates.  Per panel: wave 0 factors the 16x16 diagonal block in LDS; one thread per row
-// solves its panel row (and parks it, transposed, in LDS); 4x4 register tiles apply the rank-16 update.
+// solves and trailing updates.
+//   * The CURRENT panel (diagonal block + rows below, transposed) lives in LDS: wave 0 factors the 16x16
+//     diagonal block, one thread per row solves its panel row in place, and the 4x4 register tiles of the
+//     rank-16 update write the columns of the NEXT panel into the other LDS buffer -- no global-memory round
+//     trip sits on the panel-to-panel critical path.
+//   * Every 4x4 tile of the trailing matrix is owned by the same thread for the whole factorisation (absolute
+//     tile index modulo the 32 x 32 thread grid), so its read-modify-write sequence in global memory is
+//     thread-private and the per-panel barriers only order LDS.
+//   * Back-substitution: the rows of L a panel needs do not depend on the solution, so they are prefetched one
+//     panel ahead of the 16 x 16 triangular solve.
 // Same arithmetic as k_solve_reduced up to the summation order inside the updates.
-// grid 1 x 1024, dynamic LDS  16*(N+4) + 16*17 + 3*N + 3*n_pad doubles + N ints.
+// grid 1 x 1024, dynamic LDS solve_big_lds_bytes(N, n_pad).
 // ---------------------------------------------------------------------------------------------
 constexpr int kBigNT = 1024;
+constexpr int kBigBatch = 4;        // blocks of one block row in flight per trip of the trailing update
 __host__ __device__ inline size_t solve_big_lds_bytes(int N, int n_pad)
 {
-    return sizeof(double) * ((size_t)16 * (N + 4) + 16 * 17 + 3 * (size_t)N + 3 * (size_t)n_pad) + sizeof(int) * (size_t)N + (size_t)n_pad;
+    return sizeof(double) * ((size_t)2 * 16 * (N + 16) + 16 * 17 + 2 * (size_t)N + 16 + 3 * (size_t)n_pad) + sizeof(int) * (size_t)N + (size_t)n_pad;
 }
+// Storage of the big reduced system: packed lower triangle of 16x16 blocks, each block in the register layout of the
+// fp64 MFMA accumulator (lane = col + 16 * (row & 3) holds rows (row & 3) + 4 g, g = 0..3, as four consecutive doubles):
+// the trailing update moves a block with ONE 32-byte load and store per lane.
+__device__ __forceinline__ size_t big_block(int I, int J) { return ((size_t)(I * (I + 1) / 2 + J)) << 8; }
+__device__ __forceinline__ size_t big_idx(int r, int c)
+{
+    return big_block(r >> 4, c >> 4) + (size_t)((((c & 15) + 16 * (r & 3)) << 2) + ((r & 15) >> 2));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// barrier that orders LDS only (global loads stay in flight across it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevState S)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    extern __shared__ __attribute__((aligned(32))) double lds[];
     const int n = P.n_pad, na = P.n_act;
     const int N = (na + 15) & ~15, NP = N >> 4;     // compact columns rounded up to whole panels (identity padding)
-    const int XP = N + 4;                           // pitch of the transposed panel copy
-    double *Xt = lds;                 // [16][XP] panel rows k0+16 .. N (the rhs row), transposed
-    double *Ld = Xt + 16 * XP;        // [16][17] diagonal block
+    const int XP = N + 16;                          // pitch of the transposed panel buffers (rhs row + 15 scratch rows)
+    double *pbuf = lds;               // [2][16][XP] panel k: rows k0 .. N (the rhs row) at index row - k0, transposed
+    double *Ld = pbuf + 2 * 16 * XP;  // [16][17] diagonal block
     double *wv = Ld + 16 * 17;        // [N] w = L^{-1} b, then overwritten with y
     double *idg = wv + N;             // [N] 1 / L_kk
-    double *yk = idg + N;             // [N] (only [16] used per panel)
-    double *yv = yk + N;              // [n_pad] solution by padded column
+    double *yk = idg + N;             // [16] solution of the current panel
+    double *yv = yk + 16;             // [n_pad] solution by padded column
     double *s_sc = yv + n;            // [n_pad]
     double *s_yh = s_sc + n;          // [n_pad]
     int *s_map = reinterpret_cast<int *>(s_yh + n);                         // [N]
@@ -1292,63 +1319,95 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     const double *H = S.H[cur];
-    double *A = S.Abig;               // [(N + 1)][N], row N = rhs
+    double *A = S.Abig;               // packed lower triangle of 16x16 blocks (big_idx), block row NP: the rhs row + scratch
     for (int i = tid; i < n; i += kBigNT) { s_sc[i] = S.s_c[i]; s_act[i] = P.col_active[i]; yv[i] = 0.0; }
     for (int i = tid; i < N; i += kBigNT) s_map[i] = i < na ? P.act_map[i] : -1;
     if (tid == 0) s_fail = S.ctrl->lin_fail;
     __syncthreads();
-    // ---- build the lower triangle and the rhs row --------------------------------------------------
-    for (int r = wave; r <= N; r += kBigNT / 64) {
-        const int i = r < N ? s_map[r] : -1;
-        for (int c = lane; c < N && (c <= r); c += 64) {
+    // ---- build the lower triangle and the rhs row; the first panel goes straight to LDS -------------
+    // wave w owns rows w, w + 16, ...; 16 rows are in flight per trip (one memory round trip per 16 x 64 entries),
+    // lanes run along the columns: T (both triangles filled in by k_T_reduce) and A are read / written row-wise
+#ifdef TSCM_BIG_PROFILE
+    long long tp0 = wall_clock64(), tp_diag = 0, tp_solve = 0, tp_upd = 0;
+#endif
+    for (int kb = 0; wave + 16 * kb <= N; kb += 16) {
+        const int rmax = min(N, wave + 16 * (kb + 15));
+        for (int c = lane; c <= rmax && c < N; c += 64) {
             const int j = s_map[c];
-            double v;
-            if (r == N) {
-                v = 0.0;
-                if (j >= 0) { const int mj = j >> 4, b = j & 15; v = s_sc[j] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)j * n + mj * 16 + kFR]); }
-            } else {
-                v = (r == c) ? 1.0 : 0.0;
-                if (i >= 0 && j >= 0) {
-                    const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
-                    const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
-                    const double t = (mi > mj) ? S.T[(size_t)j * n + i] : S.T[(size_t)i * n + j];
-                    v = s_sc[i] * s_sc[j] * (h - t);
-                    if (i == j) v += fmin(fmax(s_sc[i] * s_sc[i] * h, dmin), dmax) / radius;
+            const int mj = j >> 4, bj = j & 15;
+            const double scj = j >= 0 ? s_sc[j] : 0.0;
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = wave + 16 * (kb + u);
+                v[u] = (r == c) ? 1.0 : 0.0;
+                if (r > N || c > r) continue;
+                if (r == N) {
+                    v[u] = j >= 0 ? scj * (H[256 * mj + bj * 16 + kFR] - S.T[(size_t)j * n + mj * 16 + kFR]) : 0.0;
+                } else {
+                    const int i = s_map[r];
+                    if (i >= 0 && j >= 0) {
+                        const int mi = i >> 4, ai = i & 15;
+                        const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
+                        double t = s_sc[i] * scj * (h - S.T[(size_t)i * n + j]);
+                        if (i == j) t += fmin(fmax(scj * scj * h, dmin), dmax) / radius;
+                        v[u] = t;
+                    }
                 }
             }
-            A[(size_t)r * N + c] = v;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = wave + 16 * (kb + u);
+                if (r > N || c > r) continue;
+                if (c < 16) pbuf[c * XP + r] = v[u];
+                else A[big_idx(r, c)] = v[u];
+            }
         }
     }
     __syncthreads();
+#ifdef TSCM_BIG_PROFILE
+    long long tp1 = wall_clock64();
+#endif
     // ---- factorisation -------------------------------------------------------------------------------
     for (int tk = 0; tk < NP; ++tk) {
         const int k0 = tk * 16, m0 = k0 + 16;
+        double *pc = pbuf + (tk & 1) * (16 * XP);            // this panel (index row - k0)
+        double *pn = pbuf + ((tk & 1) ^ 1) * (16 * XP);      // next panel (index row - m0)
+#ifdef TSCM_BIG_PROFILE
+        const long long q0 = wall_clock64();
+#endif
         if (wave == 0) {
-            for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; Ld[r * 17 + c] = c <= r ? A[(size_t)(k0 + r) * N + k0 + c] : 0.0; }
-            wave_lds_fence();
+            // Cholesky of the 16x16 diagonal block in REGISTERS: lane r holds row r, the pivot and the column entries
+            // travel through v_readlane (no LDS hand-off on the column-to-column dependent chain)
+            const int r = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = pc[c * XP + r];          // entries right of the diagonal are never used
+#pragma unroll
             for (int c = 0; c < 16; ++c) {
-                double d = Ld[c * 17 + c];
+                double d = readlane_f64(a[c], c);
                 if (!(d > 0.0)) { d = 1.0; if (lane == 0) s_fail = 1; }
                 const double isd = fast_rsqrt(d);
-                wave_lds_fence();
-                if (lane < 16 && lane > c) Ld[lane * 17 + c] *= isd;
-                if (lane == c) { Ld[c * 17 + c] = d * isd; idg[k0 + c] = isd; }
-                wave_lds_fence();
-                for (int e = lane; e < 256; e += 64) {
-                    const int r = e >> 4, q = e & 15;
-                    if (q > c && r >= q) Ld[r * 17 + q] -= Ld[r * 17 + c] * Ld[q * 17 + c];
-                }
-                wave_lds_fence();
+                const double l = a[c] * isd;                             // lane c: d / sqrt(d); lanes below: L[r][c]
+                a[c] = l;
+                if (lane == c) idg[k0 + c] = isd;
+#pragma unroll
+                for (int q = c + 1; q < 16; ++q) a[q] -= l * readlane_f64(l, q);
             }
-            for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; if (c <= r) A[(size_t)(k0 + r) * N + k0 + c] = Ld[r * 17 + c]; }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) if (c <= r) { Ld[r * 17 + c] = a[c]; A[big_idx(k0 + r, k0 + c)] = a[c]; }
+            }
         }
-        __syncthreads();
-        // panel rows m0 .. N: x = a L_kk^{-T}, one thread per row
+        lds_barrier();
+#ifdef TSCM_BIG_PROFILE
+        const long long q1 = wall_clock64();
+#endif
+        // panel rows m0 .. N: x = a L_kk^{-T}, one thread per row, in place in LDS (+ the final L row to global)
         for (int r = m0 + tid; r <= N; r += kBigNT) {
-            double *row = A + (size_t)r * N + k0;
             double x[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = row[c];
+            for (int c = 0; c < 16; ++c) x[c] = pc[c * XP + (r - k0)];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 double v = x[c];
@@ -1357,50 +1416,88 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
                 x[c] = v * idg[k0 + c];
             }
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { row[c] = x[c]; Xt[c * XP + (r - m0)] = x[c]; }
+            for (int c = 0; c < 16; ++c) { A[big_idx(r, k0 + c)] = x[c]; pc[c * XP + (r - k0)] = x[c]; }
         }
-        __syncthreads();
-        // trailing update A[i][j] -= sum_c X[i][c] X[j][c],  m0 <= j <= i <= N (j < N), 4x4 tiles
+        lds_barrier();
+#ifdef TSCM_BIG_PROFILE
+        const long long q2 = wall_clock64();
+#endif
+        // trailing update A_IJ -= X_I X_J^T on 16x16 blocks (four v_mfma_f64_16x16x4 each); block (I, J) belongs to
+        // wave (I % 4, J % 4) for the whole factorisation; block row NP is the rhs row (rows past N: scratch).
+        // kBigBatch blocks of a block row are in flight per trip; the blocks of the next panel's columns land in LDS.
         {
-            const int nb = (N - m0) >> 2, nr = nb + 1;         // column tiles; row tiles (the last holds only the rhs row)
-            const int ty = tid >> 5, tx = tid & 31;
-            for (int a = ty; a < nr; a += 32) {
-                for (int b = tx; b <= a && b < nb; b += 32) {
-                    double acc[4][4];
+            const int col = lane & 15, kq = lane >> 4;
+            const int Tb = tk + 1;
+            for (int I = Tb + (((wave >> 2) - Tb) & 3); I <= NP; I += 4) {
+                double xa[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int t = 0; t < 4; ++t) xa[t] = -pc[(4 * t + kq) * XP + (16 * I - k0) + col];
+                for (int J0 = Tb + (((wave & 3) - Tb) & 3); J0 <= I && J0 < NP; J0 += 4 * kBigBatch) {
+                    d4 acc[kBigBatch];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-#pragma unroll 4
-                    for (int q = 0; q < 16; ++q) {
-                        const d4 xi = *reinterpret_cast<const d4 *>(Xt + q * XP + 4 * a);
-                        const d4 xj = *reinterpret_cast<const d4 *>(Xt + q * XP + 4 * b);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[r][c] += xi[r] * xj[c];
+                    for (int u = 0; u < kBigBatch; ++u) {
+                        const int J = J0 + 4 * u;
+                        const int Jc = (J <= I && J < NP) ? J : J0;        // past the end: a harmless duplicate of the first block
+                        acc[u] = *reinterpret_cast<const d4 *>(A + big_block(I, Jc) + 4 * lane);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = m0 + 4 * a + r;
-                        if (i > N) continue;
-                        d4 *dst = reinterpret_cast<d4 *>(A + (size_t)i * N + m0 + 4 * b);
-                        d4 v = *dst;
-                        v[0] -= acc[r][0]; v[1] -= acc[r][1]; v[2] -= acc[r][2]; v[3] -= acc[r][3];
-                        *dst = v;
+                    for (int u = 0; u < kBigBatch; ++u) {
+                        const int J = J0 + 4 * u;
+                        if (!(J <= I && J < NP)) continue;                 // wave-uniform
+                        double xb[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) xb[t] = pc[(4 * t + kq) * XP + (16 * J - k0) + col];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t], xb[t], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBigBatch; ++u) {
+                        const int J = J0 + 4 * u;
+                        if (!(J <= I && J < NP)) continue;
+                        if (J == Tb) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) pn[col * XP + 16 * (I - Tb) + kq + 4 * g] = acc[u][g];
+                        } else {
+                            *reinterpret_cast<d4 *>(A + big_block(I, J) + 4 * lane) = acc[u];
+                        }
                     }
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+#ifdef TSCM_BIG_PROFILE
+        { const long long q3 = wall_clock64(); tp_diag += q1 - q0; tp_solve += q2 - q1; tp_upd += q3 - q2; }
+#endif
     }
+    __syncthreads();
+#ifdef TSCM_BIG_PROFILE
+    long long tp2 = wall_clock64();
+#endif
     // ---- back-substitution L^T y = w (w = row N of the factor) -------------------------------------
-    for (int i = tid; i < N; i += kBigNT) wv[i] = A[(size_t)N * N + i];
+    for (int i = tid; i < N; i += kBigNT) wv[i] = A[big_idx(N, i)];
+    // rows of L for the first (= last) panel; thread i keeps L[k0 + c][i], wave 0 also the diagonal block
+    double lrow[16], ldg[4];
+    {
+        const int k0 = (NP - 1) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lrow[c] = (NP > 0 && tid < k0) ? A[big_idx(k0 + c, tid)] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u, r = e >> 4, c = e & 15; ldg[u] = (NP > 0 && wave == 0 && c <= r) ? A[big_idx(k0 + r, k0 + c)] : 0.0; }
+    }
     __syncthreads();
     for (int tk = NP - 1; tk >= 0; --tk) {
         const int k0 = tk * 16;
+        double lnext[16], dnext[4];
+        {
+            const int kn = k0 - 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lnext[c] = (tk > 0 && tid < kn) ? A[big_idx(kn + c, tid)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u, r = e >> 4, c = e & 15; dnext[u] = (tk > 0 && wave == 0 && c <= r) ? A[big_idx(kn + r, kn + c)] : 0.0; }
+        }
         if (wave == 0) {
-            for (int e = lane; e < 256; e += 64) { const int r = e >> 4, c = e & 15; Ld[r * 17 + c] = c <= r ? A[(size_t)(k0 + r) * N + k0 + c] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u; Ld[(e >> 4) * 17 + (e & 15)] = ldg[u]; }
             wave_lds_fence();
             if (lane == 0) {
                 double y[16];
@@ -1415,18 +1512,29 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
                 for (int c = 0; c < 16; ++c) { yk[c] = y[c]; wv[k0 + c] = y[c]; }
             }
         }
-        __syncthreads();
-        for (int i = tid; i < k0; i += kBigNT) {
-            double v = wv[i];
+        lds_barrier();
+        if (tid < k0) {
+            double v = wv[tid];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) v -= A[(size_t)(k0 + c) * N + i] * yk[c];
-            wv[i] = v;
+            for (int c = 0; c < 16; ++c) v -= lrow[c] * yk[c];
+            wv[tid] = v;
         }
-        __syncthreads();
+        lds_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lrow[c] = lnext[c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ldg[u] = dnext[u];
     }
     for (int i = tid; i < na; i += kBigNT) yv[s_map[i]] = wv[i];          // back to padded columns
     __syncthreads();
+#ifdef TSCM_BIG_PROFILE
+    long long tp3 = wall_clock64();
+#endif
     reduced_solution_tail<kBigNT>(P, S, cur, H, s_fail, yv, s_sc, s_yh, s_act, sred);
+#ifdef TSCM_BIG_PROFILE
+    if (tid == 0) printf("big solve N=%d  build %lld  factor %lld (diag %lld solve %lld update %lld)  backsub %lld  tail %lld  [10 ns ticks]\n", N,
+                         tp1 - tp0, tp2 - tp1, tp_diag, tp_solve, tp_upd, tp3 - tp2, wall_clock64() - tp3);
+#endif
 }
 
 // back-substitution of the board steps (SchurEliminator::BackSubstitute), 16 lanes per board:

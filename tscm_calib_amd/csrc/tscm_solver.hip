@@ -458,7 +458,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
             // rigs of 9..32 cameras: the compact system (+ rhs row) lives in global memory
             const int NN = (P.n_act + 15) & ~15;
             s->lds_solve = solve_big_lds_bytes(NN, s->n_pad);
-            if ((rc = dev_alloc(s, &S.Abig, (size_t)(NN + 4) * NN + 16))) return rc;
+            if ((rc = dev_alloc(s, &S.Abig, (size_t)256 * (NN / 16 + 1) * (NN / 16 + 2) / 2))) return rc;      // packed lower triangle of 16x16 blocks, incl. the rhs block row
         }
     }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
