@@ -151,6 +151,9 @@ void tscm_default_options(tscm_options *opt, int mono);
  *                     (TS.cpp:278, multi_calib.cpp:216).  Reads the initial parameters
  *                     from the problem's cam_rt / intr / board_rt host arrays and
  *                     overwrites them with the result, like Ceres does.
+ * Shapes served (anything else: TSCM_E_UNSUPPORTED, nothing is approximated): up to 32 cameras (1..8: reduced
+ * system solved in registers/LDS, 9..32: blocked factorisation in global memory), any board shape whose corner
+ * list fits the 160 KiB LDS tile (several thousand corners), up to 3.7 M views / 536 M corners per GPU.
  */
 int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
 int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU */
