@@ -216,3 +216,16 @@ def test_cli_from_corner_file_to_yaml(hip_device, tmp_path):
     assert np.max(np.abs(Twc[:, :, 3] - gt[:, 3:])) < 6.0                                 # mm
     assert np.max(np.abs(Twc[:, :, :3] - synth.rodrigues(gt[:, :3]))) < 6e-3
     assert np.max(np.abs(intr[:, 2:4] - p.meta["gt_intr"][:, 2:4])) < 1.0                 # principal points, px
+
+
+@pytest.mark.parametrize("C", [12, 20, 32])
+def test_rig_init_and_calibrate_with_many_cameras(hip_device, C):
+    """MultiCalib with more than 8 cameras: constructor (rig init) against the oracle, then calibrate()."""
+    from tscm_calib_amd import api
+    p = synth.make_problem(C, 6, 600 + C)
+    inp = synth.make_rig_input(p)
+    g = rig.rig_init(inp, hip_device)
+    _compare(inp, g, orc.rig_init(inp))
+    q = rig.problem_from_rig(inp, g)
+    s = api.calibrate(q, hip_device)
+    assert s["termination_type"] == 0 and s["rmse"] < 0.25

@@ -76,5 +76,12 @@ for i, (c, r) in enumerate(shapes):
     for C in (2, 3, 5):
         check(f"rig   C={C} {c}x{r}", rig_case(C, c, r, 70 + i))
     check(f"init  {c}x{r}", init_case(c, r, 90 + i))
+for (c, r) in [(25, 20), (40, 30)]:
+    check(f"solve C=2 {c}x{r}", solve_case(2, c, r, 300 + c))
+    check(f"solve C=1 {c}x{r}", solve_case(1, c, r, 310 + c))
+    check(f"rig   C=3 {c}x{r}", rig_case(3, c, r, 320 + c))
+    check(f"init  {c}x{r}", init_case(c, r, 330 + c))
+for C in (9, 12, 20):
+    check(f"rig   C={C} 9x6", rig_case(C, 9, 6, 400 + C))
 print("failures:", fails)
 sys.exit(1 if fails else 0)

@@ -246,7 +246,7 @@ __global__ void k_rig_hyp_reduce(const double *partial, int J, int ksplit, doubl
     err[j] = e;
 }
 
-constexpr int kRigMaxCam = 16;
+constexpr int kRigMaxCam = 32;      // same limit as the solver (tscm_kernels.h: kMaxCam)
 
 // multi_calib.cpp:90-151, one thread per board
 __global__ void k_rig_boards(int C, int B, int n, const unsigned char *has, const double *pose, const double *pu, const double *pv,
@@ -325,7 +325,7 @@ extern "C" int tscm_rig_init(const tscm_rig_input *in, int device, tscm_rig_resu
     if (!in || !out) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
     const int C = in->n_cameras, B = in->n_boards, n = in->n_points;
     if (C < 1 || B < 0 || n < 1) return tscm_set_error(TSCM_E_INVALID, "bad rig dimensions");
-    if (C > kRigMaxCam) return tscm_set_error(TSCM_E_UNSUPPORTED, "more than 16 cameras");
+    if (C > kRigMaxCam) return tscm_set_error(TSCM_E_UNSUPPORTED, "more than 32 cameras");
     if (!in->worlds || !in->intr || !in->has || !in->Rt || !in->pix_u || !in->pix_v) return tscm_set_error(TSCM_E_INVALID, "NULL input array");
     if (!out->cam_R || !out->cam_t || !out->cam_rt || !out->board_R || !out->board_t || !out->board_rt || !out->board_initial) return tscm_set_error(TSCM_E_INVALID, "NULL output array");
     int ndev = 0;
