@@ -937,15 +937,23 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
     const int cb = P.bid_part_ptr[bid], ce = P.bid_part_ptr[bid + 1];
     const int per = (ce - cb + 3) >> 2;
     const int b0 = cb + slice * per, b1 = min(ce, b0 + per);
-    double a0 = 0.0, a1 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     int c = b0;
-    // the partial tiles of one block are stored contiguously: [bid_part_ptr[bid], bid_part_ptr[bid+1])
-    for (; c + 1 < b1; c += 2) {
-        a0 += S.pairpart[(size_t)256 * c + entry];
-        a1 += S.pairpart[(size_t)256 * (c + 1) + entry];
+    // the partial tiles of one block are stored contiguously: [bid_part_ptr[bid], bid_part_ptr[bid+1]);
+    // eight loads in flight per thread (mono problems: one block, hundreds of partial tiles -> a latency chain)
+    const double *src = S.pairpart + entry;
+    for (; c + 7 < b1; c += 8) {
+        a0 += src[(size_t)256 * c];       a1 += src[(size_t)256 * (c + 1)];
+        a2 += src[(size_t)256 * (c + 2)]; a3 += src[(size_t)256 * (c + 3)];
+        a4 += src[(size_t)256 * (c + 4)]; a5 += src[(size_t)256 * (c + 5)];
+        a6 += src[(size_t)256 * (c + 6)]; a7 += src[(size_t)256 * (c + 7)];
     }
-    if (c < b1) a0 += S.pairpart[(size_t)256 * c + entry];
-    red[slice][e] = a0 + a1;
+    for (; c + 1 < b1; c += 2) {
+        a0 += src[(size_t)256 * c];
+        a1 += src[(size_t)256 * (c + 1)];
+    }
+    if (c < b1) a0 += src[(size_t)256 * c];
+    red[slice][e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     __syncthreads();
     if (slice == 0) {
         const int mi = P.bid_mi[bid], mj = P.bid_mj[bid];
