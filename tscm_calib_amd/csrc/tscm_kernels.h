@@ -557,19 +557,19 @@ __device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int bl
     const int per = (n + kCamG1 - 1) / kCamG1;
     const int b = cb + g * per, e = min(ce, b + per);
     const int t = threadIdx.x;
-    for (int half = 0; half < 2; ++half) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        const double *src = S.campart + 256 * half + t;
-        int c = b;
-        for (; c + 3 < e; c += 4) {
-            a0 += src[(size_t)512 * c];
-            a1 += src[(size_t)512 * (c + 1)];
-            a2 += src[(size_t)512 * (c + 2)];
-            a3 += src[(size_t)512 * (c + 3)];
-        }
-        for (; c < e; ++c) a0 += src[(size_t)512 * c];
-        S.campart2[(size_t)512 * blk + 256 * half + t] = (a0 + a1) + (a2 + a3);
+    // both halves (u-tile, v-tile) in one loop: eight loads in flight per trip
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    const double *src = S.campart + t;
+    int c = b;
+    for (; c + 3 < e; c += 4) {
+        a0 += src[(size_t)512 * c];           b0 += src[(size_t)512 * c + 256];
+        a1 += src[(size_t)512 * (c + 1)];     b1 += src[(size_t)512 * (c + 1) + 256];
+        a2 += src[(size_t)512 * (c + 2)];     b2 += src[(size_t)512 * (c + 2) + 256];
+        a3 += src[(size_t)512 * (c + 3)];     b3 += src[(size_t)512 * (c + 3) + 256];
     }
+    for (; c < e; ++c) { a0 += src[(size_t)512 * c]; b0 += src[(size_t)512 * c + 256]; }
+    S.campart2[(size_t)512 * blk + t] = (a0 + a1) + (a2 + a3);
+    S.campart2[(size_t)512 * blk + 256 + t] = (b0 + b1) + (b2 + b3);
 }
 
 // deterministic block reductions (256 threads)
