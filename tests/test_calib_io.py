@@ -99,3 +99,12 @@ def test_corner_list_errors(tmp_path):
     calib_io.write_corners(str(empty), np.zeros((2, 3), dtype=np.uint8), np.zeros((2, 3, 54)), np.zeros((2, 3, 54)), 9, 6, 45.0)
     d = calib_io.read_corners(str(empty))
     assert d["has"].shape == (2, 3) and not d["has"].any()
+
+
+def test_matrix_node_without_data_is_an_error_not_a_crash():
+    """Found by the sanitizer fuzzing: a cam node with rows/cols but no data: used to be copied from an empty vector."""
+    text = ("%YAML:1.0\n---\ncam0: !!opencv-matrix\n   rows: 1\n   cols: 9\n   dt: d\n"
+            "Twc0: !!opencv-matrix\n   rows: 3\n   cols: 4\n   dt: d\n   data: [ 1., 0., 0., 0., 0., 1., 0., 0., 0., 0., 1., 0. ]\n")
+    with pytest.raises(Exception) as e:
+        calib_io.parse_calib_yaml(text)
+    assert "camera 0" in str(e.value)

@@ -93,7 +93,7 @@ bool parse_yaml(const std::string &text, std::vector<YamlMatrix> &mats, std::str
             if (!parse_double(tok, v)) { err = "matrix " + cur->name + ": bad number '" + tok + "'"; return false; }
             cur->data.push_back(v);
         }
-        if ((int)cur->data.size() != cur->rows * cur->cols) { err = "matrix " + cur->name + ": data does not match rows x cols"; return false; }
+        if (cur->rows < 0 || cur->cols < 0 || (long long)cur->data.size() != (long long)cur->rows * cur->cols) { err = "matrix " + cur->name + ": data does not match rows x cols"; return false; }
         in_data = false; data_text.clear();
         return true;
     };
@@ -180,7 +180,8 @@ extern "C" int tscm_yaml_parse(const char *text, int max_cameras, int *n_cameras
         }
         if (!cam && !twc) break;
         if (!cam || !twc) return tscm_set_error(TSCM_E_INVALID, "calibration YAML: camera " + std::to_string(n) + " lacks cam or Twc");
-        if (cam->rows * cam->cols != 9 || twc->rows != 3 || twc->cols != 4) return tscm_set_error(TSCM_E_INVALID, "calibration YAML: camera " + std::to_string(n) + ": expected 1x9 and 3x4");
+        // (a matrix node without a data: entry parses, with an empty payload)
+        if (cam->data.size() != 9 || twc->data.size() != 12 || twc->rows != 3 || twc->cols != 4) return tscm_set_error(TSCM_E_INVALID, "calibration YAML: camera " + std::to_string(n) + ": expected 1x9 and 3x4");
         if (n < max_cameras) {
             if (intr) std::memcpy(intr + 9 * n, cam->data.data(), 9 * sizeof(double));
             if (Twc) std::memcpy(Twc + 12 * n, twc->data.data(), 12 * sizeof(double));
@@ -213,9 +214,10 @@ extern "C" void tscm_corners_free(tscm_corner_set *set)
 extern "C" int tscm_corners_write(const char *path, const tscm_corner_set *set)
 {
     if (!path || !set) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
-    const int C = set->n_cameras, B = set->n_boards, n = set->board_cols * set->board_rows;
-    if (C < 0 || B < 0 || set->board_cols < 1 || set->board_rows < 1 || ((size_t)C * B > 0 && (!set->has || !set->pix_u || !set->pix_v)))
+    const int C = set->n_cameras, B = set->n_boards;
+    if (C < 0 || B < 0 || set->board_cols < 1 || set->board_rows < 1 || set->board_cols > 4096 || set->board_rows > 4096 || ((size_t)C * B > 0 && (!set->has || !set->pix_u || !set->pix_v)))
         return tscm_set_error(TSCM_E_INVALID, "inconsistent corner set");
+    const int n = set->board_cols * set->board_rows;
     std::FILE *f = std::fopen(path, "w");
     if (!f) return tscm_set_error(TSCM_E_INVALID, std::string("cannot open ") + path + " for writing");
     std::fprintf(f, "TSCM-CORNERS 1\ncameras %d boards %d cols %d rows %d pitch %.17g image %d %d\n", C, B, set->board_cols, set->board_rows,
@@ -243,7 +245,8 @@ extern "C" int tscm_corners_read(const char *path, tscm_corner_set *set)
     if (std::fscanf(f, " cameras %d boards %d cols %d rows %d pitch %lf image %d %d", &set->n_cameras, &set->n_boards, &set->board_cols, &set->board_rows,
                     &set->pitch, &set->image_width, &set->image_height) != 7) return bail("bad header");
     const int C = set->n_cameras, B = set->n_boards;
-    if (C < 0 || B < 0 || set->board_cols < 1 || set->board_rows < 1 || (long long)C * B > (1LL << 28)) return bail("bad dimensions");
+    if (C < 0 || B < 0 || set->board_cols < 1 || set->board_rows < 1 || set->board_cols > 4096 || set->board_rows > 4096 || (long long)C * B > (1LL << 28)
+        || (long long)C * B * set->board_cols * set->board_rows > (1LL << 32)) return bail("bad dimensions");
     const int n = set->board_cols * set->board_rows;
     const size_t cb = (size_t)C * B;
     set->has = static_cast<unsigned char *>(std::calloc(cb ? cb : 1, 1));
