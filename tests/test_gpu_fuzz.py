@@ -59,3 +59,34 @@ def test_random_rig_three_iterations(hip_device, seed):
         assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-7 * b["trust_region_radius"]
     d = H.param_rel_err(pg, po)
     assert max(d.values()) < 1e-7, d
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_large_rig_three_iterations(hip_device, seed):
+    """7..14 cameras (register/LDS solver up to 8, k_solve_reduced_big beyond), boards seen by 1..C cameras (the
+    explicit pair-list Schur path), unseen boards, ragged views."""
+    rng = np.random.default_rng(7000 + seed)
+    C = int(rng.integers(7, 15))
+    if rng.integers(0, 2):
+        p = H.mixed_visibility_rig(seed=700 + seed, n_frames=int(rng.integers(2 * C, 5 * C)), n_cameras=C)
+        if rng.integers(0, 2):
+            p = H.rig_with_unseen_boards(p, extra=2)
+    else:
+        p = synth.make_problem(C, int(rng.integers(4, 10)), 700 + seed)
+    cnt = p.view_count.copy()
+    idx = rng.choice(p.n_views, size=max(1, p.n_views // 5), replace=False)
+    cnt[idx] = rng.integers(0, p.n_points + 1, size=idx.shape[0])
+    q = p.copy()
+    q.view_count[:] = cnt
+    q = q.normalised()
+    pg, po = q.copy().normalised(), q.copy().normalised()
+    with api.Solver(pg) as s:
+        gs = s.solve(max_num_iterations=3)
+    os_ = orc.solve(po, max_num_iterations=3)
+    assert gs["num_iterations"] == os_["num_iterations"]
+    for a, b in zip(gs["iterations"], os_["iterations"]):
+        assert a["step_is_successful"] == b["step_is_successful"] and a["step_is_valid"] == b["step_is_valid"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(b["cost"])
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(b["step_norm"], 1e-12)
+    d = H.param_rel_err(pg, po)
+    assert max(d.values()) < 1e-7, d
