@@ -119,6 +119,10 @@ struct DevProblem {
     const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
     const int *act_map;                // [n_pad] compact index -> padded column (first n_act entries)
     int n_act;
+    // the same map in closed form for the register/LDS solver (<= kMaxCamLds cameras): the free columns of camera q are
+    // compact [cam_pre[q], cam_pre[q + 1]) = padded cam_col0[q] + 0, 1, ...  (cam_pre[q] = n_act from q = C on).
+    // Kernel arguments: the solver computes its operand addresses without a dependent table load.
+    int cam_pre[9], cam_col0[8];
 };
 
 struct DevState {
@@ -1048,47 +1052,73 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     const int n = P.n_pad;            // <= N
     const int tid = threadIdx.x;
     const int ti = tid / G, tj = tid % G;
+    const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
+    // compact index -> padded column (-1 past the last free column), from kernel arguments only
+    auto cmap = [&](int ci) -> int {
+        int base = 0, c0 = P.cam_col0[0];
+#pragma unroll
+        for (int q = 1; q < kMaxCamLds; ++q) { const bool ge = ci >= P.cam_pre[q]; base = ge ? P.cam_pre[q] : base; c0 = ge ? P.cam_col0[q] : c0; }
+        return ci < P.n_act ? c0 + (ci - base) : -1;
+    };
+    // ---- operands of my tile (lower tiles only; the diagonal thread also owns its slice of the rhs) ----
+    // Every address below comes from kernel arguments, so the control block, the scalings, BOTH candidate H
+    // buffers (the current one is picked once the control block is here) and T travel in ONE memory round trip.
+    const bool mine = tj <= ti && ti < NP, diag = ti == tj && ti < NP;
+    int mi_[TS], mj_[TS];
+    double sci[TS], scj[TS], h0[TS][TS], h1[TS][TS], tt[TS][TS], g0[TS], g1[TS], tg[TS];
+#pragma unroll
+    for (int r = 0; r < TS; ++r) { mi_[r] = mine ? cmap(ti * TS + r) : -1; mj_[r] = mine ? cmap(tj * TS + r) : -1; }
+#pragma unroll
+    for (int r = 0; r < TS; ++r) { sci[r] = mi_[r] >= 0 ? S.s_c[mi_[r]] : 0.0; scj[r] = mj_[r] >= 0 ? S.s_c[mj_[r]] : 0.0; }
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {
+#pragma unroll
+        for (int c = 0; c < TS; ++c) {
+            const int i = mi_[r], j = mj_[c];
+            h0[r][c] = 0.0; h1[r][c] = 0.0; tt[r][c] = 0.0;
+            if (i >= 0 && j >= 0) {
+                const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
+                if (mi == mj) { h0[r][c] = S.H[0][256 * mi + ai * 16 + bj]; h1[r][c] = S.H[1][256 * mi + ai * 16 + bj]; }
+                // T holds the upper camera-pair blocks; (i, j) with mi > mj is block (mj, mi) transposed
+                tt[r][c] = (mi > mj) ? S.T[(size_t)j * n + i] : S.T[(size_t)i * n + j];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {
+        const int i = diag ? mi_[r] : -1;
+        g0[r] = 0.0; g1[r] = 0.0; tg[r] = 0.0;
+        if (i >= 0) { const int mj = i >> 4, b = i & 15; g0[r] = S.H[0][256 * mj + b * 16 + kFR]; g1[r] = S.H[1][256 * mj + b * 16 + kFR]; tg[r] = S.T[(size_t)i * n + mj * 16 + kFR]; }
+    }
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     const double *H = S.H[cur];
     const int ctrl_fail = S.ctrl->lin_fail;
-    __shared__ int s_map[N];          // compact index -> padded column, -1 past the last free column
     for (int i = tid; i < NPD; i += NT) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; yv[i] = 0.0; }
-    for (int i = tid; i < N; i += NT) s_map[i] = i < P.n_act ? P.act_map[i] : -1;
     if (ctrl_done) return;
     if (tid == 0) s_fail = ctrl_fail;
-    const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
-    __syncthreads();
-    // ---- build my tile (lower tiles only); the diagonal thread also owns its slice of the rhs ----
     double a[TS][TS], bd[TS];
-    if (tj <= ti && ti < NP) {
+    if (mine) {
 #pragma unroll
         for (int r = 0; r < TS; ++r) {
 #pragma unroll
             for (int c = 0; c < TS; ++c) {
                 const int ci = ti * TS + r, cj = tj * TS + c;
-                const int i = s_map[ci], j = s_map[cj];
+                const int i = mi_[r], j = mj_[c];
                 double v = (ci == cj) ? 1.0 : 0.0;
                 if (i >= 0 && j >= 0) {
-                    const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
-                    const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
-                    // T holds the upper camera-pair blocks; (i, j) with mi > mj is block (mj, mi) transposed
-                    const double t = (mi > mj) ? S.T[(size_t)j * n + i] : S.T[(size_t)i * n + j];
-                    v = s_sc[i] * s_sc[j] * (h - t);
-                    if (i == j) v += fmin(fmax(s_sc[i] * s_sc[i] * h, dmin), dmax) / radius;
+                    const double h = cur ? h1[r][c] : h0[r][c];
+                    v = sci[r] * scj[c] * (h - tt[r][c]);
+                    if (i == j) v += fmin(fmax(sci[r] * sci[r] * h, dmin), dmax) / radius;
                 }
                 a[r][c] = v;
             }
         }
     }
-    if (ti == tj && ti < NP) {
+    if (diag) {
 #pragma unroll
-        for (int r = 0; r < TS; ++r) {
-            const int i = s_map[ti * TS + r];
-            bd[r] = 0.0;
-            if (i >= 0) { const int mj = i >> 4, b = i & 15; bd[r] = s_sc[i] * (H[256 * mj + b * 16 + kFR] - S.T[(size_t)i * n + mj * 16 + kFR]); }
-        }
+        for (int r = 0; r < TS; ++r) bd[r] = mi_[r] >= 0 ? sci[r] * ((cur ? g1[r] : g0[r]) - tg[r]) : 0.0;
     }
     // ---- factorisation: ONE barrier per panel ------------------------------------------------------
     // before the barrier of panel tk: the column threads (ti > tk, tj == tk) publish their raw tiles,
@@ -1258,7 +1288,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? s_map[tid + 64 * q] : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
+        for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? cmap(tid + 64 * q) : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
     }
     __syncthreads();
     reduced_solution_tail<NT>(P, S, cur, H, s_fail, yv, s_sc, s_yh, s_act, sred);

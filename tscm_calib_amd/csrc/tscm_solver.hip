@@ -404,6 +404,25 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
         int n_act = 0;
         for (int i = 0; i < s->n_pad; ++i) if (col_active[i]) act_map[n_act++] = i;
         P.n_act = n_act;
+        // closed form of the same map for the register/LDS solver (kernel arguments, see DevProblem)
+        for (int q = 0; q < 9; ++q) P.cam_pre[q] = n_act;
+        for (int q = 0; q < 8; ++q) P.cam_col0[q] = 0;
+        if (C <= kMaxCamLds) {
+            int run = 0;
+            for (int m = 0; m < C; ++m) {
+                P.cam_pre[m] = run;
+                P.cam_col0[m] = 16 * m + (cam_const[m] ? 6 : 0);
+                if (cam_active[m]) run += cam_const[m] ? kFA - 6 : kFA;
+            }
+            // (host replica of the kernel's cmap(): must reproduce act_map exactly)
+            bool same = run == n_act;
+            for (int ci = 0; ci < n_act && same; ++ci) {
+                int base = 0, c0 = P.cam_col0[0];
+                for (int q = 1; q < kMaxCamLds; ++q) if (ci >= P.cam_pre[q]) { base = P.cam_pre[q]; c0 = P.cam_col0[q]; }
+                same = c0 + (ci - base) == act_map[ci];
+            }
+            if (!same) return fail(TSCM_E_UNSUPPORTED, "internal error: closed-form column map disagrees with the table");
+        }
         if ((rc = dev_upload(s, &P.act_map, act_map))) return rc;
     }
 
