@@ -969,47 +969,59 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
 }
 
 // Common end of the reduced-system solvers: yhat = S_c y (camera step = -yhat), the candidate camera parameters, and
-// the camera part of the model cost change / step norm.  yv: solution by padded column (LDS); s_sc, s_yh, s_act: LDS
-// arrays of n_pad entries; NT = workgroup size.  Every thread of the workgroup calls it.
-template <int NT>
-__device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const DevState &S, int cur, const double *H, int fail,
+// the camera part of the model cost change / step norm.  One thread per padded column (n_pad <= workgroup size in
+// every variant).  The global operands of the tail -- the column's parameter and its row of H -- do not depend on
+// the solution: tail_prefetch() issues their loads early (before the back-substitution where registers allow), so
+// the tail itself waits for no memory.
+struct TailOperands { double x, hg, hrow[kFA]; };
+__device__ __forceinline__ void tail_prefetch(const DevProblem &P, const DevState &S, int cur, const double *H, TailOperands &o)
+{
+    const int i = threadIdx.x;
+    o.x = 0.0; o.hg = 0.0;
+#pragma unroll
+    for (int b = 0; b < kFA; ++b) o.hrow[b] = 0.0;
+    if (i < P.n_pad) {
+        const int m = i >> 4, ai = i & 15;
+        if (ai < 6) o.x = S.cam_rt[cur][6 * m + ai];
+        else if (ai < 15) o.x = S.intr[cur][9 * m + (ai - 6)];
+        if (ai < kFA) {
+#pragma unroll
+            for (int b = 0; b < kFA; ++b) o.hrow[b] = H[256 * m + ai * 16 + b];
+            o.hg = H[256 * m + ai * 16 + kFR];
+        }
+    }
+}
+// yv: solution by padded column (LDS); s_sc, s_yh, s_act: LDS arrays of n_pad entries.  Every thread of the workgroup calls it.
+__device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const DevState &S, int cur, int fail, const TailOperands &o,
                                                       const double *yv, const double *s_sc, double *s_yh, const unsigned char *s_act, double *sred)
 {
-    const int n = P.n_pad, tid = threadIdx.x;
-    double model = 0.0, stepsq = 0.0;
-    for (int i = tid; i < n; i += NT) {
-        const int m = i >> 4, ai = i & 15;
+    const int n = P.n_pad, i = threadIdx.x;
+    const int m = i >> 4, ai = i & 15;
+    double model = 0.0, stepsq = 0.0, yh = 0.0;
+    if (i < n) {
         const bool act = s_act[i] && !fail;
-        const double yh = act ? s_sc[i] * yv[i] : 0.0;
+        yh = act ? s_sc[i] * yv[i] : 0.0;
         S.yhat[i] = yh;
         s_yh[i] = yh;
-        if (ai < 6) {
-            const double x = S.cam_rt[cur][6 * m + ai];
+        if (ai < kFA) {
+            const double x = o.x;
             const double xn = x + (-yh);
-            S.cam_rt[cur ^ 1][6 * m + ai] = xn;
-            const double d = x - xn; stepsq += d * d;
-        } else if (ai < kFA) {
-            const double x = S.intr[cur][9 * m + (ai - 6)];
-            const double xn = x + (-yh);
-            S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
-            const double d = x - xn; stepsq += d * d;
+            if (ai < 6) S.cam_rt[cur ^ 1][6 * m + ai] = xn; else S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
+            const double d = x - xn; stepsq = d * d;
         } else if (ai < 15) {
-            S.intr[cur ^ 1][9 * m + (ai - 6)] = S.intr[cur][9 * m + (ai - 6)];   // b, c are inert
+            S.intr[cur ^ 1][9 * m + (ai - 6)] = o.x;   // b, c are inert
         }
     }
     __syncthreads();
     // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
-    for (int i = tid; i < n; i += NT) {
-        const int m = i >> 4, ai = i & 15;
-        if (ai >= kFA) continue;
-        const double yi = s_yh[i];
-        if (yi == 0.0) continue;
+    if (i < n && ai < kFA && yh != 0.0) {
         double hy = 0.0;
-        for (int b = 0; b < kFA; ++b) hy += H[256 * m + ai * 16 + b] * s_yh[m * 16 + b];
-        model += yi * (H[256 * m + ai * 16 + kFR] - 0.5 * hy);
+#pragma unroll
+        for (int b = 0; b < kFA; ++b) hy += o.hrow[b] * s_yh[m * 16 + b];
+        model = yh * (o.hg - 0.5 * hy);
     }
     { double red[2] = { model, stepsq }, mdummy = 0.0; block_reduce256<2>(red, mdummy, sred); model = red[0]; stepsq = red[1]; }
-    if (tid == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
+    if (i == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1248,6 +1260,8 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
             for (int c = 0; c < TS; ++c) Lm[(ti * TS + r) * LD + tj * TS + c] = a[r][c];
     }
     __syncthreads();
+    TailOperands tail_ops;
+    tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
     if (tid < 64) {
         // blocked back-substitution, TS unknowns per step: all lanes solve the TS x TS upper-triangular
         // diagonal system redundantly (operands by broadcast), then lane i applies the TS columns to w[i]
@@ -1291,7 +1305,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? cmap(tid + 64 * q) : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
     }
     __syncthreads();
-    reduced_solution_tail<NT>(P, S, cur, H, s_fail, yv, s_sc, s_yh, s_act, sred);
+    reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1563,12 +1577,14 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 #pragma unroll
         for (int u = 0; u < 4; ++u) ldg[u] = dnext[u];
     }
+    TailOperands tail_ops;
+    tail_prefetch(P, S, cur, H, tail_ops);
     for (int i = tid; i < na; i += kBigNT) yv[s_map[i]] = wv[i];          // back to padded columns
     __syncthreads();
 #ifdef TSCM_BIG_PROFILE
     long long tp3 = wall_clock64();
 #endif
-    reduced_solution_tail<kBigNT>(P, S, cur, H, s_fail, yv, s_sc, s_yh, s_act, sred);
+    reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred);
 #ifdef TSCM_BIG_PROFILE
     if (tid == 0) printf("big solve N=%d  build %lld  factor %lld (diag %lld solve %lld update %lld)  backsub %lld  tail %lld  [10 ns ticks]\n", N,
                          tp1 - tp0, tp2 - tp1, tp_diag, tp_solve, tp_upd, tp3 - tp2, wall_clock64() - tp3);
