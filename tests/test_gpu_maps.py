@@ -83,3 +83,29 @@ def test_bad_descriptors_are_rejected(hip_device):
     d.out_stride = 32
     with pytest.raises(lib.TscmError):
         maps.build_maps([d], 64 * 64, hip_device)            # stride < width
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_table_geometries(hip_device, seed):
+    """Random widths (1..70), heights, row strides and (unaligned) offsets of many small tables in one launch:
+    exact tables bit-identical to the oracle, gaps between rows and tables untouched."""
+    rng = np.random.default_rng(4000 + seed)
+    descs, off = [], int(rng.integers(0, 7))
+    for k in range(int(rng.integers(3, 40))):
+        w, h = int(rng.integers(1, 71)), int(rng.integers(1, 10))
+        stride = w + int(rng.integers(0, 6))
+        intr = synth.CALIB_INTR[int(rng.integers(0, len(synth.CALIB_INTR)))].copy()
+        if rng.integers(0, 2):
+            intr[7:] = rng.uniform(-0.3, 0.3, 2)
+        f = float(rng.uniform(150.0, 400.0))
+        descs.append(maps.undistort_desc(intr, f, f * float(rng.uniform(0.9, 1.1)), w / 2.0, h / 2.0, w, h, out_offset=off, out_stride=stride))
+        off += stride * h + int(rng.integers(0, 5))
+    ox, oy = orc.build_maps(descs, off)
+    gx, gy, _ = maps.build_maps(descs, off, hip_device, exact=True)
+    assert np.array_equal(gx.view(np.uint32), ox.view(np.uint32))
+    assert np.array_equal(gy.view(np.uint32), oy.view(np.uint32))
+    fx_, fy_, _ = maps.build_maps(descs, off, hip_device, exact=False)
+    written = ox != 0.0
+    assert np.all(fx_[~written] == 0.0) and np.all(fy_[~written & (oy == 0.0)] == 0.0)
+    _check_fast(fx_, ox)
+    _check_fast(fy_, oy)
