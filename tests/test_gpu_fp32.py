@@ -67,3 +67,17 @@ def test_fp32_jacobian_ragged_views_and_big_boards(hip_device):
     # the first fp32-Jacobian gradient is the fp64 one to fp32 accuracy, also across the two tile passes
     g32, g64 = sg["iterations"][0]["gradient_max_norm"], so["iterations"][0]["gradient_max_norm"]
     assert abs(g32 - g64) < 1e-6 * g64
+
+
+@pytest.mark.parametrize("cols,rows", [(10, 6), (5, 4), (7, 5), (8, 8), (9, 7), (13, 5), (3, 3), (12, 9)])
+def test_fp32_tier_first_iterations_over_board_shapes(hip_device, cols, rows):
+    """Corner counts of every residue mod 8 through k_eval_gram_f32: the first LM iterations (well away from the
+    flat valley) track the fp64 oracle to the tier's 1e-3."""
+    p = synth.make_problem(4, 10, 500 + cols * rows, cols=cols, rows=rows, pitch=360.0 / max(cols, rows))
+    pg, po = p.copy().normalised(), p.copy().normalised()
+    sg = api.calibrate(pg, hip_device, jacobian_fp32=1, max_num_iterations=3)
+    so = orc.solve(po, max_num_iterations=3)
+    assert sg["num_iterations"] == so["num_iterations"]
+    for a, b in zip(sg["iterations"], so["iterations"]):
+        assert abs(a["cost"] - b["cost"]) <= 1e-3 * b["cost"]
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-3 * so["final_cost"]
