@@ -365,6 +365,33 @@ int tscm_corners_write(const char *path, const tscm_corner_set *set);
 int tscm_corners_read(const char *path, tscm_corner_set *set);
 void tscm_corners_free(tscm_corner_set *set);
 
+/* ------------------------------------------------------------------ corner candidates (first stage)
+ * tscm_detect_corners  = findCorner() up to and including its score filter (DetectCorner/findCorner.cpp:7-66:
+ *                        gradient angle / weight, secondDerivCornerMetric :103-142, nonMaximumSuppression(cxy + c45,
+ *                        4, 0.07, 5) :144-193, getOrientations(r = 10) :200-349, scoreCorners(radii 8, 12, 16)
+ *                        :391-490, removal of candidates with score < min_score (0.01 in the reference)), plus the
+ *                        quadratic sub-pixel fit of subPixelLocation (:492-541) for EVERY kept candidate (the
+ *                        reference applies it to the candidates the structure recovery assigned to a board; the fit
+ *                        of a candidate does not depend on that assignment).
+ * Input: 8-bit grey image (the reference converts BGR with cv::cvtColor first), `stride` bytes per row; sigma as in
+ * findCorner(img, sigma): even (cv::GaussianBlur needs the odd kernel size 7 sigma + 1), main.cpp:32 passes 4.
+ * Output order = the order the suppression finds the maxima (columns of cells left to right, cells top to bottom).
+ * The chessboard structure recovery (chessboardsFromCorners, DetectCorner/chessboard.cpp) consumes this list.
+ */
+typedef struct tscm_corner_candidates {
+    int n;                  /* candidates kept                                                     */
+    int n_maxima;           /* maxima of the corner metric before the score filter                 */
+    double *x, *y;          /* [n] pixel of the maximum (integral values; x = column, y = row)     */
+    double *v1, *v2;        /* [2n] the two edge directions (unit vectors; (0,0) if none found)    */
+    double *score;          /* [n]                                                                 */
+    double *sub;            /* [2n] sub-pixel position (x, y)                                      */
+    double seconds;         /* device time of the kernels                                          */
+} tscm_corner_candidates;
+
+int tscm_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, double min_score, int device,
+                        tscm_corner_candidates *out);
+void tscm_corner_candidates_free(tscm_corner_candidates *c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -367,3 +367,26 @@ def estimate_extrinsic(intr, pix_u, pix_v, count, worlds, board_w):
     k = lib().orc_estimate_extrinsic(_dp(intr), _dp(pix_u), _dp(pix_v), count.ctypes.data_as(C.POINTER(C.c_int)), V,
                                      _dp(worlds), n, board_w, _dp(Rt))
     return Rt, k
+
+
+def detect_corners(gray, sigma: int = 4, cap: int = 8192, planes: bool = False) -> dict:
+    """findCorner.cpp:7-46 (+ the sub-pixel fit of :84 for every candidate): candidates of a grey uint8 image in the
+    order the non-maximum suppression finds them."""
+    g = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = g.shape
+    px, py, score = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    v, sub = np.zeros((cap, 4)), np.zeros((cap, 2))
+    metric = np.zeros((h, w)) if planes else None
+    ixy = np.zeros((h, w)) if planes else None
+    f = lib().orc_detect_corners
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7
+    n = f(g.ctypes.data, w, h, w, sigma, cap, px.ctypes.data, py.ctypes.data, v.ctypes.data, score.ctypes.data, sub.ctypes.data,
+          metric.ctypes.data if planes else None, ixy.ctypes.data if planes else None)
+    if n < 0:
+        raise RuntimeError(f"orc_detect_corners failed ({n})")
+    m = min(n, cap)
+    out = dict(n=n, x=px[:m], y=py[:m], v1=v[:m, :2], v2=v[:m, 2:], score=score[:m], sub=sub[:m])
+    if planes:
+        out.update(metric=metric, ixy=ixy)
+    return out

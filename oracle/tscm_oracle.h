@@ -209,4 +209,19 @@ void orc_rectify_pair_rotation(const double *t1, const double *t2, double *R);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- corner candidates (tscm_oracle_corners.c; DetectCorner/findCorner.cpp) ---- */
+void orc_corner_gradients(const unsigned char *gray, int w, int h, int stride, double *angle, double *weight);
+void orc_corner_normalise(const unsigned char *gray, int w, int h, int stride, double *img);
+void orc_gaussian_kernel(int sigma, double *k);
+int orc_corner_metric(const double *I, int w, int h, int sigma, double *metric, double *Ixy);
+int orc_corner_nms(const double *img, int width, int height, int n, double tau, int margin, int cap, double *px, double *py);
+void orc_corner_orientation(const double *angle, const double *weight, int width, int height, int cu, int cv, int r, double *v);
+double orc_corner_correlation_score(const double *img, const double *weight, int width, int u, int v, int r, const double *vv);
+double orc_corner_score(const double *img, const double *weight, int width, int height, double px, double py, const double *vv);
+void orc_subpixel_operator(double *X);
+void orc_corner_subpixel(const double *Ixy, int width, const double *X, double px, double py, double *out);
+int orc_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, int cap,
+                       double *px, double *py, double *v, double *score, double *sub, double *metric_out, double *ixy_out);
+
 #endif

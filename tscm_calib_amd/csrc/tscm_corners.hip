@@ -1,0 +1,515 @@
+// tscm_corners.hip -- chessboard-corner candidates of a grey image on the GPU (first stage):
+// findCorner() up to and including the score filter (DetectCorner/findCorner.cpp:7-66) plus the sub-pixel fit
+// of subPixelLocation (:492-541) for every candidate.  The chessboard structure recovery
+// (DetectCorner/chessboard.cpp) consumes exactly this output and is not part of this file.
+//
+//   k_corner_gradients   3x3 derivative filters on the raw grey values -> edge angle, gradient magnitude; min / max
+//   k_gauss_rows/_cols   separable Gaussian (7 sigma + 1 taps) of the normalised image, BORDER_REFLECT_101
+//   k_corner_metric      first and second derivatives fused: cxy + c45 (suppression input) and Ixy (sub-pixel fit)
+//   k_nms_cells          one thread per (n + 1)^2 cell of nonMaximumSuppression, k_nms_compact keeps the cell order
+//   k_corner_describe    one wave per candidate: orientation histogram + mode seeking, three-radius correlation
+//                        score, quadratic sub-pixel fit
+// Everything per pixel is HBM-bound fp64 streaming.  The arithmetic follows the oracle operation by operation (no
+// FMA contraction in this file); transcendental constants (Gaussian taps, normpdf tables, bin directions) are
+// computed on the host with the C library the CPU path would use, so the image planes are bit-identical to the
+// oracle's except for atan2 (device libm, <= 2 ulp; the exact cases du = 0, dv = 0, |du| = |dv| -- which sit on
+// histogram-bin boundaries -- use host constants) and the per-candidate sums (wave-parallel order).
+#pragma clang fp contract(off)
+#include "tscm/tscm.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int tscm_set_error(int code, const std::string &msg);   // tscm_solver.hip
+
+#define CRN_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return tscm_set_error(TSCM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+constexpr int kNmsN = 4, kNmsMargin = 5, kOrientR = 10, kBins = 32;
+constexpr double kNmsTau = 0.07;
+constexpr double kPi = 3.14159265358979323846;
+
+struct AtanConsts { double pp, pn, np, nn, p0, n0, zn; };      // atan2(1,1), (1,-1), (-1,1), (-1,-1), (1,0), (-1,0), (0,-1)
+
+struct DescribeTables {
+    double smooth[5];                 // normpdf(j, 0, 1), j = -2..2          (findCorner.cpp:195, :296)
+    double bcos[kBins], bsin[kBins];  // direction of histogram bin b: angle b pi / 32
+    double tsin[kBins], tcos[kBins];  // sin / cos of atan2(bsin, bcos)        (:483, :364-365)
+    double X[150];                    // 6 x 25 least-squares operator        (:495-509)
+    double npdf[3][513];              // normpdf(sqrt(d2), 0, r / 2) by squared distance, r = 8, 12, 16
+};
+
+__device__ __forceinline__ int refl101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+// findCorner.cpp:8-29.  grid ceil(w*h/256) x 256; mm[0] = min, mm[1] = max of the grey values
+__global__ __launch_bounds__(256) void k_corner_gradients(const unsigned char *gray, int w, int h, int stride, AtanConsts ac,
+                                                          double *angle, double *weight, int *mm)
+{
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    int g = -1;
+    if (o < (long)w * h) {
+        const int i = (int)(o / w), j = (int)(o % w);
+        const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
+        const unsigned char *rm = gray + (size_t)im * stride, *r0 = gray + (size_t)i * stride, *rp = gray + (size_t)ip * stride;
+        const double du = ((double)rm[jp] - rm[jm]) + ((double)r0[jp] - r0[jm]) + ((double)rp[jp] - rp[jm]);
+        const double dv = ((double)rp[jm] - rm[jm]) + ((double)rp[j] - rm[j]) + ((double)rp[jp] - rm[jp]);
+        double a;
+        if (dv == 0.0) a = du < 0.0 ? ac.zn : 0.0;
+        else if (du == 0.0) a = dv > 0.0 ? ac.p0 : ac.n0;
+        else if (fabs(du) == fabs(dv)) a = dv > 0.0 ? (du > 0.0 ? ac.pp : ac.pn) : (du > 0.0 ? ac.np : ac.nn);
+        else a = atan2(dv, du);
+        if (a < 0) a += kPi;
+        if (a > kPi) a -= kPi;
+        angle[o] = a;
+        weight[o] = sqrt(dv * dv + du * du);
+        g = r0[j];
+    }
+    int mn = g < 0 ? 255 : g, mx = g < 0 ? 0 : g;
+    for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], mn); atomicMax(&mm[1], mx); }
+}
+
+// rows of GaussianBlur on the normalised image (img - min) / (max - min) (:30-34, :106).  grid (ceil(w/256), h)
+__global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, int w, int h, int stride, const int *mm, const double *taps, int n,
+                                                    double *tmp)
+{
+    __shared__ double lut[256], k[64];
+    const double mn = mm[0], mx = mm[1];
+    lut[threadIdx.x] = ((double)threadIdx.x - mn) / (mx - mn);
+    if (threadIdx.x < n) k[threadIdx.x] = taps[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= w) return;
+    const unsigned char *row = gray + (size_t)i * stride;
+    const int half = n / 2;
+    double s = 0;
+    for (int q = 0; q < n; ++q) s += k[q] * lut[row[refl101(j + q - half, w)]];
+    tmp[(size_t)i * w + j] = s;
+}
+
+// columns (symmetric kernel: centre tap, then pairs).  grid (ceil(w/256), h)
+__global__ __launch_bounds__(256) void k_gauss_cols(const double *tmp, int w, int h, const double *taps, int n, double *Ig)
+{
+    __shared__ double k[64];
+    if (threadIdx.x < n) k[threadIdx.x] = taps[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= w) return;
+    const int half = n / 2;
+    double s = k[half] * tmp[(size_t)i * w + j];
+    for (int q = 1; q <= half; ++q) s += k[half + q] * (tmp[(size_t)refl101(i + q, h) * w + j] + tmp[(size_t)refl101(i - q, h) * w + j]);
+    Ig[(size_t)i * w + j] = s;
+}
+
+// secondDerivCornerMetric :108-141 fused: every intermediate plane (Ix, Iy, I_45, ...) is a reflected 3-tap stencil of
+// the previous one, so each output pixel reads a 5x5 neighbourhood of Ig.  grid (ceil(w/256), h)
+__global__ __launch_bounds__(256) void k_corner_metric(const double *Ig, int w, int h, int sigma, double c4, double cn4, double s4, double sn4,
+                                                       double *metric, double *Ixy)
+{
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= w) return;
+    auto G = [&](int r, int c) { return Ig[(size_t)r * w + c]; };
+    auto IX = [&](int r, int c) { return G(r, refl101(c - 1, w)) - G(r, refl101(c + 1, w)); };       // du = (1 0 -1)
+    auto IY = [&](int r, int c) { return G(refl101(r - 1, h), c) - G(refl101(r + 1, h), c); };
+    auto I45 = [&](int r, int c) { return IX(r, c) * c4 + IY(r, c) * s4; };
+    const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
+    const double ix = IX(i, j), iy = IY(i, j), i45 = ix * c4 + iy * s4;
+    const double ixy = IX(im, j) - IX(ip, j);
+    const double i45x = I45(i, jm) - I45(i, jp);
+    const double i45y = I45(im, j) - I45(ip, j);
+    const double i4545 = i45x * cn4 + i45y * sn4;
+    const double in45 = ix * cn4 + iy * sn4;
+    double cxy = sigma * sigma * fabs(ixy) - 1.5 * sigma * (fabs(i45) + fabs(in45));
+    if (cxy < 0) cxy = 0;
+    double c45 = sigma * sigma * fabs(i4545) - 1.5 * sigma * (fabs(ix) + fabs(iy));
+    if (c45 < 0) c45 = 0;
+    metric[(size_t)i * w + j] = cxy + c45;
+    Ixy[(size_t)i * w + j] = ixy;
+}
+
+// nonMaximumSuppression :144-193, one thread per cell; cells are numbered column-major like the reference's loops
+// (x outer, y inner).  cell[c] = (maxi << 16) | maxj, or -1.
+__global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width, int height, int ncx, int ncy, int *cell)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncx * ncy) return;
+    constexpr int n = kNmsN, margin = kNmsMargin;
+    const int i = n + margin + (c / ncy) * (n + 1), j = n + margin + (c % ncy) * (n + 1);
+    int maxi = i, maxj = j;
+    double maxval = img[(size_t)j * width + i];
+    for (int i2 = i; i2 <= i + n; ++i2)
+        for (int j2 = j; j2 <= j + n; ++j2) {
+            const double v = img[(size_t)j2 * width + i2];
+            if (v > maxval) { maxi = i2; maxj = j2; maxval = v; }
+        }
+    bool failed = false;
+    const int i_end = min(maxi + n, width - margin), j_end = min(maxj + n, height - margin);
+    for (int i2 = maxi - n; i2 < i_end && !failed; ++i2)
+        for (int j2 = maxj - n; j2 < j_end; ++j2) {
+            const double v = img[(size_t)j2 * width + i2];
+            if (v > maxval && (i2 < i || i2 > i + n || j2 < j || j2 > j + n)) { failed = true; break; }
+        }
+    cell[c] = (maxval >= kNmsTau && !failed) ? ((maxi << 16) | maxj) : -1;
+}
+
+// order-preserving compaction of the cell results: one 1024-thread workgroup.  count[0] = number of maxima
+__global__ __launch_bounds__(1024) void k_nms_compact(const int *cell, int ncell, int cap, int *cand, int *count)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (ncell + 1023) / 1024;
+    const int b = min(ncell, t * per), e = min(ncell, b + per);
+    int c = 0;
+    for (int q = b; q < e; ++q) c += cell[q] >= 0;
+    part[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int pos = part[t] - c;
+    for (int q = b; q < e; ++q) if (cell[q] >= 0) { if (pos < cap) cand[pos] = cell[q]; ++pos; }
+    if (t == 1023) count[0] = part[1023];
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// getOrientations + scoreCorners + subPixelLocation for one candidate per 64-thread workgroup
+__global__ __launch_bounds__(64) void k_corner_describe(const unsigned char *gray, int stride, const int *mm, const double *angle, const double *weight,
+                                                        const double *Ixy, int width, int height, const int *cand, const DescribeTables *T,
+                                                        double *out_v, double *out_score, double *out_sub)
+{
+    __shared__ double hist[kBins], vsh[4];
+    __shared__ int bsh[2];
+    const int lane = threadIdx.x, q = blockIdx.x;
+    const int cu = cand[q] >> 16, cv = cand[q] & 0xffff;
+    // ---- :200-279  orientation histogram: lane b owns bin b and walks the window in the reference's order -------------
+    {
+        const int y1 = min(cv + kOrientR, height - 1), y0 = max(cv - kOrientR, 0), x1 = min(cu + kOrientR, width - 1), x0 = max(cu - kOrientR, 0);
+        double hsum = 0;
+        if (lane < kBins) {
+            for (int i = y0; i <= y1; ++i)
+                for (int j = x0; j <= x1; ++j) {
+                    double a = angle[(size_t)i * width + j] + kPi / 2;
+                    if (a > kPi) a -= kPi;
+                    int bin = (int)floor(a / (kPi / kBins));
+                    bin = max(min(bin, kBins - 1), 0);
+                    if (bin == lane) hsum += weight[(size_t)i * width + j];
+                }
+            hist[lane] = hsum;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            // :286-349 (the histogram is circular: indices wrap, see the oracle's header for the reference's out-of-range reads)
+            double sm[kBins];
+            for (int i = 0; i < kBins; ++i) {
+                double sum = 0;
+                for (int j = -2; j <= 2; ++j) sum += hist[((i + j) % kBins + kBins) % kBins] * T->smooth[j + 2];
+                sm[i] = sum;
+            }
+            bool flat = true;
+            for (int i = 1; i < kBins; ++i) if (fabs(sm[i] - sm[0]) > 1e-5) { flat = false; break; }
+            int mb[kBins], nm = 0;
+            double mv[kBins];
+            if (!flat) {
+                for (int i = 0; i < kBins; ++i) {
+                    int j = i;
+                    for (;;) {
+                        const double h0 = sm[j];
+                        const int j1 = (j + 1) % kBins, j2 = (j - 1 + kBins) % kBins;
+                        const double h1 = sm[j1], h2 = sm[j2];
+                        if (h1 >= h0 && h1 >= h2) j = j1;
+                        else if (h2 > h0 && h2 > h1) j = j2;
+                        else break;
+                    }
+                    bool seen = false;
+                    for (int k = 0; k < nm; ++k) if (mb[k] == j) { seen = true; break; }
+                    if (!seen) { mb[nm] = j; mv[nm] = sm[j]; ++nm; }
+                }
+                for (int a = 1; a < nm; ++a) {          // strongest first, stable
+                    const int b = mb[a]; const double v = mv[a];
+                    int k = a - 1;
+                    while (k >= 0 && mv[k] < v) { mb[k + 1] = mb[k]; mv[k + 1] = mv[k]; --k; }
+                    mb[k + 1] = b; mv[k + 1] = v;
+                }
+            }
+            int b1 = -1, b2 = -1;                      // histogram bins of v1 and v2
+            if (nm > 1) {
+                const double z0 = mb[0] * kPi / kBins, z1 = mb[1] * kPi / kBins;
+                if (z0 > z1) {
+                    b1 = mb[1]; b2 = mb[0];
+                    if (fmin(z0 - z1, z1 + kPi - z0) <= 0.3 && nm > 2) b1 = mb[2];
+                } else {
+                    b1 = mb[0]; b2 = mb[1];
+                    if (fmin(z1 - z0, z0 + kPi - z1) <= 0.3 && nm > 2) b2 = mb[2];
+                }
+            }
+            bsh[0] = b1; bsh[1] = b2;
+            vsh[0] = b1 >= 0 ? T->bcos[b1] : 0.0; vsh[1] = b1 >= 0 ? T->bsin[b1] : 0.0;
+            vsh[2] = b2 >= 0 ? T->bcos[b2] : 0.0; vsh[3] = b2 >= 0 ? T->bsin[b2] : 0.0;
+        }
+        __syncthreads();
+    }
+    const double v1x = vsh[0], v1y = vsh[1], v2x = vsh[2], v2y = vsh[3];
+    const int b1 = bsh[0], b2 = bsh[1];
+    // template angles atan2(v.y, v.x) and their sin / cos (:483, :364-365); v = (0, 0): atan2 = 0
+    const double s1a = b1 >= 0 ? T->tsin[b1] : 0.0, c1a = b1 >= 0 ? T->tcos[b1] : 1.0;
+    const double s2a = b2 >= 0 ? T->tsin[b2] : 0.0, c2a = b2 >= 0 ? T->tcos[b2] : 1.0;
+    // ---- :391-490  correlation score, best of the radii that fit ---------------------------------------------------
+    const double gmn = mm[0], gmx = mm[1];
+    double best = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int r = 8 + 4 * k, n = 2 * r + 1, N = n * n;
+        double s = 0;
+        if (cu >= r && cu < width - r && cv >= r && cv < height - r) {     // wave-uniform
+            auto filt = [&](int x, int y) {
+                const double p0 = x - r, p1 = y - r;
+                const double a = p0 * v1x + p1 * v1y, b = p0 * v2x + p1 * v2y;
+                const double q0 = p0 - a * v1x, q1 = p1 - a * v1y, t0 = p0 - b * v2x, t1 = p1 - b * v2y;
+                return (sqrt(q0 * q0 + q1 * q1) <= 1.5 || sqrt(t0 * t0 + t1 * t1) <= 1.5) ? 1.0 : -1.0;
+            };
+            double sw = 0, sf = 0;
+            for (int e = lane; e < N; e += 64) { const int y = e / n, x = e % n; sw += weight[(size_t)(cv - r + y) * width + (cu - r + x)]; sf += filt(x, y); }
+            const double mw = wave_sum(sw) / N, mf = wave_sum(sf) / N;
+            double vw = 0, vf = 0;
+            for (int e = lane; e < N; e += 64) {
+                const int y = e / n, x = e % n;
+                const double dw = weight[(size_t)(cv - r + y) * width + (cu - r + x)] - mw, df = filt(x, y) - mf;
+                vw += dw * dw; vf += df * df;
+            }
+            const double sdw = sqrt(wave_sum(vw) / N), sdf = sqrt(wave_sum(vf) / N);
+            double cs = 0, t[4] = { 0, 0, 0, 0 }, nr[4] = { 0, 0, 0, 0 };
+            for (int e = lane; e < N; e += 64) {
+                const int y = e / n, x = e % n;
+                cs += ((weight[(size_t)(cv - r + y) * width + (cu - r + x)] - mw) / sdw) * ((filt(x, y) - mf) / sdf);
+                const int du = x - r, dv = y - r;
+                const double e1 = -du * s1a + dv * c1a, e2 = -du * s2a + dv * c2a;
+                int which = -1;
+                if (e1 <= -0.1 && e2 <= -0.1) which = 0;
+                else if (e1 >= 0.1 && e2 >= 0.1) which = 1;
+                else if (e1 <= -0.1 && e2 >= 0.1) which = 2;
+                else if (e1 >= 0.1 && e2 <= -0.1) which = 3;
+                if (which >= 0) {
+                    const double g = T->npdf[k][du * du + dv * dv];
+                    const double px = ((double)gray[(size_t)(cv - r + y) * stride + (cu - r + x)] - gmn) / (gmx - gmn);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) if (m == which) { nr[m] += g; t[m] += g * px; }
+                }
+            }
+            const double score_gradient = fmax(wave_sum(cs) / (N - 1), 0.0);
+            double tt[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { const double nn = wave_sum(nr[m]), ts = wave_sum(t[m]); tt[m] = nn > 2.220446049250313e-16 ? ts / nn : 0.0; }
+            const double mu = (tt[0] + tt[1] + tt[2] + tt[3]) / 4;
+            const double score_1 = fmin(fmin(tt[0] - mu, tt[1] - mu), fmin(mu - tt[2], mu - tt[3]));
+            const double score_2 = fmin(fmin(mu - tt[0], mu - tt[1]), fmin(tt[2] - mu, tt[3] - mu));
+            s = score_gradient * fmax(fmax(score_1, score_2), 0.0);
+        }
+        if (k == 0 || s > best) best = s;
+    }
+    // ---- :510-539  quadratic fit of the 5x5 neighbourhood of Ixy (lane a < 6: coefficient a, sums in the reference's order)
+    double beta = 0;
+    if (lane < 6) {
+        int cnt = 0;
+        for (int j = cu - 2; j <= cu + 2; ++j)
+            for (int k = cv - 2; k <= cv + 2; ++k) beta += T->X[lane * 25 + cnt++] * Ixy[(size_t)k * width + j];
+    }
+    const double A = __shfl(beta, 0), B = __shfl(beta, 1), C = __shfl(beta, 2), D = __shfl(beta, 3), E = __shfl(beta, 4);
+    if (lane == 0) {
+        double x = -(2 * B * C - D * E) / (4 * A * B - E * E);
+        double y = -(2 * A * D - C * E) / (4 * A * B - E * E);
+        if (fabs(x) > 2 || fabs(y) > 2) { x = 0; y = 0; }
+        out_sub[2 * q] = cu + x; out_sub[2 * q + 1] = cv + y;
+        out_score[q] = best;
+        out_v[4 * q] = v1x; out_v[4 * q + 1] = v1y; out_v[4 * q + 2] = v2x; out_v[4 * q + 3] = v2y;
+    }
+}
+
+double normpdf_i(double x, int mu, int sigma) { return std::exp(-(x - mu) * (x - mu) / 2 / sigma / sigma) / std::sqrt(2 * kPi) / sigma; }
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T)); }
+};
+
+}  // namespace
+
+extern "C" void tscm_corner_candidates_free(tscm_corner_candidates *c)
+{
+    if (!c) return;
+    std::free(c->x); std::free(c->y); std::free(c->v1); std::free(c->v2); std::free(c->score); std::free(c->sub);
+    c->x = c->y = c->v1 = c->v2 = c->score = c->sub = nullptr;
+    c->n = 0;
+}
+
+extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, double min_score, int device,
+                                   tscm_corner_candidates *out)
+{
+    if (!out) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    if (!gray || width < 1 || height < 1 || stride < width) return tscm_set_error(TSCM_E_INVALID, "bad image description");
+    if (width > 32767 || height > 32767) return tscm_set_error(TSCM_E_UNSUPPORTED, "images beyond 32767 pixels per side");
+    const int ntap = 7 * sigma + 1;
+    if (sigma < 1 || ntap % 2 == 0 || ntap > 64) return tscm_set_error(TSCM_E_UNSUPPORTED, "sigma must be even and at most 8 (cv::GaussianBlur needs an odd 7 sigma + 1; the reference uses 4)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tscm_set_error(TSCM_E_NO_DEVICE, "no HIP device available (the corner detector has no CPU fallback)");
+    if (device < 0 || device >= ndev) return tscm_set_error(TSCM_E_NO_DEVICE, "device index out of range");
+    CRN_TRY(hipSetDevice(device));
+
+    // ---- host-side constants (the C library the CPU path would use) -----------------------------------------------
+    std::vector<double> taps(ntap);
+    {
+        const double scale2x = -0.5 / ((double)sigma * sigma);
+        double sum = 0;
+        for (int i = 0; i < ntap; ++i) { const double x = i - (ntap - 1) * 0.5; taps[i] = std::exp(scale2x * x * x); sum += taps[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < ntap; ++i) taps[i] *= sum;
+    }
+    const AtanConsts ac = { std::atan2(1.0, 1.0), std::atan2(1.0, -1.0), std::atan2(-1.0, 1.0), std::atan2(-1.0, -1.0),
+                            std::atan2(1.0, 0.0), std::atan2(-1.0, 0.0), std::atan2(0.0, -1.0) };
+    std::vector<DescribeTables> tab(1);
+    DescribeTables &T = tab[0];
+    for (int j = -2; j <= 2; ++j) T.smooth[j + 2] = normpdf_i(j, 0, 1);
+    for (int b = 0; b < kBins; ++b) {
+        const double z = b * kPi / kBins;
+        T.bcos[b] = std::cos(z); T.bsin[b] = std::sin(z);
+        const double a = std::atan2(T.bsin[b], T.bcos[b]);
+        T.tsin[b] = std::sin(a); T.tcos[b] = std::cos(a);
+    }
+    for (int k = 0; k < 3; ++k) {
+        const int r = 8 + 4 * k;
+        for (int d2 = 0; d2 <= 512; ++d2) T.npdf[k][d2] = d2 <= 2 * r * r ? normpdf_i(std::sqrt((double)d2), 0, r / 2) : 0.0;
+    }
+    {   // X = (A^T A)^-1 A^T, Gauss-Jordan with partial pivoting
+        double A[25][6], M[6][12];
+        for (int y = -2; y <= 2; ++y)
+            for (int x = -2; x <= 2; ++x) {
+                const int idx = (x + 2) * 5 + y + 2;
+                A[idx][0] = x * x; A[idx][1] = y * y; A[idx][2] = x; A[idx][3] = y; A[idx][4] = x * y; A[idx][5] = 1;
+            }
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) {
+                double s = 0;
+                for (int q = 0; q < 25; ++q) s += A[q][a] * A[q][b];
+                M[a][b] = s; M[a][6 + b] = a == b ? 1.0 : 0.0;
+            }
+        for (int c = 0; c < 6; ++c) {
+            int p = c;
+            for (int q = c + 1; q < 6; ++q) if (std::fabs(M[q][c]) > std::fabs(M[p][c])) p = q;
+            if (p != c) for (int q = 0; q < 12; ++q) std::swap(M[c][q], M[p][q]);
+            const double d = M[c][c];
+            for (int q = 0; q < 12; ++q) M[c][q] /= d;
+            for (int rr = 0; rr < 6; ++rr) {
+                if (rr == c) continue;
+                const double f = M[rr][c];
+                for (int q = 0; q < 12; ++q) M[rr][q] -= f * M[c][q];
+            }
+        }
+        for (int a = 0; a < 6; ++a)
+            for (int q = 0; q < 25; ++q) {
+                double s = 0;
+                for (int b = 0; b < 6; ++b) s += M[a][6 + b] * A[q][b];
+                T.X[a * 25 + q] = s;
+            }
+    }
+
+    // ---- device buffers --------------------------------------------------------------------------------------------
+    const size_t N = (size_t)width * height;
+    constexpr int n = kNmsN, margin = kNmsMargin;
+    const int span_x = width - 2 * (n + margin), span_y = height - 2 * (n + margin);
+    const int ncx = span_x > 0 ? (span_x + n) / (n + 1) : 0, ncy = span_y > 0 ? (span_y + n) / (n + 1) : 0;
+    const int ncell = ncx * ncy;
+    DevBuf<unsigned char> d_gray;
+    DevBuf<double> d_angle, d_weight, d_tmp, d_Ig, d_metric, d_Ixy, d_taps, d_v, d_score, d_sub;
+    DevBuf<int> d_mm, d_cell, d_cand, d_count;
+    DevBuf<DescribeTables> d_tab;
+    CRN_TRY(d_gray.alloc((size_t)stride * height));
+    CRN_TRY(d_angle.alloc(N)); CRN_TRY(d_weight.alloc(N)); CRN_TRY(d_tmp.alloc(N)); CRN_TRY(d_Ig.alloc(N)); CRN_TRY(d_metric.alloc(N)); CRN_TRY(d_Ixy.alloc(N));
+    CRN_TRY(d_taps.alloc(ntap)); CRN_TRY(d_mm.alloc(2)); CRN_TRY(d_cell.alloc(ncell)); CRN_TRY(d_cand.alloc(ncell)); CRN_TRY(d_count.alloc(1));
+    CRN_TRY(d_tab.alloc(1));
+    CRN_TRY(d_v.alloc(4 * (size_t)ncell)); CRN_TRY(d_score.alloc(ncell)); CRN_TRY(d_sub.alloc(2 * (size_t)ncell));
+    CRN_TRY(hipMemcpy(d_gray.p, gray, (size_t)stride * height, hipMemcpyHostToDevice));
+    CRN_TRY(hipMemcpy(d_taps.p, taps.data(), sizeof(double) * ntap, hipMemcpyHostToDevice));
+    CRN_TRY(hipMemcpy(d_tab.p, tab.data(), sizeof(DescribeTables), hipMemcpyHostToDevice));
+    const int mm0[2] = { 255, 0 };
+    CRN_TRY(hipMemcpy(d_mm.p, mm0, sizeof mm0, hipMemcpyHostToDevice));
+    CRN_TRY(hipMemset(d_count.p, 0, sizeof(int)));
+
+    hipEvent_t e0, e1;
+    CRN_TRY(hipEventCreate(&e0)); CRN_TRY(hipEventCreate(&e1));
+    CRN_TRY(hipEventRecord(e0, nullptr));
+    const dim3 grid2((width + 255) / 256, height);
+    hipLaunchKernelGGL(k_corner_gradients, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, d_gray.p, width, height, stride, ac, d_angle.p, d_weight.p, d_mm.p);
+    hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p);
+    hipLaunchKernelGGL(k_gauss_cols, grid2, dim3(256), 0, nullptr, d_tmp.p, width, height, d_taps.p, ntap, d_Ig.p);
+    hipLaunchKernelGGL(k_corner_metric, grid2, dim3(256), 0, nullptr, d_Ig.p, width, height, sigma, std::cos(kPi / 4), std::cos(-kPi / 4), std::sin(kPi / 4),
+                       std::sin(-kPi / 4), d_metric.p, d_Ixy.p);
+    int n_max = 0;
+    if (ncell > 0) {
+        hipLaunchKernelGGL(k_nms_cells, dim3((ncell + 255) / 256), dim3(256), 0, nullptr, d_metric.p, width, height, ncx, ncy, d_cell.p);
+        hipLaunchKernelGGL(k_nms_compact, dim3(1), dim3(1024), 0, nullptr, d_cell.p, ncell, ncell, d_cand.p, d_count.p);
+        CRN_TRY(hipMemcpy(&n_max, d_count.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (n_max > 0)
+            hipLaunchKernelGGL(k_corner_describe, dim3(n_max), dim3(64), 0, nullptr, d_gray.p, stride, d_mm.p, d_angle.p, d_weight.p, d_Ixy.p, width, height, d_cand.p,
+                               d_tab.p, d_v.p, d_score.p, d_sub.p);
+    }
+    CRN_TRY(hipEventRecord(e1, nullptr));
+    CRN_TRY(hipEventSynchronize(e1));
+    CRN_TRY(hipGetLastError());
+    float ms = 0;
+    CRN_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    out->seconds = ms * 1e-3;
+    out->n_maxima = n_max;
+
+    // ---- score filter (findCorner.cpp:47-66), order preserved ------------------------------------------------------
+    std::vector<int> cand(n_max);
+    std::vector<double> v(4 * (size_t)n_max), score(n_max), sub(2 * (size_t)n_max);
+    if (n_max > 0) {
+        CRN_TRY(hipMemcpy(cand.data(), d_cand.p, sizeof(int) * n_max, hipMemcpyDeviceToHost));
+        CRN_TRY(hipMemcpy(v.data(), d_v.p, sizeof(double) * 4 * n_max, hipMemcpyDeviceToHost));
+        CRN_TRY(hipMemcpy(score.data(), d_score.p, sizeof(double) * n_max, hipMemcpyDeviceToHost));
+        CRN_TRY(hipMemcpy(sub.data(), d_sub.p, sizeof(double) * 2 * n_max, hipMemcpyDeviceToHost));
+    }
+    int keep = 0;
+    for (int q = 0; q < n_max; ++q) if (!(score[q] < min_score)) ++keep;
+    const size_t kk = keep ? keep : 1;
+    out->x = static_cast<double *>(std::calloc(kk, sizeof(double))); out->y = static_cast<double *>(std::calloc(kk, sizeof(double)));
+    out->v1 = static_cast<double *>(std::calloc(2 * kk, sizeof(double))); out->v2 = static_cast<double *>(std::calloc(2 * kk, sizeof(double)));
+    out->score = static_cast<double *>(std::calloc(kk, sizeof(double))); out->sub = static_cast<double *>(std::calloc(2 * kk, sizeof(double)));
+    if (!out->x || !out->y || !out->v1 || !out->v2 || !out->score || !out->sub) { tscm_corner_candidates_free(out); return tscm_set_error(TSCM_E_NOMEM, "out of memory"); }
+    int w = 0;
+    for (int q = 0; q < n_max; ++q) {
+        if (score[q] < min_score) continue;
+        out->x[w] = cand[q] >> 16; out->y[w] = cand[q] & 0xffff;
+        out->v1[2 * w] = v[4 * q]; out->v1[2 * w + 1] = v[4 * q + 1]; out->v2[2 * w] = v[4 * q + 2]; out->v2[2 * w + 1] = v[4 * q + 3];
+        out->score[w] = score[q];
+        out->sub[2 * w] = sub[2 * q]; out->sub[2 * w + 1] = sub[2 * q + 1];
+        ++w;
+    }
+    out->n = keep;
+    return 0;
+}

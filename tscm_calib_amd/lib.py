@@ -112,6 +112,7 @@ EXPORTS = [
     "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
     "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
+    "tscm_detect_corners", "tscm_corner_candidates_free",
 ]
 
 
@@ -226,3 +227,12 @@ def summary_dict(s: CSummary) -> dict:
                 final_cost=s.final_cost, n_residual_blocks=s.n_residual_blocks, lm_iterations=s.lm_iterations,
                 iterations=its, message=s.message.decode(), seconds_solve=s.seconds_solve,
                 seconds_total=s.seconds_total, rmse=s.rmse)
+
+
+class CCornerCandidates(C.Structure):
+    """tscm_corner_candidates (tscm.h)"""
+    _fields_ = [("n", C.c_int), ("n_maxima", C.c_int),
+                ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
+                ("v1", C.POINTER(C.c_double)), ("v2", C.POINTER(C.c_double)),
+                ("score", C.POINTER(C.c_double)), ("sub", C.POINTER(C.c_double)),
+                ("seconds", C.c_double)]

@@ -348,3 +348,46 @@ def make_rig_input(p: Problem, *, rot_sigma: float = 0.01, t_sigma: float = 3.0,
     worlds = np.concatenate([p.board_xy, np.zeros((n, 1))], axis=1)
     return RigInput(worlds, p.intr.copy(), has, Rt, pu, pv,
                     meta=dict(p.meta, rot_sigma=rot_sigma, t_sigma=t_sigma)).normalised()
+
+
+def unproject_pixels_np(intr, u, v):
+    """Vectorised inverse Triple Sphere model (TS.cpp get_unit_sphere_coordinate): pixel arrays -> unit rays."""
+    fx, fy, cx, cy, xi, lam, alpha, b, c = [float(t) for t in np.asarray(intr, dtype=np.float64).ravel()]
+    x, y = u - cx, v - cy
+    den = fx * fy - b * c
+    mx, my = (fy * x - b * y) / den, (-c * x + fx * y) / den
+    ksai = alpha / (1 - alpha)
+    r2 = mx * mx + my * my
+    gamma = (ksai + np.sqrt(np.maximum(1 + (1 - ksai * ksai) * r2, 0.0))) / (r2 + 1)      # (outside the image circle: clamped)
+    g = gamma - ksai
+    yita = lam * g + np.sqrt((g * g - 1) * lam * lam + 1)
+    mz = yita * g
+    mu = xi * (mz - lam) + np.sqrt(xi * xi * ((mz - lam) ** 2 - 1) + 1)
+    return np.stack([mu * yita * gamma * mx, mu * yita * gamma * my, mu * (mz - lam) - xi], axis=-1)
+
+
+def render_chessboard(intr, board_rt, cols: int, rows: int, pitch: float, width: int, height: int,
+                      supersample: int = 3, background: int = 110, dark: int = 25, bright: int = 230) -> np.ndarray:
+    """Synthetic grey image (uint8, height x width) of a chessboard with cols x rows INNER corners at
+    (i * pitch, j * pitch, 0), i.e. (cols + 1) x (rows + 1) squares, seen through the Triple Sphere model with the
+    board pose board_rt (angle-axis + translation, board -> camera).  Every pixel is the mean of supersample^2 rays
+    intersected with the board plane.  Test / demo data for the corner detector."""
+    R = rodrigues(np.asarray(board_rt[:3], dtype=np.float64))
+    t = np.asarray(board_rt[3:], dtype=np.float64)
+    n = R[:, 2]                                        # board normal in camera coordinates
+    ss = supersample
+    offs = (np.arange(ss) + 0.5) / ss - 0.5
+    acc = np.zeros((height, width), dtype=np.float64)
+    jj, ii = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    for oy in offs:
+        for ox in offs:
+            d = unproject_pixels_np(intr, jj + ox, ii + oy)
+            den = d @ n
+            s = (t @ n) / np.where(np.abs(den) < 1e-12, 1e-12, den)
+            P = d * s[..., None] - t                   # point on the plane, relative to the board origin (camera axes)
+            X, Y = P @ R[:, 0], P @ R[:, 1]
+            qx, qy = np.floor(X / pitch + 1.0), np.floor(Y / pitch + 1.0)      # square index, -1 outside on the low side
+            inside = (s > 0) & (qx >= 0) & (qx <= cols) & (qy >= 0) & (qy <= rows)
+            col = np.where(((qx + qy) % 2) == 0, dark, bright)
+            acc += np.where(inside, col, background)
+    return np.clip(np.rint(acc / (ss * ss)), 0, 255).astype(np.uint8)
