@@ -39,6 +39,8 @@ constexpr int kNmsN = 4, kNmsMargin = 5, kOrientR = 10, kBins = 32;
 constexpr double kNmsTau = 0.07;
 constexpr double kPi = 3.14159265358979323846;
 
+constexpr int kMmSlots = 64, kMmStride = 32;     // min / max accumulators: 64 slots, 128 bytes apart
+
 struct AtanConsts { double pp, pn, np, nn, p0, n0, zn; };      // atan2(1,1), (1,-1), (-1,1), (-1,-1), (1,0), (-1,0), (0,-1)
 
 struct DescribeTables {
@@ -56,7 +58,15 @@ __device__ __forceinline__ int refl101(int i, int n)
     return i;
 }
 
-// findCorner.cpp:8-29.  grid ceil(w*h/256) x 256; mm[0] = min, mm[1] = max of the grey values
+// min and max of the grey values from the slots; every lane of a full wave calls it
+__device__ __forceinline__ void read_extremes(const int *mm, int &mn, int &mx)
+{
+    const int lane = threadIdx.x & 63;
+    mn = mm[kMmStride * lane]; mx = mm[kMmStride * lane + 1];
+    for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+}
+
+// findCorner.cpp:8-29.  grid ceil(w*h/256) x 256; mm: kMmSlots x (min, max) of the grey values
 __global__ __launch_bounds__(256) void k_corner_gradients(const unsigned char *gray, int w, int h, int stride, AtanConsts ac,
                                                           double *angle, double *weight, int *mm)
 {
@@ -81,7 +91,15 @@ __global__ __launch_bounds__(256) void k_corner_gradients(const unsigned char *g
     }
     int mn = g < 0 ? 255 : g, mx = g < 0 ? 0 : g;
     for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], mn); atomicMax(&mm[1], mx); }
+    // one atomic pair per wave only while it can still move the extremes (a plain read of a monotone value: a stale
+    // one merely costs a redundant atomic) -- unconditional atomics on two addresses serialise 21 k waves: 0.5 ms
+    // ... and the waves are spread over kMmSlots slots on separate cache lines (the consumers reduce the slots)
+    if ((threadIdx.x & 63) == 0) {
+        int *slot = mm + kMmStride * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMmSlots - 1));
+        const volatile int *cur = slot;
+        if (mn < cur[0]) atomicMin(&slot[0], mn);
+        if (mx > cur[1]) atomicMax(&slot[1], mx);
+    }
 }
 
 // rows of GaussianBlur on the normalised image (img - min) / (max - min) (:30-34, :106).  grid (ceil(w/256), h)
@@ -89,7 +107,9 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, i
                                                     double *tmp)
 {
     __shared__ double lut[256], k[64];
-    const double mn = mm[0], mx = mm[1];
+    int imn, imx;
+    read_extremes(mm, imn, imx);
+    const double mn = imn, mx = imx;
     lut[threadIdx.x] = ((double)threadIdx.x - mn) / (mx - mn);
     if (threadIdx.x < n) k[threadIdx.x] = taps[threadIdx.x];
     __syncthreads();
@@ -146,10 +166,12 @@ __global__ __launch_bounds__(256) void k_corner_metric(const double *Ig, int w, 
 // (x outer, y inner).  cell[c] = (maxi << 16) | maxj, or -1.
 __global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width, int height, int ncx, int ncy, int *cell)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncx * ncy) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ncx * ncy) return;
     constexpr int n = kNmsN, margin = kNmsMargin;
-    const int i = n + margin + (c / ncy) * (n + 1), j = n + margin + (c % ncy) * (n + 1);
+    const int cxi = t % ncx, cyi = t / ncx;          // neighbouring threads: neighbouring cells of a row (coalescing) ...
+    const int c = cxi * ncy + cyi;                   // ... stored in the reference's column-major cell order
+    const int i = n + margin + cxi * (n + 1), j = n + margin + cyi * (n + 1);
     int maxi = i, maxj = j;
     double maxval = img[(size_t)j * width + i];
     for (int i2 = i; i2 <= i + n; ++i2)
@@ -167,26 +189,39 @@ __global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width,
     cell[c] = (maxval >= kNmsTau && !failed) ? ((maxi << 16) | maxj) : -1;
 }
 
-// order-preserving compaction of the cell results: one 1024-thread workgroup.  count[0] = number of maxima
+// order-preserving compaction of the cell results: one 1024-thread workgroup, each of the 16 waves owns a contiguous
+// range of cells and walks it 64 cells at a time (coalesced, eight loads in flight), positions by ballot + popcount.
+// count[0] = number of maxima
 __global__ __launch_bounds__(1024) void k_nms_compact(const int *cell, int ncell, int cap, int *cand, int *count)
 {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int per = (ncell + 1023) / 1024;
-    const int b = min(ncell, t * per), e = min(ncell, b + per);
-    int c = 0;
-    for (int q = b; q < e; ++q) c += cell[q] >= 0;
-    part[t] = c;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    __shared__ int wtot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = ((ncell + 15) / 16 + 63) & ~63;           // cells per wave, whole 64-cell steps
+    const int b = min(ncell, wave * per), e = min(ncell, b + per);
+    int total = 0;
+    for (int q0 = b; q0 < e; q0 += 512) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int q = q0 + 64 * u + lane; v[u] = q < e ? cell[q] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) total += __popcll(__ballot(v[u] >= 0));
     }
-    int pos = part[t] - c;
-    for (int q = b; q < e; ++q) if (cell[q] >= 0) { if (pos < cap) cand[pos] = cell[q]; ++pos; }
-    if (t == 1023) count[0] = part[1023];
+    if (lane == 0) wtot[wave] = total;
+    __syncthreads();
+    int pos = 0;
+    for (int k = 0; k < wave; ++k) pos += wtot[k];
+    for (int q0 = b; q0 < e; q0 += 512) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int q = q0 + 64 * u + lane; v[u] = q < e ? cell[q] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long m = __ballot(v[u] >= 0);
+            if (v[u] >= 0) { const int p = pos + __popcll(m & ((1ull << lane) - 1)); if (p < cap) cand[p] = v[u]; }
+            pos += __popcll(m);
+        }
+    }
+    if (threadIdx.x == 1023) count[0] = pos;
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -195,54 +230,148 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// getOrientations + scoreCorners + subPixelLocation for one candidate per 64-thread workgroup
-__global__ __launch_bounds__(64) void k_corner_describe(const unsigned char *gray, int stride, const int *mm, const double *angle, const double *weight,
-                                                        const double *Ixy, int width, int height, const int *cand, const DescribeTables *T,
-                                                        double *out_v, double *out_score, double *out_sub)
+// block-wide sum of up to eight values (256 threads: wave butterflies, then the four wave totals in wave order)
+template <int NV>
+__device__ __forceinline__ void block_sum4(double (&v)[NV], double *sh)      // sh: 4 * NV doubles
 {
-    __shared__ double hist[kBins], vsh[4];
-    __shared__ int bsh[2];
-    const int lane = threadIdx.x, q = blockIdx.x;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) v[m] = wave_sum(v[m]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int m = 0; m < NV; ++m) sh[(threadIdx.x >> 6) * NV + m] = v[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NV; ++m) v[m] = (sh[m] + sh[NV + m]) + (sh[2 * NV + m] + sh[3 * NV + m]);
+}
+
+// cornerCorrelationScore :428-490 (+ createCorrelationPatch :351-389) for one radius, by the whole 256-thread block
+template <int R>
+__device__ __forceinline__ double score_radius(const unsigned char *gray, int stride, const double *weight, int width, int cu, int cv, double gmn, double gmx,
+                                               double v1x, double v1y, double v2x, double v2y, double s1a, double c1a, double s2a, double c2a,
+                                               const double *npdf, double *sh)
+{
+    constexpr int n = 2 * R + 1, N = n * n, PER = (N + 255) / 256;
+    double wv[PER], fv[PER];
+    double acc2[2] = { 0, 0 };
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        wv[u] = 0; fv[u] = 0;
+        if (e < N) {
+            const int y = e / n, x = e % n;
+            const double p0 = x - R, p1 = y - R;
+            const double a = p0 * v1x + p1 * v1y, b = p0 * v2x + p1 * v2y;
+            const double q0 = p0 - a * v1x, q1 = p1 - a * v1y, t0 = p0 - b * v2x, t1 = p1 - b * v2y;
+            fv[u] = (sqrt(q0 * q0 + q1 * q1) <= 1.5 || sqrt(t0 * t0 + t1 * t1) <= 1.5) ? 1.0 : -1.0;
+            wv[u] = weight[(size_t)(cv - R + y) * width + (cu - R + x)];
+            acc2[0] += wv[u]; acc2[1] += fv[u];
+        }
+    }
+    block_sum4<2>(acc2, sh);
+    const double mw = acc2[0] / N, mf = acc2[1] / N;
+    double var2[2] = { 0, 0 };
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        if (threadIdx.x + 256 * u < N) { const double dw = wv[u] - mw, df = fv[u] - mf; var2[0] += dw * dw; var2[1] += df * df; }
+    }
+    block_sum4<2>(var2, sh);
+    const double sdw = sqrt(var2[0] / N), sdf = sqrt(var2[1] / N);
+    double acc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // correlation, 4 template sums, 4 template norms
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < N) {
+            const int y = e / n, x = e % n;
+            acc[0] += ((wv[u] - mw) / sdw) * ((fv[u] - mf) / sdf);
+            const int du = x - R, dv = y - R;
+            const double e1 = -du * s1a + dv * c1a, e2 = -du * s2a + dv * c2a;
+            int which = -1;
+            if (e1 <= -0.1 && e2 <= -0.1) which = 0;
+            else if (e1 >= 0.1 && e2 >= 0.1) which = 1;
+            else if (e1 <= -0.1 && e2 >= 0.1) which = 2;
+            else if (e1 >= 0.1 && e2 <= -0.1) which = 3;
+            if (which >= 0) {
+                const double g = npdf[du * du + dv * dv];
+                const double px = ((double)gray[(size_t)(cv - R + y) * stride + (cu - R + x)] - gmn) / (gmx - gmn);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) if (m == which) { acc[5 + m] += g; acc[1 + m] += g * px; }
+            }
+        }
+    }
+    block_sum4<9>(acc, sh);
+    const double score_gradient = fmax(acc[0] / (N - 1), 0.0);
+    double tt[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) tt[m] = acc[5 + m] > 2.220446049250313e-16 ? acc[1 + m] / acc[5 + m] : 0.0;
+    const double mu = (tt[0] + tt[1] + tt[2] + tt[3]) / 4;
+    const double score_1 = fmin(fmin(tt[0] - mu, tt[1] - mu), fmin(mu - tt[2], mu - tt[3]));
+    const double score_2 = fmin(fmin(mu - tt[0], mu - tt[1]), fmin(tt[2] - mu, tt[3] - mu));
+    return score_gradient * fmax(fmax(score_1, score_2), 0.0);
+}
+
+// getOrientations + scoreCorners + subPixelLocation for one candidate per 256-thread workgroup
+__global__ __launch_bounds__(256) void k_corner_describe(const unsigned char *gray, int stride, const int *mm, const double *angle, const double *weight,
+                                                         const double *Ixy, int width, int height, const int *cand, const DescribeTables *T,
+                                                         double *out_v, double *out_score, double *out_sub)
+{
+    __shared__ double hist[kBins], sm[kBins], mv[kBins], vsh[4], red[36];
+    __shared__ int bsh[2], climb[kBins], mb[kBins];
+    __shared__ double wwgt[(2 * kOrientR + 1) * (2 * kOrientR + 1)];
+    __shared__ unsigned char wbin[(2 * kOrientR + 1) * (2 * kOrientR + 1)];
+    const int tid = threadIdx.x, q = blockIdx.x;
     const int cu = cand[q] >> 16, cv = cand[q] & 0xffff;
-    // ---- :200-279  orientation histogram: lane b owns bin b and walks the window in the reference's order -------------
+    // ---- :200-279  orientation histogram ------------------------------------------------------------------------------
     {
         const int y1 = min(cv + kOrientR, height - 1), y0 = max(cv - kOrientR, 0), x1 = min(cu + kOrientR, width - 1), x0 = max(cu - kOrientR, 0);
-        double hsum = 0;
-        if (lane < kBins) {
-            for (int i = y0; i <= y1; ++i)
-                for (int j = x0; j <= x1; ++j) {
-                    double a = angle[(size_t)i * width + j] + kPi / 2;
-                    if (a > kPi) a -= kPi;
-                    int bin = (int)floor(a / (kPi / kBins));
-                    bin = max(min(bin, kBins - 1), 0);
-                    if (bin == lane) hsum += weight[(size_t)i * width + j];
-                }
-            hist[lane] = hsum;
+        // the window (<= 21 x 21) is staged in LDS by all threads, then thread b < 32 owns bin b and adds its pixels in
+        // the reference's order (row by row): the histogram is bit-identical to the sequential one
+        const int ww = x1 - x0 + 1, wn = ww * (y1 - y0 + 1);
+        for (int e = tid; e < wn; e += 256) {
+            const int i = y0 + e / ww, j = x0 + e % ww;
+            double a = angle[(size_t)i * width + j] + kPi / 2;
+            if (a > kPi) a -= kPi;
+            int bin = (int)floor(a / (kPi / kBins));
+            wbin[e] = (unsigned char)max(min(bin, kBins - 1), 0);
+            wwgt[e] = weight[(size_t)i * width + j];
         }
         __syncthreads();
-        if (lane == 0) {
-            // :286-349 (the histogram is circular: indices wrap, see the oracle's header for the reference's out-of-range reads)
-            double sm[kBins];
-            for (int i = 0; i < kBins; ++i) {
-                double sum = 0;
-                for (int j = -2; j <= 2; ++j) sum += hist[((i + j) % kBins + kBins) % kBins] * T->smooth[j + 2];
-                sm[i] = sum;
+        if (tid < kBins) {
+            double hsum = 0;
+            for (int e = 0; e < wn; ++e) if (wbin[e] == tid) hsum += wwgt[e];
+            hist[tid] = hsum;
+        }
+        __syncthreads();
+        // :286-349 (the histogram is circular: indices wrap, see the oracle's header for the reference's out-of-range
+        // reads).  Smoothing and hill climbing: thread i does bin i; the list of distinct modes in discovery order and
+        // its ordering: thread 0, on LDS arrays.
+        if (tid < kBins) {
+            double sum = 0;
+            for (int j = -2; j <= 2; ++j) sum += hist[((tid + j) % kBins + kBins) % kBins] * T->smooth[j + 2];
+            sm[tid] = sum;
+        }
+        __syncthreads();
+        if (tid < kBins) {
+            int j = tid;
+            for (;;) {
+                const double h0 = sm[j];
+                const int j1 = (j + 1) % kBins, j2 = (j - 1 + kBins) % kBins;
+                const double h1 = sm[j1], h2 = sm[j2];
+                if (h1 >= h0 && h1 >= h2) j = j1;
+                else if (h2 > h0 && h2 > h1) j = j2;
+                else break;
             }
+            climb[tid] = j;
+        }
+        __syncthreads();
+        if (tid == 0) {
             bool flat = true;
             for (int i = 1; i < kBins; ++i) if (fabs(sm[i] - sm[0]) > 1e-5) { flat = false; break; }
-            int mb[kBins], nm = 0;
-            double mv[kBins];
+            int nm = 0;
             if (!flat) {
                 for (int i = 0; i < kBins; ++i) {
-                    int j = i;
-                    for (;;) {
-                        const double h0 = sm[j];
-                        const int j1 = (j + 1) % kBins, j2 = (j - 1 + kBins) % kBins;
-                        const double h1 = sm[j1], h2 = sm[j2];
-                        if (h1 >= h0 && h1 >= h2) j = j1;
-                        else if (h2 > h0 && h2 > h1) j = j2;
-                        else break;
-                    }
+                    const int j = climb[i];
                     bool seen = false;
                     for (int k = 0; k < nm; ++k) if (mb[k] == j) { seen = true; break; }
                     if (!seen) { mb[nm] = j; mv[nm] = sm[j]; ++nm; }
@@ -276,73 +405,37 @@ __global__ __launch_bounds__(64) void k_corner_describe(const unsigned char *gra
     // template angles atan2(v.y, v.x) and their sin / cos (:483, :364-365); v = (0, 0): atan2 = 0
     const double s1a = b1 >= 0 ? T->tsin[b1] : 0.0, c1a = b1 >= 0 ? T->tcos[b1] : 1.0;
     const double s2a = b2 >= 0 ? T->tsin[b2] : 0.0, c2a = b2 >= 0 ? T->tcos[b2] : 1.0;
-    // ---- :391-490  correlation score, best of the radii that fit ---------------------------------------------------
-    const double gmn = mm[0], gmx = mm[1];
-    double best = 0;
-    for (int k = 0; k < 3; ++k) {
-        const int r = 8 + 4 * k, n = 2 * r + 1, N = n * n;
-        double s = 0;
-        if (cu >= r && cu < width - r && cv >= r && cv < height - r) {     // wave-uniform
-            auto filt = [&](int x, int y) {
-                const double p0 = x - r, p1 = y - r;
-                const double a = p0 * v1x + p1 * v1y, b = p0 * v2x + p1 * v2y;
-                const double q0 = p0 - a * v1x, q1 = p1 - a * v1y, t0 = p0 - b * v2x, t1 = p1 - b * v2y;
-                return (sqrt(q0 * q0 + q1 * q1) <= 1.5 || sqrt(t0 * t0 + t1 * t1) <= 1.5) ? 1.0 : -1.0;
-            };
-            double sw = 0, sf = 0;
-            for (int e = lane; e < N; e += 64) { const int y = e / n, x = e % n; sw += weight[(size_t)(cv - r + y) * width + (cu - r + x)]; sf += filt(x, y); }
-            const double mw = wave_sum(sw) / N, mf = wave_sum(sf) / N;
-            double vw = 0, vf = 0;
-            for (int e = lane; e < N; e += 64) {
-                const int y = e / n, x = e % n;
-                const double dw = weight[(size_t)(cv - r + y) * width + (cu - r + x)] - mw, df = filt(x, y) - mf;
-                vw += dw * dw; vf += df * df;
-            }
-            const double sdw = sqrt(wave_sum(vw) / N), sdf = sqrt(wave_sum(vf) / N);
-            double cs = 0, t[4] = { 0, 0, 0, 0 }, nr[4] = { 0, 0, 0, 0 };
-            for (int e = lane; e < N; e += 64) {
-                const int y = e / n, x = e % n;
-                cs += ((weight[(size_t)(cv - r + y) * width + (cu - r + x)] - mw) / sdw) * ((filt(x, y) - mf) / sdf);
-                const int du = x - r, dv = y - r;
-                const double e1 = -du * s1a + dv * c1a, e2 = -du * s2a + dv * c2a;
-                int which = -1;
-                if (e1 <= -0.1 && e2 <= -0.1) which = 0;
-                else if (e1 >= 0.1 && e2 >= 0.1) which = 1;
-                else if (e1 <= -0.1 && e2 >= 0.1) which = 2;
-                else if (e1 >= 0.1 && e2 <= -0.1) which = 3;
-                if (which >= 0) {
-                    const double g = T->npdf[k][du * du + dv * dv];
-                    const double px = ((double)gray[(size_t)(cv - r + y) * stride + (cu - r + x)] - gmn) / (gmx - gmn);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) if (m == which) { nr[m] += g; t[m] += g * px; }
-                }
-            }
-            const double score_gradient = fmax(wave_sum(cs) / (N - 1), 0.0);
-            double tt[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) { const double nn = wave_sum(nr[m]), ts = wave_sum(t[m]); tt[m] = nn > 2.220446049250313e-16 ? ts / nn : 0.0; }
-            const double mu = (tt[0] + tt[1] + tt[2] + tt[3]) / 4;
-            const double score_1 = fmin(fmin(tt[0] - mu, tt[1] - mu), fmin(mu - tt[2], mu - tt[3]));
-            const double score_2 = fmin(fmin(mu - tt[0], mu - tt[1]), fmin(tt[2] - mu, tt[3] - mu));
-            s = score_gradient * fmax(fmax(score_1, score_2), 0.0);
-        }
-        if (k == 0 || s > best) best = s;
-    }
-    // ---- :510-539  quadratic fit of the 5x5 neighbourhood of Ixy (lane a < 6: coefficient a, sums in the reference's order)
+    // ---- :391-426  correlation score, best of the radii that fit (block-uniform conditions) ---------------------------
+    int imn, imx;
+    read_extremes(mm, imn, imx);
+    const double gmn = imn, gmx = imx;
+    auto fits = [&](int r) { return cu >= r && cu < width - r && cv >= r && cv < height - r; };
+    double best = 0, sc = 0;
+    if (fits(8)) sc = score_radius<8>(gray, stride, weight, width, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[0], red);
+    best = sc;
+    sc = 0;
+    if (fits(12)) sc = score_radius<12>(gray, stride, weight, width, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[1], red);
+    if (sc > best) best = sc;
+    sc = 0;
+    if (fits(16)) sc = score_radius<16>(gray, stride, weight, width, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[2], red);
+    if (sc > best) best = sc;
+    // ---- :510-539  quadratic fit of the 5x5 neighbourhood of Ixy (thread a < 6: coefficient a, sums in the reference's order)
     double beta = 0;
-    if (lane < 6) {
+    if (tid < 6) {
         int cnt = 0;
         for (int j = cu - 2; j <= cu + 2; ++j)
-            for (int k = cv - 2; k <= cv + 2; ++k) beta += T->X[lane * 25 + cnt++] * Ixy[(size_t)k * width + j];
+            for (int k = cv - 2; k <= cv + 2; ++k) beta += T->X[tid * 25 + cnt++] * Ixy[(size_t)k * width + j];
     }
-    const double A = __shfl(beta, 0), B = __shfl(beta, 1), C = __shfl(beta, 2), D = __shfl(beta, 3), E = __shfl(beta, 4);
-    if (lane == 0) {
-        double x = -(2 * B * C - D * E) / (4 * A * B - E * E);
-        double y = -(2 * A * D - C * E) / (4 * A * B - E * E);
-        if (fabs(x) > 2 || fabs(y) > 2) { x = 0; y = 0; }
-        out_sub[2 * q] = cu + x; out_sub[2 * q + 1] = cv + y;
-        out_score[q] = best;
-        out_v[4 * q] = v1x; out_v[4 * q + 1] = v1y; out_v[4 * q + 2] = v2x; out_v[4 * q + 3] = v2y;
+    if (tid < 64) {
+        const double A = __shfl(beta, 0), B = __shfl(beta, 1), C = __shfl(beta, 2), D = __shfl(beta, 3), E = __shfl(beta, 4);
+        if (tid == 0) {
+            double x = -(2 * B * C - D * E) / (4 * A * B - E * E);
+            double y = -(2 * A * D - C * E) / (4 * A * B - E * E);
+            if (fabs(x) > 2 || fabs(y) > 2) { x = 0; y = 0; }
+            out_sub[2 * q] = cu + x; out_sub[2 * q + 1] = cv + y;
+            out_score[q] = best;
+            out_v[4 * q] = v1x; out_v[4 * q + 1] = v1y; out_v[4 * q + 2] = v2x; out_v[4 * q + 3] = v2y;
+        }
     }
 }
 
@@ -448,14 +541,17 @@ extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int hei
     DevBuf<DescribeTables> d_tab;
     CRN_TRY(d_gray.alloc((size_t)stride * height));
     CRN_TRY(d_angle.alloc(N)); CRN_TRY(d_weight.alloc(N)); CRN_TRY(d_tmp.alloc(N)); CRN_TRY(d_Ig.alloc(N)); CRN_TRY(d_metric.alloc(N)); CRN_TRY(d_Ixy.alloc(N));
-    CRN_TRY(d_taps.alloc(ntap)); CRN_TRY(d_mm.alloc(2)); CRN_TRY(d_cell.alloc(ncell)); CRN_TRY(d_cand.alloc(ncell)); CRN_TRY(d_count.alloc(1));
+    CRN_TRY(d_taps.alloc(ntap)); CRN_TRY(d_mm.alloc((size_t)kMmSlots * kMmStride)); CRN_TRY(d_cell.alloc(ncell)); CRN_TRY(d_cand.alloc(ncell)); CRN_TRY(d_count.alloc(1));
     CRN_TRY(d_tab.alloc(1));
     CRN_TRY(d_v.alloc(4 * (size_t)ncell)); CRN_TRY(d_score.alloc(ncell)); CRN_TRY(d_sub.alloc(2 * (size_t)ncell));
     CRN_TRY(hipMemcpy(d_gray.p, gray, (size_t)stride * height, hipMemcpyHostToDevice));
     CRN_TRY(hipMemcpy(d_taps.p, taps.data(), sizeof(double) * ntap, hipMemcpyHostToDevice));
     CRN_TRY(hipMemcpy(d_tab.p, tab.data(), sizeof(DescribeTables), hipMemcpyHostToDevice));
-    const int mm0[2] = { 255, 0 };
-    CRN_TRY(hipMemcpy(d_mm.p, mm0, sizeof mm0, hipMemcpyHostToDevice));
+    {
+        std::vector<int> mm0((size_t)kMmSlots * kMmStride, 0);
+        for (int q = 0; q < kMmSlots; ++q) { mm0[(size_t)q * kMmStride] = 255; mm0[(size_t)q * kMmStride + 1] = 0; }
+        CRN_TRY(hipMemcpy(d_mm.p, mm0.data(), sizeof(int) * mm0.size(), hipMemcpyHostToDevice));
+    }
     CRN_TRY(hipMemset(d_count.p, 0, sizeof(int)));
 
     hipEvent_t e0, e1;
@@ -473,7 +569,7 @@ extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int hei
         hipLaunchKernelGGL(k_nms_compact, dim3(1), dim3(1024), 0, nullptr, d_cell.p, ncell, ncell, d_cand.p, d_count.p);
         CRN_TRY(hipMemcpy(&n_max, d_count.p, sizeof(int), hipMemcpyDeviceToHost));
         if (n_max > 0)
-            hipLaunchKernelGGL(k_corner_describe, dim3(n_max), dim3(64), 0, nullptr, d_gray.p, stride, d_mm.p, d_angle.p, d_weight.p, d_Ixy.p, width, height, d_cand.p,
+            hipLaunchKernelGGL(k_corner_describe, dim3(n_max), dim3(256), 0, nullptr, d_gray.p, stride, d_mm.p, d_angle.p, d_weight.p, d_Ixy.p, width, height, d_cand.p,
                                d_tab.p, d_v.p, d_score.p, d_sub.p);
     }
     CRN_TRY(hipEventRecord(e1, nullptr));
