@@ -392,6 +392,24 @@ int tscm_detect_corners(const unsigned char *gray, int width, int height, int st
                         tscm_corner_candidates *out);
 void tscm_corner_candidates_free(tscm_corner_candidates *c);
 
+/* ------------------------------------------------------------------ chessboard structure (second stage)
+ * tscm_chessboards_from_corners = chessboardsFromCorners (DetectCorner/chessboard.cpp:3-103): 3x3 seeds around every
+ * candidate, energy-driven growth on the four sides, overlap resolution by energy, boards turned so that
+ * cols >= rows.  Host logic (sequential, a few hundred candidates), input = the lists of tscm_detect_corners
+ * (x, y = pixel of the maximum; v1, v2 = [2n] edge directions).  Board q is the rows[q] x cols[q] row-major matrix of
+ * candidate indices cells[offset[q] .. offset[q + 1]).  findCorner (:67-95) then reads the sub-pixel position of
+ * every board member; main.cpp:33 accepts an image when exactly one board of the expected size came out.
+ */
+typedef struct tscm_chessboards {
+    int n_boards;
+    int *rows, *cols;       /* [n_boards]                         */
+    int *offset;            /* [n_boards + 1] start of each board */
+    int *cells;             /* candidate indices                  */
+} tscm_chessboards;
+
+int tscm_chessboards_from_corners(int n, const double *x, const double *y, const double *v1, const double *v2, tscm_chessboards *out);
+void tscm_chessboards_free(tscm_chessboards *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -390,3 +390,16 @@ def detect_corners(gray, sigma: int = 4, cap: int = 8192, planes: bool = False) 
     if planes:
         out.update(metric=metric, ixy=ixy)
     return out
+
+
+def chessboards_from_corners(x, y, v1, v2, max_boards: int = 16, max_cells: int = 4096) -> list:
+    """DetectCorner/chessboard.cpp:3-103 -> list of index matrices (rows x cols, cols >= rows)."""
+    x, y, v1, v2 = _f(x), _f(y), _f(v1), _f(v2)
+    n = x.shape[0]
+    rows, cols = np.zeros(max_boards, dtype=np.int32), np.zeros(max_boards, dtype=np.int32)
+    cells = np.zeros(max_boards * max_cells, dtype=np.int32)
+    f = lib().orc_chessboards_from_corners
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 3
+    nb = f(n, x.ctypes.data, y.ctypes.data, v1.ctypes.data, v2.ctypes.data, max_boards, max_cells, rows.ctypes.data, cols.ctypes.data, cells.ctypes.data)
+    return [cells[q * max_cells:q * max_cells + rows[q] * cols[q]].reshape(rows[q], cols[q]).copy() for q in range(min(nb, max_boards))]

@@ -224,4 +224,8 @@ void orc_corner_subpixel(const double *Ixy, int width, const double *X, double p
 int orc_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, int cap,
                        double *px, double *py, double *v, double *score, double *sub, double *metric_out, double *ixy_out);
 
+/* ---- chessboard structure recovery (tscm_oracle_boards.c; DetectCorner/chessboard.cpp) ---- */
+int orc_chessboards_from_corners(int n, const double *px, const double *py, const double *v1, const double *v2,
+                                 int max_boards, int max_cells, int *rows, int *cols, int *cells);
+
 #endif

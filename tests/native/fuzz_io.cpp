@@ -4,6 +4,7 @@
 // Every call must return 0 or a negative error code -- never crash, leak or trip a sanitizer.
 #include "tscm/tscm.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -86,6 +87,34 @@ int main(int argc, char **argv)
     }
     std::remove(path.c_str());
     std::remove(mpath.c_str());
+    // ---- chessboard structure recovery (tscm_boards.cpp) on random candidate sets: jittered grids, clutter, degenerate input
+    for (int i = 0; i < rounds / 10; ++i) {
+        const int gw = 3 + rnd() % 8, gh = 3 + rnd() % 6, clutter = rnd() % 12;
+        std::vector<double> x, y, v1, v2;
+        const double ang = (rnd() % 628) / 100.0, step = 20 + rnd() % 40;
+        for (int r = 0; r < gh; ++r)
+            for (int c = 0; c < gw; ++c) {
+                const double jx = (rnd() % 200) / 100.0 - 1.0, jy = (rnd() % 200) / 100.0 - 1.0;
+                x.push_back(300 + step * (c * std::cos(ang) - r * std::sin(ang)) + jx);
+                y.push_back(300 + step * (c * std::sin(ang) + r * std::cos(ang)) + jy);
+                v1.push_back(std::cos(ang)); v1.push_back(std::sin(ang)); v2.push_back(-std::sin(ang)); v2.push_back(std::cos(ang));
+            }
+        for (int k = 0; k < clutter; ++k) {
+            x.push_back(rnd() % 900); y.push_back(rnd() % 900);
+            const double a = (rnd() % 628) / 100.0;
+            v1.push_back(std::cos(a)); v1.push_back(std::sin(a)); v2.push_back(rnd() & 1 ? 0.0 : -std::sin(a)); v2.push_back(rnd() & 1 ? 0.0 : std::cos(a));
+        }
+        if (rnd() % 7 == 0) { x.resize(rnd() % 9); y.resize(x.size()); v1.resize(2 * x.size()); v2.resize(2 * x.size()); }      // fewer than 9 candidates
+        if (rnd() % 9 == 0) for (size_t k = 0; k < x.size(); ++k) { x[k] = 5; y[k] = 5; }                                       // all on one spot
+        tscm_chessboards cb;
+        const int rc = tscm_chessboards_from_corners((int)x.size(), x.data(), y.data(), v1.data(), v2.data(), &cb);
+        if (rc != 0) return 11;
+        for (int q = 0; q < cb.n_boards; ++q) {
+            if (cb.cols[q] < cb.rows[q] || cb.rows[q] < 3) return 12;
+            for (int k = cb.offset[q]; k < cb.offset[q + 1]; ++k) if (cb.cells[k] < 0 || cb.cells[k] >= (int)x.size()) return 13;
+        }
+        tscm_chessboards_free(&cb);
+    }
     std::printf("fuzz_io: %d rounds per parser, clean\n", rounds);
     return 0;
 }

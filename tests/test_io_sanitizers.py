@@ -1,5 +1,5 @@
 """AddressSanitizer + UBSan run of the CPU-only part of the library (tscm_io.cpp: calibration YAML and corner-list
-parsers) under deterministic mutation fuzzing (tests/native/fuzz_io.cpp).  GPU sanitizers are not available on
+parsers; tscm_boards.cpp: chessboard structure recovery on random candidate sets) under deterministic fuzzing (tests/native/fuzz_io.cpp).  GPU sanitizers are not available on
 the pool, so this is where the sanitizers earn their keep: malformed files must come back as error codes."""
 import os
 import shutil
@@ -15,7 +15,8 @@ def test_yaml_and_corner_parsers_under_asan_ubsan(tmp_path):
     exe = tmp_path / "fuzz_io"
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "fuzz_io.cpp"),
-           os.path.join(ROOT, "tscm_calib_amd", "csrc", "tscm_io.cpp"), "-o", str(exe)]
+           os.path.join(ROOT, "tscm_calib_amd", "csrc", "tscm_io.cpp"), os.path.join(ROOT, "tscm_calib_amd", "csrc", "tscm_boards.cpp"),
+           "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "asan" in (r.stderr + r.stdout).lower():
         pytest.skip("sanitizer runtime not installed")

@@ -32,3 +32,36 @@ def detect_corners(gray, sigma: int = 4, min_score: float = 0.01, device: int = 
         fr.restype = None
         fr.argtypes = [C.POINTER(_l.CCornerCandidates)]
         fr(C.byref(out))
+
+
+def chessboards_from_corners(x, y, v1, v2) -> list:
+    """chessboardsFromCorners (DetectCorner/chessboard.cpp:3-103): list of index matrices (rows x cols, cols >= rows)
+    into the candidate list.  Host logic of the library (no device needed)."""
+    x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+    v1, v2 = np.ascontiguousarray(v1, dtype=np.float64), np.ascontiguousarray(v2, dtype=np.float64)
+    out = _l.CChessboards()
+    f = _l.lib().tscm_chessboards_from_corners
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.POINTER(_l.CChessboards)]
+    _l.check(f(int(x.shape[0]), x.ctypes.data, y.ctypes.data, v1.ctypes.data, v2.ctypes.data, C.byref(out)))
+    try:
+        res = []
+        for q in range(out.n_boards):
+            r, c, o = out.rows[q], out.cols[q], out.offset[q]
+            res.append(np.array([out.cells[o + k] for k in range(r * c)], dtype=np.int32).reshape(r, c))
+        return res
+    finally:
+        fr = _l.lib().tscm_chessboards_free
+        fr.restype = None
+        fr.argtypes = [C.POINTER(_l.CChessboards)]
+        fr(C.byref(out))
+
+
+def find_chessboard(gray, cols: int, rows: int, sigma: int = 4, device: int = 0):
+    """The acceptance test of main.cpp:32-46: corner candidates, structure recovery, and -- when exactly one board of
+    cols x rows inner corners came out -- its sub-pixel corners as a (rows * cols, 2) array in board order; else None."""
+    d = detect_corners(gray, sigma=sigma, device=device)
+    boards = chessboards_from_corners(d["x"], d["y"], d["v1"], d["v2"])
+    if len(boards) != 1 or boards[0].shape != (rows, cols):
+        return None
+    return d["sub"][boards[0].ravel()]

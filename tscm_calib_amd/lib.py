@@ -112,7 +112,7 @@ EXPORTS = [
     "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
     "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
-    "tscm_detect_corners", "tscm_corner_candidates_free",
+    "tscm_detect_corners", "tscm_corner_candidates_free", "tscm_chessboards_from_corners", "tscm_chessboards_free",
 ]
 
 
@@ -236,3 +236,9 @@ class CCornerCandidates(C.Structure):
                 ("v1", C.POINTER(C.c_double)), ("v2", C.POINTER(C.c_double)),
                 ("score", C.POINTER(C.c_double)), ("sub", C.POINTER(C.c_double)),
                 ("seconds", C.c_double)]
+
+
+class CChessboards(C.Structure):
+    """tscm_chessboards (tscm.h)"""
+    _fields_ = [("n_boards", C.c_int), ("rows", C.POINTER(C.c_int)), ("cols", C.POINTER(C.c_int)),
+                ("offset", C.POINTER(C.c_int)), ("cells", C.POINTER(C.c_int))]
