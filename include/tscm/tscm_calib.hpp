@@ -386,5 +386,51 @@ private:
     int device_;
 };
 
+// ---- corner detection: findCorner(img, sigma) (DetectCorner/findCorner.cpp:7-101) -------------------------------------
+// Same result structure as the reference (Corner_t / Chessboarder_t, chessboard = matrices of indices into corners.p),
+// grey 8-bit image instead of cv::Mat.  Board members carry their sub-pixel position (findCorner.cpp:84-97).
+struct Corner_t {
+    std::vector<Point2d> p, v1, v2;
+    std::vector<double> score;
+};
+struct IndexMat {
+    int rows, cols;
+    std::vector<unsigned short> data;                 // row-major, CV_16U like the reference
+    unsigned short at(int r, int c) const { return data[(size_t)r * cols + c]; }
+};
+struct Chessboarder_t {
+    Corner_t corners;
+    std::vector<IndexMat> chessboard;
+};
+
+inline Chessboarder_t findCorner(const unsigned char *gray, int width, int height, int stride, int sigma, int device = 0)
+{
+    tscm_corner_candidates c;
+    check(tscm_detect_corners(gray, width, height, stride, sigma, 0.01, device, &c));
+    tscm_chessboards b;
+    const int rc = tscm_chessboards_from_corners(c.n, c.x, c.y, c.v1, c.v2, &b);
+    if (rc != 0) { tscm_corner_candidates_free(&c); check(rc); }
+    Chessboarder_t out;
+    for (int i = 0; i < c.n; ++i) {
+        out.corners.p.push_back(Point2d{ c.x[i], c.y[i] });
+        out.corners.v1.push_back(Point2d{ c.v1[2 * i], c.v1[2 * i + 1] });
+        out.corners.v2.push_back(Point2d{ c.v2[2 * i], c.v2[2 * i + 1] });
+        out.corners.score.push_back(c.score[i]);
+    }
+    for (int q = 0; q < b.n_boards; ++q) {
+        IndexMat m;
+        m.rows = b.rows[q]; m.cols = b.cols[q];
+        for (int k = b.offset[q]; k < b.offset[q + 1]; ++k) {
+            const int idx = b.cells[k];
+            m.data.push_back((unsigned short)idx);
+            out.corners.p[(size_t)idx] = Point2d{ c.sub[2 * idx], c.sub[2 * idx + 1] };
+        }
+        out.chessboard.push_back(m);
+    }
+    tscm_chessboards_free(&b);
+    tscm_corner_candidates_free(&c);
+    return out;
+}
+
 }  // namespace tscm
 #endif

@@ -117,3 +117,23 @@ def test_mono_calibration_from_rendered_images(hip_device):
     # (measured: rmse 0.27 px, fx 432.3 vs 431.3, principal point within 0.35 px, projections within 0.65 px)
     assert abs(q.intr[0][0] / intr_gt[0] - 1) < 0.01 and np.abs(q.intr[0][2:4] - intr_gt[2:4]).max() < 1.0
     assert np.abs(uv_gt - uv_fit).max() < 2.0, np.abs(uv_gt - uv_fit).max()
+
+
+def test_cpp_mirror_find_corner_on_a_pgm(hip_device, tmp_path):
+    """examples/find_corners_demo.cpp: tscm::findCorner of the C++ mirror on a PGM file, same corners as the Python path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "tscm_calib_amd", "csrc")
+    exe = str(tmp_path / "find_corners_demo")
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "find_corners_demo.cpp"),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", exe])
+    img, _ = _scene(3, 0)
+    with open(tmp_path / "board.pgm", "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "board.pgm")]).decode().splitlines()
+    assert out[0].startswith("candidates 54 boards 1")
+    got = np.array([[float(t) for t in line.split()] for line in out[1:]])
+    want = corners.find_chessboard(img, 9, 6, device=hip_device)
+    assert got.shape == (54, 2) and np.allclose(got, want, atol=2e-6)
