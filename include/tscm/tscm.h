@@ -365,6 +365,16 @@ int tscm_corners_write(const char *path, const tscm_corner_set *set);
 int tscm_corners_read(const char *path, tscm_corner_set *set);
 void tscm_corners_free(tscm_corner_set *set);
 
+/* ------------------------------------------------------------------ application of remap tables
+ * tscm_remap = cv::remap(src, dst, mapx, mapy, cv::INTER_LINEAR) with the defaulted border (constant 0) as
+ * TripleSphereCamera::undistort / undistort_chessboard call it (TS.cpp:304, :329) for 8-bit images of 1 or 3
+ * interleaved channels; to_gray != 0 (3 channels): the result is converted like cv::cvtColor(BGR2GRAY)
+ * (findCorner.cpp:9-10 on the remapped chessboard, main.cpp:71) and dst has one channel.  OpenCV's fixed-point
+ * interpolation (coordinates to 1/32 pixel, 15-bit weights).  dst: map_height rows of dst_stride bytes.
+ */
+int tscm_remap(const unsigned char *src, int width, int height, int stride, int channels, const float *mapx, const float *mapy, int map_width,
+               int map_height, int map_stride, int to_gray, int device, unsigned char *dst, int dst_stride);
+
 /* ------------------------------------------------------------------ corner candidates (first stage)
  * tscm_detect_corners  = findCorner() up to and including its score filter (DetectCorner/findCorner.cpp:7-66:
  *                        gradient angle / weight, secondDerivCornerMetric :103-142, nonMaximumSuppression(cxy + c45,

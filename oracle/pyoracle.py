@@ -403,3 +403,18 @@ def chessboards_from_corners(x, y, v1, v2, max_boards: int = 16, max_cells: int 
     f.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 3
     nb = f(n, x.ctypes.data, y.ctypes.data, v1.ctypes.data, v2.ctypes.data, max_boards, max_cells, rows.ctypes.data, cols.ctypes.data, cells.ctypes.data)
     return [cells[q * max_cells:q * max_cells + rows[q] * cols[q]].reshape(rows[q], cols[q]).copy() for q in range(min(nb, max_boards))]
+
+
+def remap(src, mapx, mapy, to_gray: bool = False) -> np.ndarray:
+    """cv::remap(src, dst, mapx, mapy, INTER_LINEAR) for uint8 images (H, W) or (H, W, 3); to_gray: BGR2GRAY of the result."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    mapx, mapy = np.ascontiguousarray(mapx, dtype=np.float32), np.ascontiguousarray(mapy, dtype=np.float32)
+    mh, mw = mapx.shape
+    out_ch = 1 if (to_gray or ch == 1) else ch
+    dst = np.zeros((mh, mw) if out_ch == 1 else (mh, mw, out_ch), dtype=np.uint8)
+    f = lib().orc_remap_bilinear
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    f(src.ctypes.data, src.shape[1], src.shape[0], src.strides[0], ch, mapx.ctypes.data, mapy.ctypes.data, mw, mh, mw, int(bool(to_gray)), dst.ctypes.data, dst.strides[0])
+    return dst

@@ -228,4 +228,8 @@ int orc_detect_corners(const unsigned char *gray, int width, int height, int str
 int orc_chessboards_from_corners(int n, const double *px, const double *py, const double *v1, const double *v2,
                                  int max_boards, int max_cells, int *rows, int *cols, int *cells);
 
+/* ---- cv::remap(INTER_LINEAR) + BGR2GRAY (tscm_oracle_remap.c) ---- */
+void orc_remap_bilinear(const unsigned char *src, int w, int h, int stride, int channels, const float *mapx, const float *mapy, int map_w, int map_h,
+                        int map_stride, int to_gray, unsigned char *dst, int dst_stride);
+
 #endif

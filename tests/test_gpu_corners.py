@@ -137,3 +137,37 @@ def test_cpp_mirror_find_corner_on_a_pgm(hip_device, tmp_path):
     got = np.array([[float(t) for t in line.split()] for line in out[1:]])
     want = corners.find_chessboard(img, 9, 6, device=hip_device)
     assert got.shape == (54, 2) and np.allclose(got, want, atol=2e-6)
+
+
+def test_second_pass_on_the_remapped_chessboard(hip_device):
+    """The refinement pass of monocular_calib (main.cpp:59-105): with the board pose known, undistort_chessboard
+    (TS.cpp:308-330: table + cv::remap) turns the view into a fronto-parallel chessboard, findCorner runs on it, and the
+    refined corners go back through [r1 r2 t] and project().  On the rendering they land closer to the truth."""
+    from tscm_calib_amd import maps
+    p = synth.make_problem(1, 6, 3, noise_px=0.0, perturb=False)
+    intr = p.meta["gt_intr"][0]
+    k = 0
+    rt = p.meta["gt_board_rt"][k]
+    img, uv = _scene(3, k)
+    first = corners.find_chessboard(img, 9, 6, device=hip_device)
+    assert first is not None
+    R = synth.rodrigues(rt[:3])
+    Rt = np.stack([R[:, 0], R[:, 1], rt[3:]], axis=1)                       # TS.cpp:316: [r1 r2 t]
+    desc = maps.chessboard_desc(intr, Rt, 9, 6, 45.0)
+    mx, my, _ = maps.build_maps([desc], 450 * 315, hip_device)
+    board_img = maps.remap(img, mx.reshape(315, 450), my.reshape(315, 450), device=hip_device)
+    assert np.array_equal(board_img, orc.remap(img, mx.reshape(315, 450), my.reshape(315, 450)))
+    second = corners.find_chessboard(board_img, 9, 6, device=hip_device)
+    assert second is not None
+    # fronto-parallel image: the inner corners sit on the 45-pixel grid starting at (45, 45) (main.cpp:99-100)
+    grid = np.stack(np.meshgrid(np.arange(9), np.arange(6)), axis=-1).reshape(-1, 2) * 45.0 + 45.0
+    fwd, rev = np.abs(second - grid).max(), np.abs(second[::-1] - grid).max()
+    assert min(fwd, rev) < 0.6
+    if rev < fwd:
+        second = second[::-1]
+    # back to the image: P = Rt (x - 45, y - 45, 1), project (main.cpp:99-102)
+    P = (Rt @ np.concatenate([second - 45.0, np.ones((54, 1))], axis=1).T).T
+    back = np.stack([orc.project(intr, q) for q in P])
+    e1 = min(np.abs(first - uv).max(), np.abs(first[::-1] - uv).max())
+    e2 = np.abs(back - uv).max()
+    assert e2 < 0.25 and e2 <= e1 + 0.05, (e1, e2)

@@ -109,3 +109,36 @@ def test_random_table_geometries(hip_device, seed):
     assert np.all(fx_[~written] == 0.0) and np.all(fy_[~written & (oy == 0.0)] == 0.0)
     _check_fast(fx_, ox)
     _check_fast(fy_, oy)
+
+
+@pytest.mark.parametrize("channels,to_gray", [(1, False), (3, False), (3, True)])
+def test_remap_is_bit_identical_to_the_oracle(hip_device, channels, to_gray):
+    """tscm_remap = cv::remap(INTER_LINEAR, border 0) [+ BGR2GRAY]: integer arithmetic, exact."""
+    rng = np.random.default_rng(17 + channels)
+    h, w = 97, 131
+    src = rng.integers(0, 256, size=(h, w) if channels == 1 else (h, w, 3), dtype=np.uint8)
+    mh, mw = 60, 83
+    mapx = rng.uniform(-6, w + 5, size=(mh, mw)).astype(np.float32)
+    mapy = rng.uniform(-6, h + 5, size=(mh, mw)).astype(np.float32)
+    mapx[0, :10] = np.arange(10)                                   # exact pixel positions, image corners, far outside
+    mapy[0, :10] = 3.0
+    mapx[1, :4] = [0.0, w - 1.0, -1.0, 1e6]
+    mapy[1, :4] = [0.0, h - 1.0, h - 0.5, -1e6]
+    g = maps.remap(src, mapx, mapy, to_gray=to_gray, device=hip_device)
+    o = orc.remap(src, mapx, mapy, to_gray=to_gray)
+    assert g.shape == o.shape and np.array_equal(g, o)
+    if channels == 1:
+        assert np.array_equal(g[0, :10], src[3, :10])              # integer coordinates reproduce the pixels
+
+
+def test_remap_with_an_undistortion_table(hip_device):
+    """undistort (TS.cpp:284-306) end to end: table on the GPU, applied on the GPU; a straight board edge of the
+    rendering becomes straight."""
+    p = synth.make_problem(1, 4, 3, noise_px=0.0, perturb=False)
+    intr = p.meta["gt_intr"][0]
+    img = synth.render_chessboard(intr, p.meta["gt_board_rt"][0], 9, 6, 45.0, 1280, 1080, supersample=1)
+    d = maps.undistort_desc(intr, 300.0, 300.0, 639.5, 539.5, 1280, 1080)
+    mx, my, _ = maps.build_maps([d], 1280 * 1080, hip_device)
+    und = maps.remap(img, mx.reshape(1080, 1280), my.reshape(1080, 1280), device=hip_device)
+    assert und.shape == (1080, 1280) and np.array_equal(und, orc.remap(img, mx.reshape(1080, 1280), my.reshape(1080, 1280)))
+    assert und.std() > 5

@@ -171,3 +171,80 @@ extern "C" int tscm_build_maps(const tscm_map_desc *maps, int n_maps, int device
     MAP_TRY(hipMemcpy(mapy, d_y.p, sizeof(float) * n_elems, hipMemcpyDeviceToHost));
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// cv::remap(src, dst, mapx, mapy, INTER_LINEAR) for 8-bit images (TS.cpp:304, :329), border constant 0, optionally
+// followed by BGR2GRAY (findCorner.cpp:9-10).  OpenCV's fixed-point scheme (see oracle/tscm_oracle_remap.c): map
+// coordinates rounded to 1/32 pixel, 15-bit weights, (sum + 2^14) >> 15.  Integer arithmetic: bit-identical to the oracle.
+namespace {
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_remap(const unsigned char *src, int w, int h, int stride, const float *mapx, const float *mapy, int map_w, int map_h,
+                                               int to_gray, unsigned char *dst, int dst_stride)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= map_w) return;
+    const int sx = __float2int_rn(mapx[(size_t)i * map_w + j] * 32.0f), sy = __float2int_rn(mapy[(size_t)i * map_w + j] * 32.0f);
+    const int ix = max(-32768, min(32767, sx >> 5)), iy = max(-32768, min(32767, sy >> 5));
+    const int fx = sx & 31, fy = sy & 31;
+    int wgt[4] = { 32 * (32 - fx) * (32 - fy), 32 * fx * (32 - fy), 32 * (32 - fx) * fy, 32 * fx * fy };
+    if (wgt[0] == 32768) { wgt[0] = 32767; wgt[3] = 1; }
+    int px[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = ix + (k & 1), y = iy + (k >> 1);
+            const int p = (x >= 0 && x < w && y >= 0 && y < h) ? src[(size_t)y * stride + (size_t)x * CH + c] : 0;
+            acc += wgt[k] * p;
+        }
+        px[c] = max(0, min(255, (acc + (1 << 14)) >> 15));
+    }
+    if (CH == 3 && to_gray) dst[(size_t)i * dst_stride + j] = (unsigned char)((px[0] * 1868 + px[CH > 1 ? 1 : 0] * 9617 + px[CH > 2 ? 2 : 0] * 4899 + (1 << 13)) >> 14);
+    else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) dst[(size_t)i * dst_stride + (size_t)j * CH + c] = (unsigned char)px[c];
+    }
+}
+
+struct DevBytes {
+    void *p = nullptr;
+    ~DevBytes() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" int tscm_remap(const unsigned char *src, int width, int height, int stride, int channels, const float *mapx, const float *mapy, int map_width,
+                          int map_height, int map_stride, int to_gray, int device, unsigned char *dst, int dst_stride)
+{
+    if (!src || !mapx || !mapy || !dst) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    if (channels != 1 && channels != 3) return tscm_set_error(TSCM_E_UNSUPPORTED, "remap: 1 or 3 channels");
+    const int out_ch = (to_gray || channels == 1) ? 1 : channels;
+    if (width < 1 || height < 1 || stride < width * channels || map_width < 0 || map_height < 0 || map_stride < map_width || dst_stride < map_width * out_ch)
+        return tscm_set_error(TSCM_E_INVALID, "bad image / map description");
+    if (width > 32767 || height > 32767) return tscm_set_error(TSCM_E_UNSUPPORTED, "images beyond 32767 pixels per side");
+    if (map_width == 0 || map_height == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tscm_set_error(TSCM_E_NO_DEVICE, "no HIP device available (remap has no CPU fallback)");
+    if (device < 0 || device >= ndev) return tscm_set_error(TSCM_E_NO_DEVICE, "device index out of range");
+    MAP_TRY(hipSetDevice(device));
+    DevBytes d_src, d_mx, d_my, d_dst;
+    const size_t nmap = (size_t)map_width * map_height, dst_row = (size_t)map_width * out_ch;
+    MAP_TRY(hipMalloc(&d_src.p, (size_t)stride * height));
+    MAP_TRY(hipMalloc(&d_mx.p, nmap * sizeof(float))); MAP_TRY(hipMalloc(&d_my.p, nmap * sizeof(float)));
+    MAP_TRY(hipMalloc(&d_dst.p, dst_row * map_height));
+    MAP_TRY(hipMemcpy(d_src.p, src, (size_t)stride * height, hipMemcpyHostToDevice));
+    MAP_TRY(hipMemcpy2D(d_mx.p, (size_t)map_width * sizeof(float), mapx, (size_t)map_stride * sizeof(float), (size_t)map_width * sizeof(float), map_height, hipMemcpyHostToDevice));
+    MAP_TRY(hipMemcpy2D(d_my.p, (size_t)map_width * sizeof(float), mapy, (size_t)map_stride * sizeof(float), (size_t)map_width * sizeof(float), map_height, hipMemcpyHostToDevice));
+    const dim3 grid((map_width + 255) / 256, map_height);
+    if (channels == 1)
+        hipLaunchKernelGGL(k_remap<1>, grid, dim3(256), 0, nullptr, static_cast<const unsigned char *>(d_src.p), width, height, stride, static_cast<const float *>(d_mx.p),
+                           static_cast<const float *>(d_my.p), map_width, map_height, 0, static_cast<unsigned char *>(d_dst.p), (int)dst_row);
+    else
+        hipLaunchKernelGGL(k_remap<3>, grid, dim3(256), 0, nullptr, static_cast<const unsigned char *>(d_src.p), width, height, stride, static_cast<const float *>(d_mx.p),
+                           static_cast<const float *>(d_my.p), map_width, map_height, to_gray ? 1 : 0, static_cast<unsigned char *>(d_dst.p), (int)dst_row);
+    MAP_TRY(hipGetLastError());
+    MAP_TRY(hipMemcpy2D(dst, (size_t)dst_stride, d_dst.p, dst_row, dst_row, map_height, hipMemcpyDeviceToHost));
+    return 0;
+}

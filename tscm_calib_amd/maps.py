@@ -104,3 +104,24 @@ def build_maps(descs, n_elems: int | None = None, device: int = 0, exact: bool =
     _lib.check(_lib.lib().tscm_build_maps(arr, len(descs), device, 1 if exact else 0, mapx.ctypes.data_as(fp),
                                            mapy.ctypes.data_as(fp), n_elems, C.cast(C.byref(sec), C.POINTER(C.c_double))))
     return mapx, mapy, sec.value
+
+
+def remap(src, mapx, mapy, to_gray: bool = False, device: int = 0) -> np.ndarray:
+    """cv::remap(src, dst, mapx, mapy, INTER_LINEAR) on the GPU (TS.cpp:304, :329) for uint8 images (H, W) or
+    (H, W, 3) and float32 tables of the output size; to_gray: BGR2GRAY of the result (findCorner.cpp:9-10)."""
+    import ctypes as C
+    from . import lib as _l
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    mapx, mapy = np.ascontiguousarray(mapx, dtype=np.float32), np.ascontiguousarray(mapy, dtype=np.float32)
+    if mapx.shape != mapy.shape or mapx.ndim != 2:
+        raise ValueError("mapx and mapy must be 2-D tables of the same shape")
+    mh, mw = mapx.shape
+    out_ch = 1 if (to_gray or ch == 1) else ch
+    dst = np.zeros((mh, mw) if out_ch == 1 else (mh, mw, out_ch), dtype=np.uint8)
+    f = _l.lib().tscm_remap
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    _l.check(f(src.ctypes.data, src.shape[1], src.shape[0], src.strides[0], ch, mapx.ctypes.data, mapy.ctypes.data, mw, mh, mw, int(bool(to_gray)), int(device),
+               dst.ctypes.data, dst.strides[0] if mh else mw * out_ch))
+    return dst
