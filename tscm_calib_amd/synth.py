@@ -372,8 +372,11 @@ def render_chessboard(intr, board_rt, cols: int, rows: int, pitch: float, width:
     (i * pitch, j * pitch, 0), i.e. (cols + 1) x (rows + 1) squares, seen through the Triple Sphere model with the
     board pose board_rt (angle-axis + translation, board -> camera).  Every pixel is the mean of supersample^2 rays
     intersected with the board plane.  Test / demo data for the corner detector."""
-    R = rodrigues(np.asarray(board_rt[:3], dtype=np.float64))
-    t = np.asarray(board_rt[3:], dtype=np.float64)
+    if isinstance(board_rt, tuple):                    # (R, t) given directly
+        R, t = np.asarray(board_rt[0], dtype=np.float64), np.asarray(board_rt[1], dtype=np.float64)
+    else:
+        R = rodrigues(np.asarray(board_rt[:3], dtype=np.float64))
+        t = np.asarray(board_rt[3:], dtype=np.float64)
     n = R[:, 2]                                        # board normal in camera coordinates
     ss = supersample
     offs = (np.arange(ss) + 0.5) / ss - 0.5
