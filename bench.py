@@ -59,6 +59,20 @@ def run_iterations(solver, n_iter, **extra):
     return s
 
 
+def _grid_delta(intr_gpu, intr_cpu, device):
+    """Rays of a 25 x 21 grid of pixels (1280 x 1080 image) under the GPU-fitted model, projected with the CPU-fitted
+    one: the largest pixel displacement, over all cameras."""
+    uu, vv = np.meshgrid(np.linspace(40, 1240, 25), np.linspace(40, 1040, 21))
+    px = np.stack([uu.ravel(), vv.ravel()], axis=1)
+    worst = 0.0
+    for a, b in zip(intr_gpu, intr_cpu):
+        rays = api.unproject(a, px, device)
+        ok = np.all(np.isfinite(rays), axis=1)
+        d = api.project(b, rays[ok], device) - px[ok]
+        worst = max(worst, float(np.max(np.hypot(d[:, 0], d[:, 1]))))
+    return worst
+
+
 def cpu_baseline(full_problem, device):
     """Oracle (port of the reference's Ceres DENSE_SCHUR LM, 1 thread) on the first 1/8 of the
     frames of the same workload, termination disabled, scaled to the full corner count.  The GPU
@@ -85,6 +99,8 @@ def cpu_baseline(full_problem, device):
         "rmse_px_cpu": rmse_cpu, "rmse_px_gpu_same_sample": g["rmse"],
         "rmse_rel_delta": abs(g["rmse"] - rmse_cpu) / rmse_cpu,
         "max_rel_intrinsics_delta": float(np.max(np.abs(gsub.intr[:, :7] - sub.intr[:, :7]) / np.abs(sub.intr[:, :7]))),
+        # SURVEY 8d parity procedure: pixel-space difference of the two fitted models over a 25 x 21 image grid
+        "max_pixel_delta_25x21_grid": _grid_delta(gsub.intr, sub.intr, device),
     }
 
 
