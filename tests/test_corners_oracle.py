@@ -70,3 +70,29 @@ def test_odd_sigma_is_refused():
     img = np.zeros((64, 64), dtype=np.uint8)
     with pytest.raises(RuntimeError):
         orc.detect_corners(img, sigma=3)
+
+
+def _golden():
+    import base64
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "corners_small.json")))
+    img = np.frombuffer(base64.b64decode(g["image_b64"]), dtype=np.uint8).reshape(g["height"], g["width"]).copy()
+    return g, img
+
+
+def test_oracle_reproduces_the_committed_fixture():
+    """tests/golden/corners_small.json (made by make_corners_golden.py): maxima, directions, boards exact; scores and
+    sub-pixel positions to the last digits (libm differences between machines stay below 1e-12)."""
+    g, img = _golden()
+    d = orc.detect_corners(img)
+    assert d["n"] == g["n_maxima"]
+    assert np.array_equal(d["x"], g["x"]) and np.array_equal(d["y"], g["y"])
+    assert np.allclose(d["v1"], g["v1"], atol=1e-15) and np.allclose(d["v2"], g["v2"], atol=1e-15)
+    assert np.allclose(d["score"], g["score"], rtol=1e-12, atol=1e-16) and np.allclose(d["sub"], g["sub"], atol=1e-11)
+    keep = d["score"] >= 0.01
+    boards = orc.chessboards_from_corners(d["x"][keep], d["y"][keep], d["v1"][keep], d["v2"][keep])
+    assert [b.tolist() for b in boards] == g["boards"]
+    truth = np.array(g["truth"])
+    det = d["sub"][keep][np.array(g["boards"][0]).ravel()]
+    assert min(np.abs(det - truth).max(), np.abs(det[::-1] - truth).max()) < 0.2

@@ -171,3 +171,16 @@ def test_second_pass_on_the_remapped_chessboard(hip_device):
     e1 = min(np.abs(first - uv).max(), np.abs(first[::-1] - uv).max())
     e2 = np.abs(back - uv).max()
     assert e2 < 0.25 and e2 <= e1 + 0.05, (e1, e2)
+
+
+def test_gpu_reproduces_the_committed_fixture(hip_device):
+    from tests.test_corners_oracle import _golden
+    g, img = _golden()
+    d = corners.detect_corners(img, min_score=-1.0, device=hip_device)
+    assert d["n_maxima"] == g["n_maxima"]
+    assert np.array_equal(d["x"], g["x"]) and np.array_equal(d["y"], g["y"])
+    assert np.allclose(d["v1"], g["v1"], atol=1e-15) and np.allclose(d["v2"], g["v2"], atol=1e-15)
+    assert np.allclose(d["score"], g["score"], rtol=1e-10, atol=1e-14) and np.allclose(d["sub"], g["sub"], atol=1e-9)
+    keep = d["score"] >= 0.01
+    boards = corners.chessboards_from_corners(d["x"][keep], d["y"][keep], d["v1"][keep], d["v2"][keep])
+    assert [b.tolist() for b in boards] == g["boards"]
