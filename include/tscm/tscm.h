@@ -400,6 +400,11 @@ typedef struct tscm_corner_candidates {
 
 int tscm_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, double min_score, int device,
                         tscm_corner_candidates *out);
+/* The same for n_images images of one size in ONE pass of the kernels (a calibration run detects on every image of
+ * every camera: main.cpp:24-50): out[n_images], each freed with tscm_corner_candidates_free; out[i].seconds is the
+ * image's share of the batch's device time.  Results are identical to n_images single calls. */
+int tscm_detect_corners_batch(const unsigned char *const *images, int n_images, int width, int height, int stride, int sigma, double min_score,
+                              int device, tscm_corner_candidates *out);
 void tscm_corner_candidates_free(tscm_corner_candidates *c);
 
 /* ------------------------------------------------------------------ chessboard structure (second stage)

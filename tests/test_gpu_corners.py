@@ -184,3 +184,20 @@ def test_gpu_reproduces_the_committed_fixture(hip_device):
     keep = d["score"] >= 0.01
     boards = corners.chessboards_from_corners(d["x"][keep], d["y"][keep], d["v1"][keep], d["v2"][keep])
     assert [b.tolist() for b in boards] == g["boards"]
+
+
+def test_batch_equals_single_calls(hip_device):
+    rng = np.random.default_rng(5)
+    full = [_scene(3, v)[0] for v in (0, 1, 2)]
+    imgs = [np.ascontiguousarray(f[300:300 + 420, 380:380 + 560]) for f in full]
+    imgs.append(np.full((420, 560), 99, dtype=np.uint8))                                       # nothing to find
+    imgs.append(np.clip(imgs[0].astype(int) + rng.integers(-9, 10, size=imgs[0].shape), 0, 255).astype(np.uint8))
+    batch = corners.detect_corners_batch(imgs, min_score=-1.0, device=hip_device)
+    assert len(batch) == len(imgs)
+    for g, im in zip(batch, imgs):
+        s = corners.detect_corners(im, min_score=-1.0, device=hip_device)
+        assert g["n"] == s["n"] and g["n_maxima"] == s["n_maxima"]
+        for k in ("x", "y", "v1", "v2", "score", "sub"):
+            assert np.array_equal(g[k], s[k]), k
+    assert batch[3]["n"] == 0 and batch[0]["n"] > 0
+    assert corners.detect_corners_batch([], device=hip_device) == []

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--repeats", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--batch", type=int, default=32, help="images per tscm_detect_corners_batch call (second measurement)")
     a = ap.parse_args()
     p = synth.make_problem(1, 6, 3, noise_px=0.0, perturb=False)
     img = synth.render_chessboard(p.meta["gt_intr"][0], p.meta["gt_board_rt"][0], 9, 6, 45.0, a.width, a.height, supersample=2)
@@ -46,6 +47,20 @@ def main():
                device_ms=1e3 * sec, call_ms_incl_alloc_and_copies=1e3 * float(np.median(wall)), candidates=int(d["n"]), maxima=int(d["n_maxima"]),
                roofline=dict(bound="hbm", achieved=BYTES_PER_PIXEL * npix / sec / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                              frac=BYTES_PER_PIXEL * npix / sec / 1e9 / PEAK_HBM_GBS, traffic=None))
+    if a.batch > 1:
+        imgs = [img] * a.batch
+        corners.detect_corners_batch(imgs)
+        bdev, bwall = [], []
+        for _ in range(max(3, a.repeats // 6)):
+            t0 = time.perf_counter()
+            r = corners.detect_corners_batch(imgs)
+            bwall.append(time.perf_counter() - t0)
+            bdev.append(sum(x["seconds"] for x in r))
+        bsec = float(np.median(bdev)) / a.batch
+        out["batched"] = dict(images_per_call=a.batch, value=1.0 / bsec, unit="images/s", device_ms_per_image=1e3 * bsec,
+                              call_ms_per_image_incl_copies=1e3 * float(np.median(bwall)) / a.batch,
+                              roofline=dict(bound="hbm", achieved=BYTES_PER_PIXEL * npix / bsec / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                                            frac=BYTES_PER_PIXEL * npix / bsec / 1e9 / PEAK_HBM_GBS, traffic=None))
     if not a.no_cpu:
         from oracle import pyoracle as orc
         t0 = time.perf_counter()

@@ -34,6 +34,39 @@ def detect_corners(gray, sigma: int = 4, min_score: float = 0.01, device: int = 
         fr(C.byref(out))
 
 
+def _unpack(out) -> dict:
+    n = out.n
+    arr = lambda p, k: np.ctypeslib.as_array(p, shape=(n * k,)).copy().reshape(n, k) if n else np.zeros((0, k))
+    return dict(n=n, n_maxima=out.n_maxima, x=arr(out.x, 1)[:, 0], y=arr(out.y, 1)[:, 0], v1=arr(out.v1, 2), v2=arr(out.v2, 2),
+                score=arr(out.score, 1)[:, 0], sub=arr(out.sub, 2), seconds=out.seconds)
+
+
+def detect_corners_batch(images, sigma: int = 4, min_score: float = 0.01, device: int = 0) -> list:
+    """tscm_detect_corners_batch: a list of (H, W) uint8 images of one size -> list of candidate dicts, one pass of the
+    kernels for all of them."""
+    imgs = [np.ascontiguousarray(g) for g in images]
+    if not imgs:
+        return []
+    h, w = imgs[0].shape
+    if any(g.ndim != 2 or g.dtype != np.uint8 or g.shape != (h, w) for g in imgs):
+        raise ValueError("detect_corners_batch expects 2-D uint8 images of one size")
+    n = len(imgs)
+    ptrs = (C.c_void_p * n)(*[g.ctypes.data for g in imgs])
+    outs = (_l.CCornerCandidates * n)()
+    f = _l.lib().tscm_detect_corners_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    _l.check(f(ptrs, n, w, h, w, int(sigma), float(min_score), int(device), outs))
+    fr = _l.lib().tscm_corner_candidates_free
+    fr.restype = None
+    fr.argtypes = [C.POINTER(_l.CCornerCandidates)]
+    try:
+        return [_unpack(outs[i]) for i in range(n)]
+    finally:
+        for i in range(n):
+            fr(C.byref(outs[i]))
+
+
 def chessboards_from_corners(x, y, v1, v2) -> list:
     """chessboardsFromCorners (DetectCorner/chessboard.cpp:3-103): list of index matrices (rows x cols, cols >= rows)
     into the candidate list.  Host logic of the library (no device needed)."""

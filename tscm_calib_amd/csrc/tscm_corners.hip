@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -70,8 +71,10 @@ __device__ __forceinline__ void read_extremes(const int *mm, int &mn, int &mx)
 
 // findCorner.cpp:8-29.  grid ceil(w*h/256) x 256; mm: kMmSlots x (min, max) of the grey values
 __global__ __launch_bounds__(256) void k_corner_gradients(const unsigned char *gray, int w, int h, int stride, AtanConsts ac,
-                                                          double *angle, double *weight, int *mm)
+                                                          double *angle, double *weight, int *mm, size_t plane)
 {
+    // blockIdx.y = image of the batch: planes are `plane` pixels apart, grey images stride * h bytes
+    gray += (size_t)blockIdx.y * stride * h; angle += blockIdx.y * plane; weight += blockIdx.y * plane; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
     const long o = (long)blockIdx.x * 256 + threadIdx.x;
     int g = -1;
     if (o < (long)w * h) {
@@ -106,8 +109,9 @@ __global__ __launch_bounds__(256) void k_corner_gradients(const unsigned char *g
 
 // rows of GaussianBlur on the normalised image (img - min) / (max - min) (:30-34, :106).  grid (ceil(w/256), h)
 __global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, int w, int h, int stride, const int *mm, const double *taps, int n,
-                                                    double *tmp)
+                                                    double *tmp, size_t plane)
 {
+    gray += (size_t)blockIdx.z * stride * h; mm += (size_t)blockIdx.z * kMmSlots * kMmStride; tmp += blockIdx.z * plane;
     __shared__ double lut[256], k[64];
     int imn, imx;
     read_extremes(mm, imn, imx);
@@ -125,8 +129,9 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, i
 }
 
 // columns (symmetric kernel: centre tap, then pairs).  grid (ceil(w/256), h)
-__global__ __launch_bounds__(256) void k_gauss_cols(const double *tmp, int w, int h, const double *taps, int n, double *Ig)
+__global__ __launch_bounds__(256) void k_gauss_cols(const double *tmp, int w, int h, const double *taps, int n, double *Ig, size_t plane)
 {
+    tmp += blockIdx.z * plane; Ig += blockIdx.z * plane;
     __shared__ double k[64];
     if (threadIdx.x < n) k[threadIdx.x] = taps[threadIdx.x];
     __syncthreads();
@@ -141,8 +146,9 @@ __global__ __launch_bounds__(256) void k_gauss_cols(const double *tmp, int w, in
 // secondDerivCornerMetric :108-141 fused: every intermediate plane (Ix, Iy, I_45, ...) is a reflected 3-tap stencil of
 // the previous one, so each output pixel reads a 5x5 neighbourhood of Ig.  grid (ceil(w/256), h)
 __global__ __launch_bounds__(256) void k_corner_metric(const double *Ig, int w, int h, int sigma, double c4, double cn4, double s4, double sn4,
-                                                       double *metric, double *Ixy)
+                                                       double *metric, double *Ixy, size_t plane)
 {
+    Ig += blockIdx.z * plane; metric += blockIdx.z * plane; Ixy += blockIdx.z * plane;
     const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= w) return;
     auto G = [&](int r, int c) { return Ig[(size_t)r * w + c]; };
@@ -166,8 +172,9 @@ __global__ __launch_bounds__(256) void k_corner_metric(const double *Ig, int w, 
 
 // nonMaximumSuppression :144-193, one thread per cell; cells are numbered column-major like the reference's loops
 // (x outer, y inner).  cell[c] = (maxi << 16) | maxj, or -1.
-__global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width, int height, int ncx, int ncy, int *cell)
+__global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width, int height, int ncx, int ncy, int *cell, size_t plane)
 {
+    img += blockIdx.y * plane; cell += (size_t)blockIdx.y * ncx * ncy;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= ncx * ncy) return;
     constexpr int n = kNmsN, margin = kNmsMargin;
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width,
 // count[0] = number of maxima
 __global__ __launch_bounds__(1024) void k_nms_compact(const int *cell, int ncell, int cap, int *cand, int *count)
 {
+    cell += (size_t)blockIdx.x * ncell; cand += (size_t)blockIdx.x * ncell; count += blockIdx.x;          // one workgroup per image
     __shared__ int wtot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = ((ncell + 15) / 16 + 63) & ~63;           // cells per wave, whole 64-cell steps
@@ -316,8 +324,13 @@ __device__ __forceinline__ double score_radius(const unsigned char *gray, int st
 // getOrientations + scoreCorners + subPixelLocation for one candidate per 256-thread workgroup
 __global__ __launch_bounds__(256) void k_corner_describe(const unsigned char *gray, int stride, const int *mm, const double *angle, const double *weight,
                                                          const double *Ixy, int width, int height, const int *cand, const DescribeTables *T,
-                                                         double *out_v, double *out_score, double *out_sub)
+                                                         double *out_v, double *out_score, double *out_sub, size_t plane, int ncell, const int *count)
 {
+    // blockIdx.y = image; candidates past this image's count (the grid is sized for the fullest image): nothing to do
+    if ((int)blockIdx.x >= count[blockIdx.y]) return;
+    gray += (size_t)blockIdx.y * stride * height; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
+    angle += blockIdx.y * plane; weight += blockIdx.y * plane; Ixy += blockIdx.y * plane;
+    cand += (size_t)blockIdx.y * ncell; out_v += (size_t)blockIdx.y * 4 * ncell; out_score += (size_t)blockIdx.y * ncell; out_sub += (size_t)blockIdx.y * 2 * ncell;
     __shared__ double hist[kBins], sm[kBins], mv[kBins], vsh[4], red[36];
     __shared__ int bsh[2], climb[kBins], mb[kBins];
     __shared__ double wwgt[(2 * kOrientR + 1) * (2 * kOrientR + 1)];
@@ -474,12 +487,15 @@ extern "C" void tscm_corner_candidates_free(tscm_corner_candidates *c)
     c->n = 0;
 }
 
-extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, double min_score, int device,
-                                   tscm_corner_candidates *out)
+extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int n_images, int width, int height, int stride, int sigma, double min_score,
+                                         int device, tscm_corner_candidates *out)
 {
-    if (!out) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
-    std::memset(out, 0, sizeof(*out));
-    if (!gray || width < 1 || height < 1 || stride < width) return tscm_set_error(TSCM_E_INVALID, "bad image description");
+    if (n_images < 0 || (n_images > 0 && (!out || !images))) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    if (n_images == 0) return 0;
+    std::memset(out, 0, sizeof(*out) * (size_t)n_images);
+    for (int q = 0; q < n_images; ++q) if (!images[q]) return tscm_set_error(TSCM_E_INVALID, "NULL image");
+    if (width < 1 || height < 1 || stride < width) return tscm_set_error(TSCM_E_INVALID, "bad image description");
+    if (n_images > 65535) return tscm_set_error(TSCM_E_UNSUPPORTED, "more than 65535 images per batch");
     if (width > 32767 || height > 32767) return tscm_set_error(TSCM_E_UNSUPPORTED, "images beyond 32767 pixels per side");
     const int ntap = 7 * sigma + 1;
     if (sigma < 1 || ntap % 2 == 0 || ntap > 64) return tscm_set_error(TSCM_E_UNSUPPORTED, "sigma must be even and at most 8 (cv::GaussianBlur needs an odd 7 sigma + 1; the reference uses 4)");
@@ -554,50 +570,55 @@ extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int hei
     if (device >= 16) return tscm_set_error(TSCM_E_UNSUPPORTED, "device index beyond 15");
     Arena &arena = g_arena[device];
     std::lock_guard<std::mutex> lock(arena.mu);
-    const size_t cells_n = (size_t)(ncell > 0 ? ncell : 1);
-    const size_t need = 256 * 24 + (size_t)stride * height + 6 * N * sizeof(double) + 64 * sizeof(double) + (size_t)kMmSlots * kMmStride * sizeof(int)
-                      + 2 * cells_n * sizeof(int) + 256 + sizeof(DescribeTables) + 7 * cells_n * sizeof(double);
+    const size_t B = (size_t)n_images;
+    const size_t cells_n = (size_t)(ncell > 0 ? ncell : 1) * B;
+    const size_t gbytes = (size_t)stride * height;
+    const size_t need = 256 * 24 + B * gbytes + 6 * B * N * sizeof(double) + 64 * sizeof(double) + B * kMmSlots * kMmStride * sizeof(int)
+                      + 2 * cells_n * sizeof(int) + B * sizeof(int) + sizeof(DescribeTables) + 7 * cells_n * sizeof(double);
     if (arena.bytes < need) {
         if (arena.base) { (void)hipFree(arena.base); arena.base = nullptr; arena.bytes = 0; }
         CRN_TRY(hipMalloc(&arena.base, need));
         arena.bytes = need;
     }
     ArenaCursor cur = { static_cast<char *>(arena.base), arena.bytes };
-    struct { unsigned char *p; } d_gray = { cur.take<unsigned char>((size_t)stride * height) };
-    struct { double *p; } d_angle = { cur.take<double>(N) }, d_weight = { cur.take<double>(N) }, d_tmp = { cur.take<double>(N) }, d_Ig = { cur.take<double>(N) },
-                          d_metric = { cur.take<double>(N) }, d_Ixy = { cur.take<double>(N) }, d_taps = { cur.take<double>(64) },
+    struct { unsigned char *p; } d_gray = { cur.take<unsigned char>(B * gbytes) };
+    struct { double *p; } d_angle = { cur.take<double>(B * N) }, d_weight = { cur.take<double>(B * N) }, d_tmp = { cur.take<double>(B * N) }, d_Ig = { cur.take<double>(B * N) },
+                          d_metric = { cur.take<double>(B * N) }, d_Ixy = { cur.take<double>(B * N) }, d_taps = { cur.take<double>(64) },
                           d_v = { cur.take<double>(4 * cells_n) }, d_score = { cur.take<double>(cells_n) }, d_sub = { cur.take<double>(2 * cells_n) };
-    struct { int *p; } d_mm = { cur.take<int>((size_t)kMmSlots * kMmStride) }, d_cell = { cur.take<int>(cells_n) }, d_cand = { cur.take<int>(cells_n) },
-                       d_count = { cur.take<int>(1) };
+    struct { int *p; } d_mm = { cur.take<int>(B * kMmSlots * kMmStride) }, d_cell = { cur.take<int>(cells_n) }, d_cand = { cur.take<int>(cells_n) },
+                       d_count = { cur.take<int>(B) };
     struct { DescribeTables *p; } d_tab = { cur.take<DescribeTables>(1) };
     if (!d_tab.p || !d_count.p || !d_sub.p) return tscm_set_error(TSCM_E_HIP, "internal error: arena too small");
-    CRN_TRY(hipMemcpy(d_gray.p, gray, (size_t)stride * height, hipMemcpyHostToDevice));
+    for (size_t q = 0; q < B; ++q) CRN_TRY(hipMemcpy(d_gray.p + q * gbytes, images[q], gbytes, hipMemcpyHostToDevice));
     CRN_TRY(hipMemcpy(d_taps.p, taps.data(), sizeof(double) * ntap, hipMemcpyHostToDevice));
     CRN_TRY(hipMemcpy(d_tab.p, tab.data(), sizeof(DescribeTables), hipMemcpyHostToDevice));
     {
-        std::vector<int> mm0((size_t)kMmSlots * kMmStride, 0);
-        for (int q = 0; q < kMmSlots; ++q) { mm0[(size_t)q * kMmStride] = 255; mm0[(size_t)q * kMmStride + 1] = 0; }
+        std::vector<int> mm0(B * kMmSlots * kMmStride, 0);
+        for (size_t q = 0; q < B * kMmSlots; ++q) { mm0[q * kMmStride] = 255; mm0[q * kMmStride + 1] = 0; }
         CRN_TRY(hipMemcpy(d_mm.p, mm0.data(), sizeof(int) * mm0.size(), hipMemcpyHostToDevice));
     }
-    CRN_TRY(hipMemset(d_count.p, 0, sizeof(int)));
+    CRN_TRY(hipMemset(d_count.p, 0, sizeof(int) * B));
 
     hipEvent_t e0, e1;
     CRN_TRY(hipEventCreate(&e0)); CRN_TRY(hipEventCreate(&e1));
     CRN_TRY(hipEventRecord(e0, nullptr));
-    const dim3 grid2((width + 255) / 256, height);
-    hipLaunchKernelGGL(k_corner_gradients, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, d_gray.p, width, height, stride, ac, d_angle.p, d_weight.p, d_mm.p);
-    hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p);
-    hipLaunchKernelGGL(k_gauss_cols, grid2, dim3(256), 0, nullptr, d_tmp.p, width, height, d_taps.p, ntap, d_Ig.p);
+    const dim3 grid2((width + 255) / 256, height, n_images);
+    hipLaunchKernelGGL(k_corner_gradients, dim3((unsigned)((N + 255) / 256), n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, ac, d_angle.p, d_weight.p,
+                       d_mm.p, N);
+    hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p, N);
+    hipLaunchKernelGGL(k_gauss_cols, grid2, dim3(256), 0, nullptr, d_tmp.p, width, height, d_taps.p, ntap, d_Ig.p, N);
     hipLaunchKernelGGL(k_corner_metric, grid2, dim3(256), 0, nullptr, d_Ig.p, width, height, sigma, std::cos(kPi / 4), std::cos(-kPi / 4), std::sin(kPi / 4),
-                       std::sin(-kPi / 4), d_metric.p, d_Ixy.p);
-    int n_max = 0;
+                       std::sin(-kPi / 4), d_metric.p, d_Ixy.p, N);
+    std::vector<int> counts(B, 0);
+    int n_top = 0;
     if (ncell > 0) {
-        hipLaunchKernelGGL(k_nms_cells, dim3((ncell + 255) / 256), dim3(256), 0, nullptr, d_metric.p, width, height, ncx, ncy, d_cell.p);
-        hipLaunchKernelGGL(k_nms_compact, dim3(1), dim3(1024), 0, nullptr, d_cell.p, ncell, ncell, d_cand.p, d_count.p);
-        CRN_TRY(hipMemcpy(&n_max, d_count.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (n_max > 0)
-            hipLaunchKernelGGL(k_corner_describe, dim3(n_max), dim3(256), 0, nullptr, d_gray.p, stride, d_mm.p, d_angle.p, d_weight.p, d_Ixy.p, width, height, d_cand.p,
-                               d_tab.p, d_v.p, d_score.p, d_sub.p);
+        hipLaunchKernelGGL(k_nms_cells, dim3((ncell + 255) / 256, n_images), dim3(256), 0, nullptr, d_metric.p, width, height, ncx, ncy, d_cell.p, N);
+        hipLaunchKernelGGL(k_nms_compact, dim3(n_images), dim3(1024), 0, nullptr, d_cell.p, ncell, ncell, d_cand.p, d_count.p);
+        CRN_TRY(hipMemcpy(counts.data(), d_count.p, sizeof(int) * B, hipMemcpyDeviceToHost));
+        for (int c : counts) n_top = std::max(n_top, c);
+        if (n_top > 0)
+            hipLaunchKernelGGL(k_corner_describe, dim3(n_top, n_images), dim3(256), 0, nullptr, d_gray.p, stride, d_mm.p, d_angle.p, d_weight.p, d_Ixy.p, width, height,
+                               d_cand.p, d_tab.p, d_v.p, d_score.p, d_sub.p, N, ncell, d_count.p);
     }
     CRN_TRY(hipEventRecord(e1, nullptr));
     CRN_TRY(hipEventSynchronize(e1));
@@ -605,34 +626,49 @@ extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int hei
     float ms = 0;
     CRN_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    out->seconds = ms * 1e-3;
-    out->n_maxima = n_max;
-
-    // ---- score filter (findCorner.cpp:47-66), order preserved ------------------------------------------------------
-    std::vector<int> cand(n_max);
-    std::vector<double> v(4 * (size_t)n_max), score(n_max), sub(2 * (size_t)n_max);
-    if (n_max > 0) {
-        CRN_TRY(hipMemcpy(cand.data(), d_cand.p, sizeof(int) * n_max, hipMemcpyDeviceToHost));
-        CRN_TRY(hipMemcpy(v.data(), d_v.p, sizeof(double) * 4 * n_max, hipMemcpyDeviceToHost));
-        CRN_TRY(hipMemcpy(score.data(), d_score.p, sizeof(double) * n_max, hipMemcpyDeviceToHost));
-        CRN_TRY(hipMemcpy(sub.data(), d_sub.p, sizeof(double) * 2 * n_max, hipMemcpyDeviceToHost));
+    // ---- score filter (findCorner.cpp:47-66) per image, order preserved ---------------------------------------------
+    for (size_t b = 0; b < B; ++b) {
+        tscm_corner_candidates *o = out + b;
+        const int n_max = counts[b];
+        o->seconds = ms * 1e-3 / (double)B;          // share of the batch's device time
+        o->n_maxima = n_max;
+        std::vector<int> cand(n_max);
+        std::vector<double> v(4 * (size_t)n_max), score(n_max), sub(2 * (size_t)n_max);
+        if (n_max > 0) {
+            CRN_TRY(hipMemcpy(cand.data(), d_cand.p + b * ncell, sizeof(int) * n_max, hipMemcpyDeviceToHost));
+            CRN_TRY(hipMemcpy(v.data(), d_v.p + b * 4 * ncell, sizeof(double) * 4 * n_max, hipMemcpyDeviceToHost));
+            CRN_TRY(hipMemcpy(score.data(), d_score.p + b * ncell, sizeof(double) * n_max, hipMemcpyDeviceToHost));
+            CRN_TRY(hipMemcpy(sub.data(), d_sub.p + b * 2 * ncell, sizeof(double) * 2 * n_max, hipMemcpyDeviceToHost));
+        }
+        int keep = 0;
+        for (int q = 0; q < n_max; ++q) if (!(score[q] < min_score)) ++keep;
+        const size_t kk = keep ? keep : 1;
+        o->x = static_cast<double *>(std::calloc(kk, sizeof(double))); o->y = static_cast<double *>(std::calloc(kk, sizeof(double)));
+        o->v1 = static_cast<double *>(std::calloc(2 * kk, sizeof(double))); o->v2 = static_cast<double *>(std::calloc(2 * kk, sizeof(double)));
+        o->score = static_cast<double *>(std::calloc(kk, sizeof(double))); o->sub = static_cast<double *>(std::calloc(2 * kk, sizeof(double)));
+        if (!o->x || !o->y || !o->v1 || !o->v2 || !o->score || !o->sub) {
+            for (size_t q = 0; q <= b; ++q) tscm_corner_candidates_free(out + q);
+            return tscm_set_error(TSCM_E_NOMEM, "out of memory");
+        }
+        int w = 0;
+        for (int q = 0; q < n_max; ++q) {
+            if (score[q] < min_score) continue;
+            o->x[w] = cand[q] >> 16; o->y[w] = cand[q] & 0xffff;
+            o->v1[2 * w] = v[4 * q]; o->v1[2 * w + 1] = v[4 * q + 1]; o->v2[2 * w] = v[4 * q + 2]; o->v2[2 * w + 1] = v[4 * q + 3];
+            o->score[w] = score[q];
+            o->sub[2 * w] = sub[2 * q]; o->sub[2 * w + 1] = sub[2 * q + 1];
+            ++w;
+        }
+        o->n = keep;
     }
-    int keep = 0;
-    for (int q = 0; q < n_max; ++q) if (!(score[q] < min_score)) ++keep;
-    const size_t kk = keep ? keep : 1;
-    out->x = static_cast<double *>(std::calloc(kk, sizeof(double))); out->y = static_cast<double *>(std::calloc(kk, sizeof(double)));
-    out->v1 = static_cast<double *>(std::calloc(2 * kk, sizeof(double))); out->v2 = static_cast<double *>(std::calloc(2 * kk, sizeof(double)));
-    out->score = static_cast<double *>(std::calloc(kk, sizeof(double))); out->sub = static_cast<double *>(std::calloc(2 * kk, sizeof(double)));
-    if (!out->x || !out->y || !out->v1 || !out->v2 || !out->score || !out->sub) { tscm_corner_candidates_free(out); return tscm_set_error(TSCM_E_NOMEM, "out of memory"); }
-    int w = 0;
-    for (int q = 0; q < n_max; ++q) {
-        if (score[q] < min_score) continue;
-        out->x[w] = cand[q] >> 16; out->y[w] = cand[q] & 0xffff;
-        out->v1[2 * w] = v[4 * q]; out->v1[2 * w + 1] = v[4 * q + 1]; out->v2[2 * w] = v[4 * q + 2]; out->v2[2 * w + 1] = v[4 * q + 3];
-        out->score[w] = score[q];
-        out->sub[2 * w] = sub[2 * q]; out->sub[2 * w + 1] = sub[2 * q + 1];
-        ++w;
-    }
-    out->n = keep;
     return 0;
+}
+
+extern "C" int tscm_detect_corners(const unsigned char *gray, int width, int height, int stride, int sigma, double min_score, int device,
+                                   tscm_corner_candidates *out)
+{
+    if (!out) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    if (!gray) return tscm_set_error(TSCM_E_INVALID, "bad image description");
+    return tscm_detect_corners_batch(&gray, 1, width, height, stride, sigma, min_score, device, out);
 }

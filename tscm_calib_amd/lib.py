@@ -112,7 +112,7 @@ EXPORTS = [
     "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
     "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
-    "tscm_detect_corners", "tscm_corner_candidates_free", "tscm_chessboards_from_corners", "tscm_chessboards_free", "tscm_remap",
+    "tscm_detect_corners", "tscm_detect_corners_batch", "tscm_corner_candidates_free", "tscm_chessboards_from_corners", "tscm_chessboards_free", "tscm_remap",
 ]
 
 
