@@ -69,36 +69,42 @@ __device__ __forceinline__ void read_extremes(const int *mm, int &mn, int &mx)
     for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
 }
 
-// findCorner.cpp:8-29.  grid ceil(w*h/256) x 256; mm: kMmSlots x (min, max) of the grey values
-__global__ __launch_bounds__(256) void k_corner_gradients(const unsigned char *gray, int w, int h, int stride, AtanConsts ac,
-                                                          double *angle, double *weight, int *mm, size_t plane)
+// findCorner.cpp:8-29, evaluated where it is needed: the edge angle in [0, pi] and the gradient magnitude of pixel (i, j)
+// from the 3x3 derivative filters on the raw grey values (BORDER_REFLECT_101).  Only the 21 x 21 / 33 x 33 windows
+// around the ~100 maxima ever read these planes, so they are not materialised for the other 1.4 M pixels.
+__device__ __forceinline__ void pixel_gradient(const unsigned char *gray, int w, int h, int stride, int i, int j, double &du, double &dv)
 {
-    // blockIdx.y = image of the batch: planes are `plane` pixels apart, grey images stride * h bytes
-    gray += (size_t)blockIdx.y * stride * h; angle += blockIdx.y * plane; weight += blockIdx.y * plane; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
-    const long o = (long)blockIdx.x * 256 + threadIdx.x;
-    int g = -1;
-    if (o < (long)w * h) {
-        const int i = (int)(o / w), j = (int)(o % w);
-        const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
-        const unsigned char *rm = gray + (size_t)im * stride, *r0 = gray + (size_t)i * stride, *rp = gray + (size_t)ip * stride;
-        const double du = ((double)rm[jp] - rm[jm]) + ((double)r0[jp] - r0[jm]) + ((double)rp[jp] - rp[jm]);
-        const double dv = ((double)rp[jm] - rm[jm]) + ((double)rp[j] - rm[j]) + ((double)rp[jp] - rm[jp]);
-        double a;
-        if (dv == 0.0) a = du < 0.0 ? ac.zn : 0.0;
-        else if (du == 0.0) a = dv > 0.0 ? ac.p0 : ac.n0;
-        else if (fabs(du) == fabs(dv)) a = dv > 0.0 ? (du > 0.0 ? ac.pp : ac.pn) : (du > 0.0 ? ac.np : ac.nn);
-        else a = atan2(dv, du);
-        if (a < 0) a += kPi;
-        if (a > kPi) a -= kPi;
-        angle[o] = a;
-        weight[o] = sqrt(dv * dv + du * du);
-        g = r0[j];
+    const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
+    const unsigned char *rm = gray + (size_t)im * stride, *r0 = gray + (size_t)i * stride, *rp = gray + (size_t)ip * stride;
+    du = ((double)rm[jp] - rm[jm]) + ((double)r0[jp] - r0[jm]) + ((double)rp[jp] - rp[jm]);
+    dv = ((double)rp[jm] - rm[jm]) + ((double)rp[j] - rm[j]) + ((double)rp[jp] - rm[jp]);
+}
+__device__ __forceinline__ double edge_angle(double du, double dv, const AtanConsts &ac)
+{
+    double a;
+    if (dv == 0.0) a = du < 0.0 ? ac.zn : 0.0;
+    else if (du == 0.0) a = dv > 0.0 ? ac.p0 : ac.n0;
+    else if (fabs(du) == fabs(dv)) a = dv > 0.0 ? (du > 0.0 ? ac.pp : ac.pn) : (du > 0.0 ? ac.np : ac.nn);
+    else a = atan2(dv, du);
+    if (a < 0) a += kPi;
+    if (a > kPi) a -= kPi;
+    return a;
+}
+
+// min and max of the grey values (normalisation of :30-34).  grid (ceil(w*h/1024), n_images) x 256, four pixels per thread
+__global__ __launch_bounds__(256) void k_grey_extremes(const unsigned char *gray, int w, int h, int stride, int *mm)
+{
+    gray += (size_t)blockIdx.y * stride * h; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
+    int mn = 255, mx = 0;
+    const long base = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (int k = 0; k < 4; ++k) {
+        const long o = base + k;
+        if (o < (long)w * h) { const int g = gray[(size_t)(o / w) * stride + (o % w)]; mn = min(mn, g); mx = max(mx, g); }
     }
-    int mn = g < 0 ? 255 : g, mx = g < 0 ? 0 : g;
     for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
     // one atomic pair per wave only while it can still move the extremes (a plain read of a monotone value: a stale
-    // one merely costs a redundant atomic) -- unconditional atomics on two addresses serialise 21 k waves: 0.5 ms
-    // ... and the waves are spread over kMmSlots slots on separate cache lines (the consumers reduce the slots)
+    // one merely costs a redundant atomic), spread over kMmSlots slots on separate cache lines (the consumers reduce
+    // the slots): unconditional atomics on two addresses serialise 21 k waves -- 0.5 ms
     if ((threadIdx.x & 63) == 0) {
         int *slot = mm + kMmStride * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMmSlots - 1));
         const volatile int *cur = slot;
@@ -258,7 +264,7 @@ __device__ __forceinline__ void block_sum4(double (&v)[NV], double *sh)      // 
 
 // cornerCorrelationScore :428-490 (+ createCorrelationPatch :351-389) for one radius, by the whole 256-thread block
 template <int R>
-__device__ __forceinline__ double score_radius(const unsigned char *gray, int stride, const double *weight, int width, int cu, int cv, double gmn, double gmx,
+__device__ __forceinline__ double score_radius(const unsigned char *gray, int stride, int width, int height, int cu, int cv, double gmn, double gmx,
                                                double v1x, double v1y, double v2x, double v2y, double s1a, double c1a, double s2a, double c2a,
                                                const double *npdf, double *sh)
 {
@@ -275,7 +281,9 @@ __device__ __forceinline__ double score_radius(const unsigned char *gray, int st
             const double a = p0 * v1x + p1 * v1y, b = p0 * v2x + p1 * v2y;
             const double q0 = p0 - a * v1x, q1 = p1 - a * v1y, t0 = p0 - b * v2x, t1 = p1 - b * v2y;
             fv[u] = (sqrt(q0 * q0 + q1 * q1) <= 1.5 || sqrt(t0 * t0 + t1 * t1) <= 1.5) ? 1.0 : -1.0;
-            wv[u] = weight[(size_t)(cv - R + y) * width + (cu - R + x)];
+            double du, dv;
+            pixel_gradient(gray, width, height, stride, cv - R + y, cu - R + x, du, dv);
+            wv[u] = sqrt(dv * dv + du * du);
             acc2[0] += wv[u]; acc2[1] += fv[u];
         }
     }
@@ -322,14 +330,14 @@ __device__ __forceinline__ double score_radius(const unsigned char *gray, int st
 }
 
 // getOrientations + scoreCorners + subPixelLocation for one candidate per 256-thread workgroup
-__global__ __launch_bounds__(256) void k_corner_describe(const unsigned char *gray, int stride, const int *mm, const double *angle, const double *weight,
+__global__ __launch_bounds__(256) void k_corner_describe(const unsigned char *gray, int stride, const int *mm, AtanConsts ac,
                                                          const double *Ixy, int width, int height, const int *cand, const DescribeTables *T,
                                                          double *out_v, double *out_score, double *out_sub, size_t plane, int ncell, const int *count)
 {
     // blockIdx.y = image; candidates past this image's count (the grid is sized for the fullest image): nothing to do
     if ((int)blockIdx.x >= count[blockIdx.y]) return;
     gray += (size_t)blockIdx.y * stride * height; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
-    angle += blockIdx.y * plane; weight += blockIdx.y * plane; Ixy += blockIdx.y * plane;
+    Ixy += blockIdx.y * plane;
     cand += (size_t)blockIdx.y * ncell; out_v += (size_t)blockIdx.y * 4 * ncell; out_score += (size_t)blockIdx.y * ncell; out_sub += (size_t)blockIdx.y * 2 * ncell;
     __shared__ double hist[kBins], sm[kBins], mv[kBins], vsh[4], red[36];
     __shared__ int bsh[2], climb[kBins], mb[kBins];
@@ -345,11 +353,13 @@ __global__ __launch_bounds__(256) void k_corner_describe(const unsigned char *gr
         const int ww = x1 - x0 + 1, wn = ww * (y1 - y0 + 1);
         for (int e = tid; e < wn; e += 256) {
             const int i = y0 + e / ww, j = x0 + e % ww;
-            double a = angle[(size_t)i * width + j] + kPi / 2;
+            double du, dv;
+            pixel_gradient(gray, width, height, stride, i, j, du, dv);
+            double a = edge_angle(du, dv, ac) + kPi / 2;
             if (a > kPi) a -= kPi;
             int bin = (int)floor(a / (kPi / kBins));
             wbin[e] = (unsigned char)max(min(bin, kBins - 1), 0);
-            wwgt[e] = weight[(size_t)i * width + j];
+            wwgt[e] = sqrt(dv * dv + du * du);
         }
         __syncthreads();
         if (tid < kBins) {
@@ -426,13 +436,13 @@ __global__ __launch_bounds__(256) void k_corner_describe(const unsigned char *gr
     const double gmn = imn, gmx = imx;
     auto fits = [&](int r) { return cu >= r && cu < width - r && cv >= r && cv < height - r; };
     double best = 0, sc = 0;
-    if (fits(8)) sc = score_radius<8>(gray, stride, weight, width, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[0], red);
+    if (fits(8)) sc = score_radius<8>(gray, stride, width, height, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[0], red);
     best = sc;
     sc = 0;
-    if (fits(12)) sc = score_radius<12>(gray, stride, weight, width, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[1], red);
+    if (fits(12)) sc = score_radius<12>(gray, stride, width, height, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[1], red);
     if (sc > best) best = sc;
     sc = 0;
-    if (fits(16)) sc = score_radius<16>(gray, stride, weight, width, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[2], red);
+    if (fits(16)) sc = score_radius<16>(gray, stride, width, height, cu, cv, gmn, gmx, v1x, v1y, v2x, v2y, s1a, c1a, s2a, c2a, T->npdf[2], red);
     if (sc > best) best = sc;
     // ---- :510-539  quadratic fit of the 5x5 neighbourhood of Ixy (thread a < 6: coefficient a, sums in the reference's order)
     double beta = 0;
@@ -573,7 +583,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     const size_t B = (size_t)n_images;
     const size_t cells_n = (size_t)(ncell > 0 ? ncell : 1) * B;
     const size_t gbytes = (size_t)stride * height;
-    const size_t need = 256 * 24 + B * gbytes + 6 * B * N * sizeof(double) + 64 * sizeof(double) + B * kMmSlots * kMmStride * sizeof(int)
+    const size_t need = 256 * 24 + B * gbytes + 4 * B * N * sizeof(double) + 64 * sizeof(double) + B * kMmSlots * kMmStride * sizeof(int)
                       + 2 * cells_n * sizeof(int) + B * sizeof(int) + sizeof(DescribeTables) + 7 * cells_n * sizeof(double);
     if (arena.bytes < need) {
         if (arena.base) { (void)hipFree(arena.base); arena.base = nullptr; arena.bytes = 0; }
@@ -582,7 +592,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     }
     ArenaCursor cur = { static_cast<char *>(arena.base), arena.bytes };
     struct { unsigned char *p; } d_gray = { cur.take<unsigned char>(B * gbytes) };
-    struct { double *p; } d_angle = { cur.take<double>(B * N) }, d_weight = { cur.take<double>(B * N) }, d_tmp = { cur.take<double>(B * N) }, d_Ig = { cur.take<double>(B * N) },
+    struct { double *p; } d_tmp = { cur.take<double>(B * N) }, d_Ig = { cur.take<double>(B * N) },
                           d_metric = { cur.take<double>(B * N) }, d_Ixy = { cur.take<double>(B * N) }, d_taps = { cur.take<double>(64) },
                           d_v = { cur.take<double>(4 * cells_n) }, d_score = { cur.take<double>(cells_n) }, d_sub = { cur.take<double>(2 * cells_n) };
     struct { int *p; } d_mm = { cur.take<int>(B * kMmSlots * kMmStride) }, d_cell = { cur.take<int>(cells_n) }, d_cand = { cur.take<int>(cells_n) },
@@ -603,8 +613,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     CRN_TRY(hipEventCreate(&e0)); CRN_TRY(hipEventCreate(&e1));
     CRN_TRY(hipEventRecord(e0, nullptr));
     const dim3 grid2((width + 255) / 256, height, n_images);
-    hipLaunchKernelGGL(k_corner_gradients, dim3((unsigned)((N + 255) / 256), n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, ac, d_angle.p, d_weight.p,
-                       d_mm.p, N);
+    hipLaunchKernelGGL(k_grey_extremes, dim3((unsigned)((N + 1023) / 1024), n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p);
     hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p, N);
     hipLaunchKernelGGL(k_gauss_cols, grid2, dim3(256), 0, nullptr, d_tmp.p, width, height, d_taps.p, ntap, d_Ig.p, N);
     hipLaunchKernelGGL(k_corner_metric, grid2, dim3(256), 0, nullptr, d_Ig.p, width, height, sigma, std::cos(kPi / 4), std::cos(-kPi / 4), std::sin(kPi / 4),
@@ -617,7 +626,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
         CRN_TRY(hipMemcpy(counts.data(), d_count.p, sizeof(int) * B, hipMemcpyDeviceToHost));
         for (int c : counts) n_top = std::max(n_top, c);
         if (n_top > 0)
-            hipLaunchKernelGGL(k_corner_describe, dim3(n_top, n_images), dim3(256), 0, nullptr, d_gray.p, stride, d_mm.p, d_angle.p, d_weight.p, d_Ixy.p, width, height,
+            hipLaunchKernelGGL(k_corner_describe, dim3(n_top, n_images), dim3(256), 0, nullptr, d_gray.p, stride, d_mm.p, ac, d_Ixy.p, width, height,
                                d_cand.p, d_tab.p, d_v.p, d_score.p, d_sub.p, N, ncell, d_count.p);
     }
     CRN_TRY(hipEventRecord(e1, nullptr));
