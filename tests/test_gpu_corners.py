@@ -201,3 +201,12 @@ def test_batch_equals_single_calls(hip_device):
             assert np.array_equal(g[k], s[k]), k
     assert batch[3]["n"] == 0 and batch[0]["n"] > 0
     assert corners.detect_corners_batch([], device=hip_device) == []
+
+
+@pytest.mark.parametrize("sigma", [2, 6])
+def test_other_sigmas_use_the_generic_column_pass(hip_device, sigma):
+    full, _ = _scene(3, 0)
+    img = np.ascontiguousarray(full[200:200 + 500, 300:300 + 700])
+    g = corners.detect_corners(img, sigma=sigma, min_score=-1.0, device=hip_device)
+    o = orc.detect_corners(img, sigma=sigma)
+    _compare(g, o, min_score=-1.0)
