@@ -91,22 +91,21 @@ __device__ __forceinline__ double edge_angle(double du, double dv, const AtanCon
     return a;
 }
 
-// min and max of the grey values (normalisation of :30-34).  grid (ceil(w*h/1024), n_images) x 256, four pixels per thread
+// min and max of the grey values (normalisation of :30-34).  grid (ceil(w/4096), h, n_images) x 256, 16 pixels of a row per thread
 __global__ __launch_bounds__(256) void k_grey_extremes(const unsigned char *gray, int w, int h, int stride, int *mm)
 {
-    gray += (size_t)blockIdx.y * stride * h; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
+    gray += (size_t)blockIdx.z * stride * h; mm += (size_t)blockIdx.z * kMmSlots * kMmStride;
     int mn = 255, mx = 0;
-    const long base = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    for (int k = 0; k < 4; ++k) {
-        const long o = base + k;
-        if (o < (long)w * h) { const int g = gray[(size_t)(o / w) * stride + (o % w)]; mn = min(mn, g); mx = max(mx, g); }
-    }
+    const unsigned char *row = gray + (size_t)blockIdx.y * stride;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (j0 + k < w) { const int g = row[j0 + k]; mn = min(mn, g); mx = max(mx, g); }
     for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
     // one atomic pair per wave only while it can still move the extremes (a plain read of a monotone value: a stale
     // one merely costs a redundant atomic), spread over kMmSlots slots on separate cache lines (the consumers reduce
     // the slots): unconditional atomics on two addresses serialise 21 k waves -- 0.5 ms
     if ((threadIdx.x & 63) == 0) {
-        int *slot = mm + kMmStride * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMmSlots - 1));
+        int *slot = mm + kMmStride * (((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & (kMmSlots - 1));
         const volatile int *cur = slot;
         if (mn < cur[0]) atomicMin(&slot[0], mn);
         if (mx > cur[1]) atomicMax(&slot[1], mx);
@@ -124,12 +123,15 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, i
     int imn, imx;
     read_extremes(mm, imn, imx);
     const double mn = imn, mx = imx;
+    __shared__ double lut[256];
+    lut[threadIdx.x] = ((double)threadIdx.x - mn) / (mx - mn);          // one division per thread instead of one per staged pixel
     if (threadIdx.x < n) k[threadIdx.x] = taps[threadIdx.x];
+    __syncthreads();
     const int i = blockIdx.y, j0 = blockIdx.x * 256, half = n / 2;
     const unsigned char *row = gray + (size_t)i * stride;
     for (int e = threadIdx.x; e < 256 + n - 1; e += 256) {
         const int c = j0 + e - half;
-        seg[e] = c < w + half ? ((double)row[refl101(c, w)] - mn) / (mx - mn) : 0.0;
+        seg[e] = c < w + half ? lut[row[(c >= 0 && c < w) ? c : refl101(c, w)]] : 0.0;
     }
     __syncthreads();
     const int j = j0 + threadIdx.x;
@@ -202,14 +204,28 @@ __global__ __launch_bounds__(256) void k_corner_metric(const double *Ig, int w, 
     const int j = j0 + threadIdx.x;
     if (j >= w) return;
     auto G = [&](int r, int c) { return tile[r - (i - 2)][c - (j0 - 2)]; };
-    auto IX = [&](int r, int c) { return G(r, refl101(c - 1, w)) - G(r, refl101(c + 1, w)); };       // du = (1 0 -1)
-    auto IY = [&](int r, int c) { return G(refl101(r - 1, h), c) - G(refl101(r + 1, h), c); };
-    auto I45 = [&](int r, int c) { return IX(r, c) * c4 + IY(r, c) * s4; };
-    const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
-    const double ix = IX(i, j), iy = IY(i, j), i45 = ix * c4 + iy * s4;
-    const double ixy = IX(im, j) - IX(ip, j);
-    const double i45x = I45(i, jm) - I45(i, jp);
-    const double i45y = I45(im, j) - I45(ip, j);
+    double ix, iy, i45, ixy, i45x, i45y;
+    if (i >= 2 && i < h - 2 && j >= 2 && j < w - 2) {
+        // interior: no reflection, fixed tile offsets (t(dr, dc) = Ig(i + dr, j + dc)); same operations in the same order
+        const int tc = threadIdx.x + 2;
+        auto t = [&](int dr, int dc) { return tile[2 + dr][tc + dc]; };
+        auto ixo = [&](int dr, int dc) { return t(dr, dc - 1) - t(dr, dc + 1); };
+        auto iyo = [&](int dr, int dc) { return t(dr - 1, dc) - t(dr + 1, dc); };
+        auto i45o = [&](int dr, int dc) { return ixo(dr, dc) * c4 + iyo(dr, dc) * s4; };
+        ix = ixo(0, 0); iy = iyo(0, 0); i45 = ix * c4 + iy * s4;
+        ixy = ixo(-1, 0) - ixo(1, 0);
+        i45x = i45o(0, -1) - i45o(0, 1);
+        i45y = i45o(-1, 0) - i45o(1, 0);
+    } else {
+        auto IX = [&](int r, int c) { return G(r, refl101(c - 1, w)) - G(r, refl101(c + 1, w)); };       // du = (1 0 -1)
+        auto IY = [&](int r, int c) { return G(refl101(r - 1, h), c) - G(refl101(r + 1, h), c); };
+        auto I45 = [&](int r, int c) { return IX(r, c) * c4 + IY(r, c) * s4; };
+        const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
+        ix = IX(i, j); iy = IY(i, j); i45 = ix * c4 + iy * s4;
+        ixy = IX(im, j) - IX(ip, j);
+        i45x = I45(i, jm) - I45(i, jp);
+        i45y = I45(im, j) - I45(ip, j);
+    }
     const double i4545 = i45x * cn4 + i45y * sn4;
     const double in45 = ix * cn4 + iy * sn4;
     double cxy = sigma * sigma * fabs(ixy) - 1.5 * sigma * (fabs(i45) + fabs(in45));
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(256) void k_nms_cells(const double *img, int width,
             const double v = img[(size_t)j2 * width + i2];
             if (v > maxval) { maxi = i2; maxj = j2; maxval = v; }
         }
+    if (!(maxval >= kNmsTau)) { cell[c] = -1; return; }      // (nearly all cells: the neighbourhood test cannot matter)
     bool failed = false;
     const int i_end = min(maxi + n, width - margin), j_end = min(maxj + n, height - margin);
     for (int i2 = maxi - n; i2 < i_end && !failed; ++i2)
@@ -657,7 +674,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     CRN_TRY(hipEventCreate(&e0)); CRN_TRY(hipEventCreate(&e1));
     CRN_TRY(hipEventRecord(e0, nullptr));
     const dim3 grid2((width + 255) / 256, height, n_images);
-    hipLaunchKernelGGL(k_grey_extremes, dim3((unsigned)((N + 1023) / 1024), n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p);
+    hipLaunchKernelGGL(k_grey_extremes, dim3((width + 4095) / 4096, height, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p);
     hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p, N);
     if (ntap == 29)
         hipLaunchKernelGGL(k_gauss_cols_strip<29>, dim3((width + 255) / 256, (height + kStrip - 1) / kStrip, n_images), dim3(256), 0, nullptr, d_tmp.p, width, height,
