@@ -17,9 +17,10 @@ sys.path.insert(0, ROOT)
 
 from tscm_calib_amd import corners, synth  # noqa: E402
 
-# algorithmic HBM bytes per pixel of the per-pixel kernels (corner candidates):
-# grey 1 r; angle + weight 16 w; row pass 8 w; column pass 8 r + 8 w; metric 8 r + 16 w; suppression 8 r
-BYTES_PER_PIXEL = 73
+# algorithmic HBM bytes per pixel of the per-pixel kernels (corner candidates): grey 1 r (extremes) + 1 r (row
+# pass); row pass 8 w; column pass 8 r + 8 w; metric 8 r + 16 w; suppression 8 r.  (The edge-angle / gradient planes of the
+# reference are evaluated on demand around the maxima and never stored.)
+BYTES_PER_PIXEL = 58
 PEAK_HBM_GBS = 8000.0
 
 
