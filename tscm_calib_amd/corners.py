@@ -98,3 +98,13 @@ def find_chessboard(gray, cols: int, rows: int, sigma: int = 4, device: int = 0)
     if len(boards) != 1 or boards[0].shape != (rows, cols):
         return None
     return d["sub"][boards[0].ravel()]
+
+
+def find_chessboards(images, cols: int, rows: int, sigma: int = 4, device: int = 0) -> list:
+    """find_chessboard for a list of images of one size: ONE pass of the detection kernels for all of them
+    (tscm_detect_corners_batch), then the structure recovery per image.  Entries are (rows * cols, 2) arrays or None."""
+    out = []
+    for d in detect_corners_batch(images, sigma=sigma, device=device):
+        boards = chessboards_from_corners(d["x"], d["y"], d["v1"], d["v2"])
+        out.append(d["sub"][boards[0].ravel()] if len(boards) == 1 and boards[0].shape == (rows, cols) else None)
+    return out

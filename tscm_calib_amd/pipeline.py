@@ -52,16 +52,18 @@ def monocular_calib(images, cols: int, rows: int, pitch: float, sigma: int = 4, 
     img_size = (grey[0].shape[1], grey[0].shape[0])
     has = np.zeros(V, dtype=np.uint8)
     pu, pv = np.zeros((V, n)), np.zeros((V, n))
-    for i, g in enumerate(grey):                                              # :24-50
-        pts = corners.find_chessboard(g, cols, rows, sigma=sigma, device=device)
+    for i, pts in enumerate(corners.find_chessboards(grey, cols, rows, sigma=sigma, device=device)):     # :24-50, one batch
         if pts is not None:
             has[i], pu[i], pv[i] = 1, pts[:, 0], pts[:, 1]
     intr, Rt, first = calibrate_camera(pu, pv, has, cols, rows, pitch, img_size, device)          # :57
-    for i in np.flatnonzero(has):                                             # :59-126 refinement pass
+    seen = np.flatnonzero(has)                                                # :59-126 refinement pass
+    board_imgs = []
+    for i in seen:
         desc = maps.chessboard_desc(intr, Rt[i], cols, rows, pitch)
         mx, my, _ = maps.build_maps([desc], desc.width * desc.height, device)
-        board_img = maps.remap(images[i], mx.reshape(desc.height, desc.width), my.reshape(desc.height, desc.width), to_gray=images[i].ndim == 3, device=device)
-        pts = corners.find_chessboard(board_img, cols, rows, sigma=sigma, device=device)
+        board_imgs.append(maps.remap(images[i], mx.reshape(desc.height, desc.width), my.reshape(desc.height, desc.width), to_gray=images[i].ndim == 3,
+                                     device=device))
+    for i, board_img, pts in zip(seen, board_imgs, corners.find_chessboards(board_imgs, cols, rows, sigma=sigma, device=device)):
         if pts is not None:                                                   # :92-105 back through [r1 r2 t] and project()
             P = (Rt[i] @ np.concatenate([pts - pitch, np.ones((n, 1))], axis=1).T).T
             uv = api.project(intr, P, device)
