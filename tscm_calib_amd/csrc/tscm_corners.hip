@@ -91,6 +91,36 @@ __device__ __forceinline__ double edge_angle(double du, double dv, const AtanCon
     return a;
 }
 
+// min and max of a contiguous image (stride == width): 64 bytes per thread as four 16-byte loads.
+// grid (ceil(w*h/16384), n_images) x 256
+__global__ __launch_bounds__(256) void k_grey_extremes_flat(const unsigned char *gray, size_t bytes, int *mm)
+{
+    gray += blockIdx.y * bytes; mm += (size_t)blockIdx.y * kMmSlots * kMmStride;
+    int mn = 255, mx = 0;
+    const size_t o = ((size_t)blockIdx.x * 256 + threadIdx.x) * 64;
+    if (o + 64 <= bytes && ((reinterpret_cast<size_t>(gray) + o) & 15) == 0) {
+        const uint4 *r = reinterpret_cast<const uint4 *>(gray + o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 v = r[k];
+            const unsigned q[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const int g = (q[a] >> (8 * b)) & 0xff; mn = min(mn, g); mx = max(mx, g); }
+        }
+    } else {
+        for (int k = 0; k < 64; ++k) if (o + k < bytes) { const int g = gray[o + k]; mn = min(mn, g); mx = max(mx, g); }
+    }
+    for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) {
+        int *slot = mm + kMmStride * ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMmSlots - 1));
+        const volatile int *cur = slot;
+        if (mn < cur[0]) atomicMin(&slot[0], mn);
+        if (mx > cur[1]) atomicMax(&slot[1], mx);
+    }
+}
+
 // min and max of the grey values (normalisation of :30-34).  grid (ceil(w/4096), h, n_images) x 256, 16 pixels of a row per thread
 __global__ __launch_bounds__(256) void k_grey_extremes(const unsigned char *gray, int w, int h, int stride, int *mm)
 {
@@ -98,8 +128,18 @@ __global__ __launch_bounds__(256) void k_grey_extremes(const unsigned char *gray
     int mn = 255, mx = 0;
     const unsigned char *row = gray + (size_t)blockIdx.y * stride;
     const int j0 = (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (j0 + 16 <= w && ((reinterpret_cast<size_t>(row) + j0) & 3) == 0) {       // four aligned 32-bit loads
+        const unsigned *r4 = reinterpret_cast<const unsigned *>(row + j0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (j0 + k < w) { const int g = row[j0 + k]; mn = min(mn, g); mx = max(mx, g); }
+        for (int k = 0; k < 4; ++k) {
+            const unsigned v = r4[k];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { const int g = (v >> (8 * b)) & 0xff; mn = min(mn, g); mx = max(mx, g); }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (j0 + k < w) { const int g = row[j0 + k]; mn = min(mn, g); mx = max(mx, g); }
+    }
     for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
     // one atomic pair per wave only while it can still move the extremes (a plain read of a monotone value: a stale
     // one merely costs a redundant atomic), spread over kMmSlots slots on separate cache lines (the consumers reduce
@@ -139,6 +179,49 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, i
     double s = 0;
     for (int q = 0; q < n; ++q) s += k[q] * seg[threadIdx.x + q];
     tmp[(size_t)i * w + j] = s;
+}
+
+// The same for a compile-time tap count: a thread computes four consecutive outputs from NT + 3 LDS values (8 LDS reads
+// per output instead of NT) and takes the taps as scalar operands (constant address space: uniform, written by the host).
+// Same order of additions per output.  grid (ceil(w/1024), h, n_images)
+template <int NT>
+__global__ __launch_bounds__(256) void k_gauss_rows4(const unsigned char *gray, int w, int h, int stride, const int *mm, const double *taps,
+                                                     double *tmp, size_t plane)
+{
+    gray += (size_t)blockIdx.z * stride * h; mm += (size_t)blockIdx.z * kMmSlots * kMmStride; tmp += blockIdx.z * plane;
+    constexpr int H = NT / 2, SEG = 1024 + NT - 1;
+    // element idx sits at idx + idx / 32: the 32 lanes of a half-wave read seg[4 lane + e] from 32 distinct bank pairs
+    __shared__ double seg[SEG + SEG / 32 + 2], lut[256];
+    int imn, imx;
+    read_extremes(mm, imn, imx);
+    const double mn = imn, mx = imx;
+    lut[threadIdx.x] = ((double)threadIdx.x - mn) / (mx - mn);
+    __syncthreads();
+    const int i = blockIdx.y, j0 = blockIdx.x * 1024;
+    const unsigned char *row = gray + (size_t)i * stride;
+    for (int e = threadIdx.x; e < SEG; e += 256) {
+        const int c = j0 + e - H;
+        seg[e + (e >> 5)] = c < w + H ? lut[row[(c >= 0 && c < w) ? c : refl101(c, w)]] : 0.0;
+    }
+    __syncthreads();
+    typedef const double __attribute__((address_space(4))) *cptr4;
+    const cptr4 kt = (cptr4)taps;
+    const int j = j0 + 4 * threadIdx.x;
+    if (j >= w) return;
+    double win[NT + 3];
+#pragma unroll
+    for (int e = 0; e < NT + 3; ++e) { const int idx = 4 * threadIdx.x + e; win[e] = seg[idx + (idx >> 5)]; }
+    double o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) s += kt[q] * win[u + q];
+        o[u] = s;
+    }
+    double *dst = tmp + (size_t)i * w + j;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (j + u < w) dst[u] = o[u];
 }
 
 // columns (symmetric kernel: centre tap, then pairs).  Generic version: grid (ceil(w/256), h, n_images)
@@ -188,52 +271,58 @@ __global__ __launch_bounds__(256) void k_gauss_cols_strip(const double *tmp, int
 
 // secondDerivCornerMetric :108-141 fused: every intermediate plane (Ix, Iy, I_45, ...) is a reflected 3-tap stencil of
 // the previous one, so each output pixel reads a 5x5 neighbourhood of Ig.  grid (ceil(w/256), h)
+constexpr int kMetricRows = 8;
 __global__ __launch_bounds__(256) void k_corner_metric(const double *Ig, int w, int h, int sigma, double c4, double cn4, double s4, double sn4,
                                                        double *metric, double *Ixy, size_t plane)
 {
     Ig += blockIdx.z * plane; metric += blockIdx.z * plane; Ixy += blockIdx.z * plane;
-    // the 5 x (256 + 4) neighbourhood of the block's row segment is staged in LDS; reflected indices of pixels in the
-    // segment always land inside this window
-    __shared__ double tile[5][256 + 4];
-    const int i = blockIdx.y, j0 = blockIdx.x * 256;
-    for (int e = threadIdx.x; e < 5 * 260; e += 256) {
-        const int r = e / 260, c = e % 260, gi = i - 2 + r, gj = j0 - 2 + c;
+    // a block computes kMetricRows rows of a 256-column segment: the (kMetricRows + 4) x (256 + 4) neighbourhood is
+    // staged in LDS once (1.5 reads of Ig per output instead of 5); reflected indices of pixels in the block always
+    // land inside this window
+    __shared__ double tile[kMetricRows + 4][256 + 4];
+    const int i0 = blockIdx.y * kMetricRows, j0 = blockIdx.x * 256;
+    for (int e = threadIdx.x; e < (kMetricRows + 4) * 260; e += 256) {
+        const int r = e / 260, c = e % 260, gi = i0 - 2 + r, gj = j0 - 2 + c;
         tile[r][c] = (gi >= 0 && gi < h && gj >= 0 && gj < w) ? Ig[(size_t)gi * w + gj] : 0.0;
     }
     __syncthreads();
     const int j = j0 + threadIdx.x;
     if (j >= w) return;
-    auto G = [&](int r, int c) { return tile[r - (i - 2)][c - (j0 - 2)]; };
-    double ix, iy, i45, ixy, i45x, i45y;
-    if (i >= 2 && i < h - 2 && j >= 2 && j < w - 2) {
-        // interior: no reflection, fixed tile offsets (t(dr, dc) = Ig(i + dr, j + dc)); same operations in the same order
-        const int tc = threadIdx.x + 2;
-        auto t = [&](int dr, int dc) { return tile[2 + dr][tc + dc]; };
-        auto ixo = [&](int dr, int dc) { return t(dr, dc - 1) - t(dr, dc + 1); };
-        auto iyo = [&](int dr, int dc) { return t(dr - 1, dc) - t(dr + 1, dc); };
-        auto i45o = [&](int dr, int dc) { return ixo(dr, dc) * c4 + iyo(dr, dc) * s4; };
-        ix = ixo(0, 0); iy = iyo(0, 0); i45 = ix * c4 + iy * s4;
-        ixy = ixo(-1, 0) - ixo(1, 0);
-        i45x = i45o(0, -1) - i45o(0, 1);
-        i45y = i45o(-1, 0) - i45o(1, 0);
-    } else {
-        auto IX = [&](int r, int c) { return G(r, refl101(c - 1, w)) - G(r, refl101(c + 1, w)); };       // du = (1 0 -1)
-        auto IY = [&](int r, int c) { return G(refl101(r - 1, h), c) - G(refl101(r + 1, h), c); };
-        auto I45 = [&](int r, int c) { return IX(r, c) * c4 + IY(r, c) * s4; };
-        const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
-        ix = IX(i, j); iy = IY(i, j); i45 = ix * c4 + iy * s4;
-        ixy = IX(im, j) - IX(ip, j);
-        i45x = I45(i, jm) - I45(i, jp);
-        i45y = I45(im, j) - I45(ip, j);
+    auto G = [&](int r, int c) { return tile[r - (i0 - 2)][c - (j0 - 2)]; };
+    for (int u = 0; u < kMetricRows; ++u) {
+        const int i = i0 + u;
+        if (i >= h) break;
+        double ix, iy, i45, ixy, i45x, i45y;
+        if (i >= 2 && i < h - 2 && j >= 2 && j < w - 2) {
+            // interior: no reflection, fixed tile offsets (t(dr, dc) = Ig(i + dr, j + dc)); same operations in the same order
+            const int tc = threadIdx.x + 2, tr = u + 2;
+            auto t = [&](int dr, int dc) { return tile[tr + dr][tc + dc]; };
+            auto ixo = [&](int dr, int dc) { return t(dr, dc - 1) - t(dr, dc + 1); };
+            auto iyo = [&](int dr, int dc) { return t(dr - 1, dc) - t(dr + 1, dc); };
+            auto i45o = [&](int dr, int dc) { return ixo(dr, dc) * c4 + iyo(dr, dc) * s4; };
+            ix = ixo(0, 0); iy = iyo(0, 0); i45 = ix * c4 + iy * s4;
+            ixy = ixo(-1, 0) - ixo(1, 0);
+            i45x = i45o(0, -1) - i45o(0, 1);
+            i45y = i45o(-1, 0) - i45o(1, 0);
+        } else {
+            auto IX = [&](int r, int c) { return G(r, refl101(c - 1, w)) - G(r, refl101(c + 1, w)); };       // du = (1 0 -1)
+            auto IY = [&](int r, int c) { return G(refl101(r - 1, h), c) - G(refl101(r + 1, h), c); };
+            auto I45 = [&](int r, int c) { return IX(r, c) * c4 + IY(r, c) * s4; };
+            const int im = refl101(i - 1, h), ip = refl101(i + 1, h), jm = refl101(j - 1, w), jp = refl101(j + 1, w);
+            ix = IX(i, j); iy = IY(i, j); i45 = ix * c4 + iy * s4;
+            ixy = IX(im, j) - IX(ip, j);
+            i45x = I45(i, jm) - I45(i, jp);
+            i45y = I45(im, j) - I45(ip, j);
+        }
+        const double i4545 = i45x * cn4 + i45y * sn4;
+        const double in45 = ix * cn4 + iy * sn4;
+        double cxy = sigma * sigma * fabs(ixy) - 1.5 * sigma * (fabs(i45) + fabs(in45));
+        if (cxy < 0) cxy = 0;
+        double c45 = sigma * sigma * fabs(i4545) - 1.5 * sigma * (fabs(ix) + fabs(iy));
+        if (c45 < 0) c45 = 0;
+        metric[(size_t)i * w + j] = cxy + c45;
+        Ixy[(size_t)i * w + j] = ixy;
     }
-    const double i4545 = i45x * cn4 + i45y * sn4;
-    const double in45 = ix * cn4 + iy * sn4;
-    double cxy = sigma * sigma * fabs(ixy) - 1.5 * sigma * (fabs(i45) + fabs(in45));
-    if (cxy < 0) cxy = 0;
-    double c45 = sigma * sigma * fabs(i4545) - 1.5 * sigma * (fabs(ix) + fabs(iy));
-    if (c45 < 0) c45 = 0;
-    metric[(size_t)i * w + j] = cxy + c45;
-    Ixy[(size_t)i * w + j] = ixy;
 }
 
 // nonMaximumSuppression :144-193, one thread per cell; cells are numbered column-major like the reference's loops
@@ -674,14 +763,21 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     CRN_TRY(hipEventCreate(&e0)); CRN_TRY(hipEventCreate(&e1));
     CRN_TRY(hipEventRecord(e0, nullptr));
     const dim3 grid2((width + 255) / 256, height, n_images);
-    hipLaunchKernelGGL(k_grey_extremes, dim3((width + 4095) / 4096, height, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p);
-    hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p, N);
+    if (stride == width)
+        hipLaunchKernelGGL(k_grey_extremes_flat, dim3((unsigned)((gbytes + 16383) / 16384), n_images), dim3(256), 0, nullptr, d_gray.p, gbytes, d_mm.p);
+    else
+        hipLaunchKernelGGL(k_grey_extremes, dim3((width + 4095) / 4096, height, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p);
+    if (ntap == 29)
+        hipLaunchKernelGGL(k_gauss_rows4<29>, dim3((width + 1023) / 1024, height, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p,
+                           d_tmp.p, N);
+    else
+        hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p, N);
     if (ntap == 29)
         hipLaunchKernelGGL(k_gauss_cols_strip<29>, dim3((width + 255) / 256, (height + kStrip - 1) / kStrip, n_images), dim3(256), 0, nullptr, d_tmp.p, width, height,
                            d_taps.p, d_Ig.p, N);
     else
         hipLaunchKernelGGL(k_gauss_cols, grid2, dim3(256), 0, nullptr, d_tmp.p, width, height, d_taps.p, ntap, d_Ig.p, N);
-    hipLaunchKernelGGL(k_corner_metric, grid2, dim3(256), 0, nullptr, d_Ig.p, width, height, sigma, std::cos(kPi / 4), std::cos(-kPi / 4), std::sin(kPi / 4),
+    hipLaunchKernelGGL(k_corner_metric, dim3((width + 255) / 256, (height + kMetricRows - 1) / kMetricRows, n_images), dim3(256), 0, nullptr, d_Ig.p, width, height, sigma, std::cos(kPi / 4), std::cos(-kPi / 4), std::sin(kPi / 4),
                        std::sin(-kPi / 4), d_metric.p, d_Ixy.p, N);
     std::vector<int> counts(B, 0);
     int n_top = 0;
