@@ -181,47 +181,56 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const unsigned char *gray, i
     tmp[(size_t)i * w + j] = s;
 }
 
-// The same for a compile-time tap count: a thread computes four consecutive outputs from NT + 3 LDS values (8 LDS reads
-// per output instead of NT) and takes the taps as scalar operands (constant address space: uniform, written by the host).
-// Same order of additions per output.  grid (ceil(w/1024), h, n_images)
-template <int NT>
-__global__ __launch_bounds__(256) void k_gauss_rows4(const unsigned char *gray, int w, int h, int stride, const int *mm, const double *taps,
-                                                     double *tmp, size_t plane)
+// normalisation table of an image: lut[g] = (g - min) / (max - min).  grid n_images x 256
+__global__ __launch_bounds__(256) void k_norm_lut(const int *mm, double *lut)
 {
-    gray += (size_t)blockIdx.z * stride * h; mm += (size_t)blockIdx.z * kMmSlots * kMmStride; tmp += blockIdx.z * plane;
-    constexpr int H = NT / 2, SEG = 1024 + NT - 1;
-    // element idx sits at idx + idx / 32: the 32 lanes of a half-wave read seg[4 lane + e] from 32 distinct bank pairs
-    __shared__ double seg[SEG + SEG / 32 + 2], lut[256];
+    mm += (size_t)blockIdx.x * kMmSlots * kMmStride;
     int imn, imx;
     read_extremes(mm, imn, imx);
     const double mn = imn, mx = imx;
-    lut[threadIdx.x] = ((double)threadIdx.x - mn) / (mx - mn);
-    __syncthreads();
-    const int i = blockIdx.y, j0 = blockIdx.x * 1024;
-    const unsigned char *row = gray + (size_t)i * stride;
-    for (int e = threadIdx.x; e < SEG; e += 256) {
-        const int c = j0 + e - H;
-        seg[e + (e >> 5)] = c < w + H ? lut[row[(c >= 0 && c < w) ? c : refl101(c, w)]] : 0.0;
-    }
-    __syncthreads();
+    lut[(size_t)blockIdx.x * 256 + threadIdx.x] = ((double)threadIdx.x - mn) / (mx - mn);
+}
+
+// The row pass for a compile-time tap count: a thread computes OPT consecutive outputs from NT + OPT - 1 LDS values
+// (~8 LDS reads per output instead of NT) and takes the taps as scalar operands (constant address space: uniform,
+// written by the host); a block walks kRowsPerBlock rows so that the table / tap set-up and the launch are amortised.
+// Same order of additions per output.  grid (ceil(w/(256 OPT)), ceil(h/kRowsPerBlock), n_images)
+constexpr int kRowsPerBlock = 4;
+template <int NT, int OPT>
+__global__ __launch_bounds__(256) void k_gauss_rows_n(const unsigned char *gray, int w, int h, int stride, const double *lut_g, const double *taps,
+                                                      double *tmp, size_t plane)
+{
+    gray += (size_t)blockIdx.z * stride * h; lut_g += (size_t)blockIdx.z * 256; tmp += blockIdx.z * plane;
+    constexpr int H = NT / 2, SEG = 256 * OPT + NT - 1;
+    // element idx sits at idx + idx / 32 (bank spreading for the strided window reads)
+    __shared__ double seg[SEG + SEG / 32 + 2], lut[256];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
     typedef const double __attribute__((address_space(4))) *cptr4;
     const cptr4 kt = (cptr4)taps;
-    const int j = j0 + 4 * threadIdx.x;
-    if (j >= w) return;
-    double win[NT + 3];
+    const int j0 = blockIdx.x * 256 * OPT, j = j0 + OPT * threadIdx.x;
+    for (int rr = 0; rr < kRowsPerBlock; ++rr) {
+        const int i = blockIdx.y * kRowsPerBlock + rr;
+        if (i >= h) break;                                   // block-uniform
+        const unsigned char *row = gray + (size_t)i * stride;
+        __syncthreads();                                     // the previous row's windows have been read (and lut is there)
+        for (int e = threadIdx.x; e < SEG; e += 256) {
+            const int c = j0 + e - H;
+            seg[e + (e >> 5)] = c < w + H ? lut[row[(c >= 0 && c < w) ? c : refl101(c, w)]] : 0.0;
+        }
+        __syncthreads();
+        if (j >= w) continue;
+        double win[NT + OPT - 1];
 #pragma unroll
-    for (int e = 0; e < NT + 3; ++e) { const int idx = 4 * threadIdx.x + e; win[e] = seg[idx + (idx >> 5)]; }
-    double o[4];
+        for (int e = 0; e < NT + OPT - 1; ++e) { const int idx = OPT * threadIdx.x + e; win[e] = seg[idx + (idx >> 5)]; }
+        double *dst = tmp + (size_t)i * w + j;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        double s = 0;
+        for (int u = 0; u < OPT; ++u) {
+            double sum = 0;
 #pragma unroll
-        for (int q = 0; q < NT; ++q) s += kt[q] * win[u + q];
-        o[u] = s;
+            for (int q = 0; q < NT; ++q) sum += kt[q] * win[u + q];
+            if (j + u < w) dst[u] = sum;
+        }
     }
-    double *dst = tmp + (size_t)i * w + j;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (j + u < w) dst[u] = o[u];
 }
 
 // columns (symmetric kernel: centre tap, then pairs).  Generic version: grid (ceil(w/256), h, n_images)
@@ -733,7 +742,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     const size_t B = (size_t)n_images;
     const size_t cells_n = (size_t)(ncell > 0 ? ncell : 1) * B;
     const size_t gbytes = (size_t)stride * height;
-    const size_t need = 256 * 24 + B * gbytes + 4 * B * N * sizeof(double) + 64 * sizeof(double) + B * kMmSlots * kMmStride * sizeof(int)
+    const size_t need = 256 * 26 + B * gbytes + 4 * B * N * sizeof(double) + 64 * sizeof(double) + B * 256 * sizeof(double) + B * kMmSlots * kMmStride * sizeof(int)
                       + 2 * cells_n * sizeof(int) + B * sizeof(int) + sizeof(DescribeTables) + 7 * cells_n * sizeof(double);
     if (arena.bytes < need) {
         if (arena.base) { (void)hipFree(arena.base); arena.base = nullptr; arena.bytes = 0; }
@@ -743,7 +752,7 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
     ArenaCursor cur = { static_cast<char *>(arena.base), arena.bytes };
     struct { unsigned char *p; } d_gray = { cur.take<unsigned char>(B * gbytes) };
     struct { double *p; } d_tmp = { cur.take<double>(B * N) }, d_Ig = { cur.take<double>(B * N) },
-                          d_metric = { cur.take<double>(B * N) }, d_Ixy = { cur.take<double>(B * N) }, d_taps = { cur.take<double>(64) },
+                          d_metric = { cur.take<double>(B * N) }, d_Ixy = { cur.take<double>(B * N) }, d_taps = { cur.take<double>(64) }, d_lut = { cur.take<double>(B * 256) },
                           d_v = { cur.take<double>(4 * cells_n) }, d_score = { cur.take<double>(cells_n) }, d_sub = { cur.take<double>(2 * cells_n) };
     struct { int *p; } d_mm = { cur.take<int>(B * kMmSlots * kMmStride) }, d_cell = { cur.take<int>(cells_n) }, d_cand = { cur.take<int>(cells_n) },
                        d_count = { cur.take<int>(B) };
@@ -767,10 +776,15 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
         hipLaunchKernelGGL(k_grey_extremes_flat, dim3((unsigned)((gbytes + 16383) / 16384), n_images), dim3(256), 0, nullptr, d_gray.p, gbytes, d_mm.p);
     else
         hipLaunchKernelGGL(k_grey_extremes, dim3((width + 4095) / 4096, height, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p);
-    if (ntap == 29)
-        hipLaunchKernelGGL(k_gauss_rows4<29>, dim3((width + 1023) / 1024, height, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p,
-                           d_tmp.p, N);
-    else
+    if (ntap == 29) {
+        hipLaunchKernelGGL(k_norm_lut, dim3(n_images), dim3(256), 0, nullptr, d_mm.p, d_lut.p);
+        const int rows_y = (height + kRowsPerBlock - 1) / kRowsPerBlock;
+        if (width > 1024 && width <= 1280)       // one block per row at the reference's image width
+            hipLaunchKernelGGL((k_gauss_rows_n<29, 5>), dim3(1, rows_y, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_lut.p, d_taps.p, d_tmp.p, N);
+        else
+            hipLaunchKernelGGL((k_gauss_rows_n<29, 4>), dim3((width + 1023) / 1024, rows_y, n_images), dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_lut.p,
+                               d_taps.p, d_tmp.p, N);
+    } else
         hipLaunchKernelGGL(k_gauss_rows, grid2, dim3(256), 0, nullptr, d_gray.p, width, height, stride, d_mm.p, d_taps.p, ntap, d_tmp.p, N);
     if (ntap == 29)
         hipLaunchKernelGGL(k_gauss_cols_strip<29>, dim3((width + 255) / 256, (height + kStrip - 1) / kStrip, n_images), dim3(256), 0, nullptr, d_tmp.p, width, height,
