@@ -225,6 +225,23 @@ public:
         return img;
     }
 
+    // undistort_chessboard(src, index, chessboard, chessboard_size) (TS.cpp:308-330): table + cv::remap(INTER_LINEAR) of an
+    // 8-bit image with `channels` interleaved channels (1 or 3); dst gets img.height rows of img.width * channels bytes
+    // (empty when the view has no board).  to_gray: BGR input, grey output (what findCorner does next, findCorner.cpp:9-10).
+    Size undistort_chessboard(const unsigned char *src, int width, int height, int stride, int channels, int index, Size chessboard, double chessboard_size,
+                              std::vector<unsigned char> &dst, bool to_gray = false) const
+    {
+        std::vector<float> mapx, mapy;
+        const Size img = undistort_chessboard_maps(index, chessboard, chessboard_size, mapx, mapy);
+        dst.clear();
+        if (img.width == 0) return img;
+        const int out_ch = (to_gray || channels == 1) ? 1 : channels;
+        dst.assign((size_t)img.width * img.height * out_ch, 0);
+        check(tscm_remap(src, width, height, stride, channels, mapx.data(), mapy.data(), img.width, img.height, img.width, to_gray ? 1 : 0, device_, dst.data(),
+                         img.width * out_ch));
+        return img;
+    }
+
     int device() const { return device_; }
 
 private:

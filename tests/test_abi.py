@@ -100,7 +100,7 @@ def test_synthetic_generator_is_deterministic_and_valid():
     assert p8.n_cameras == 8 and p8.cam_pose_constant[0] == 1
 
 
-@pytest.mark.parametrize("src", ["dropin_demo.cpp", "multicalib_demo.cpp", "calibrate_from_corners.cpp", "find_corners_demo.cpp"])
+@pytest.mark.parametrize("src", ["dropin_demo.cpp", "multicalib_demo.cpp", "calibrate_from_corners.cpp", "find_corners_demo.cpp", "calibrate_from_images.cpp"])
 def test_cpp_hosts_compile_and_link_against_the_abi(tmp_path, src):
     """The C++11 hosts (the reference's language) -- the raw C ABI one and the class mirror
     include/tscm/tscm_calib.hpp -- build with plain g++ against libtscm_hip.so."""

@@ -50,6 +50,40 @@ def test_two_camera_rig_from_rendered_images(hip_device, tmp_path):
         assert d < 3.0, (m, d)
     # result file in the reference's format
     R = synth.rodrigues(prob.cam_rt[:, :3])
-    calib_io.write_calib_yaml(str(tmp_path / "calib.yaml"), prob.intr, np.transpose(R, (0, 2, 1)), -np.einsum("cji,cj->ci", R, prob.cam_rt[:, 3:]))
+    calib_io.write_calib_yaml(str(tmp_path / "calib.yaml"), prob.intr, R, prob.cam_rt[:, 3:])          # main.cpp:314-316: [R | t] as it stands
     intr, Twc = calib_io.read_calib_yaml(str(tmp_path / "calib.yaml"))
     assert intr.shape == (2, 9) and np.allclose(Twc[0], np.eye(3, 4), atol=1e-12)
+
+
+def test_cpp_cli_from_pgm_files_to_yaml(hip_device, tmp_path):
+    """examples/calibrate_from_images.cpp: main.cpp's flow in C++ against the mirror header, PGM files in, YAML out."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "tscm_calib_amd", "csrc")
+    exe = str(tmp_path / "calibrate_from_images")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "calibrate_from_images.cpp"),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", exe])
+    gt_intr, gt, images = _render_rig(31, 10)
+    lines = []
+    for m in range(2):
+        paths = []
+        for b, im in enumerate(images[m]):
+            path = str(tmp_path / f"cam{m}_{b}.pgm")
+            with open(path, "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (im.shape[1], im.shape[0]))
+                f.write(im.tobytes())
+            paths.append(path)
+        lines.append(" ".join([str(len(paths))] + paths))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    out = subprocess.check_output([exe, str(tmp_path / "list.txt"), str(tmp_path / "calib.yaml")]).decode()
+    assert out.count("converged") >= 2 and "NOT converged" not in out and "average reproject error" in out
+    intr, Twc = calib_io.read_calib_yaml(str(tmp_path / "calib.yaml"))
+    assert intr.shape == (2, 9) and np.allclose(Twc[0], np.eye(3, 4), atol=1e-12)
+    # main.cpp:314-316 writes the camera's [R | t] as it stands in MultiCalib
+    R = synth.rodrigues(gt[1, :3])
+    assert np.max(np.abs(Twc[1][:, :3] - R)) < 8e-3
+    assert np.max(np.abs(Twc[1][:, 3] - gt[1, 3:])) < 6.0
+    # and the same result as the Python orchestration of the same calls
+    py = pipeline.calibrate_rig(images, 9, 6, 45.0, device=hip_device)["problem"]
+    assert np.max(np.abs(intr - py.intr)) < 1e-3 * np.max(np.abs(py.intr))
