@@ -15,7 +15,8 @@ def detect_corners(gray, sigma: int = 4, min_score: float = 0.01, device: int = 
     g = np.asarray(gray)
     if g.ndim != 2 or g.dtype != np.uint8:
         raise ValueError("detect_corners expects a 2-D uint8 image (convert BGR to grey first, findCorner.cpp:9-10)")
-    g = np.ascontiguousarray(g)
+    if g.strides[1] != 1 or g.strides[0] < g.shape[1]:          # rows must be contiguous; a row stride > width is passed through
+        g = np.ascontiguousarray(g)
     h, w = g.shape
     out = _l.CCornerCandidates()
     f = _l.lib().tscm_detect_corners
