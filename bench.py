@@ -123,9 +123,10 @@ def main():
     # single rank, so that it can be exercised on a one-GPU box
     multi = world > 1 or os.environ.get("TSCM_BENCH_FORCE_DIST") == "1"
     if multi:
-        # torch is used for the CPU-side rendezvous only (gloo).  torch.cuda is deliberately never touched:
-        # the torch wheel carries its own HIP runtime, and two HIP runtimes in one process do not mix with the
-        # library's (system) one -- device selection and fencing go through the C ABI instead.
+        # torch is used for the CPU-side rendezvous only (gloo) and is imported BEFORE the library is first loaded
+        # (api.Solver below): the torch wheel carries its own HIP / RCCL runtime, and the library then binds to the
+        # copies that are already in the process.  torch.cuda is deliberately never touched -- device selection and
+        # fencing go through the C ABI instead.
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
