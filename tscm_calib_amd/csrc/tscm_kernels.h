@@ -1606,6 +1606,13 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
     double mb = 0.0, ss = 0.0;
     if (b < P.B) {
         const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
+        // everything that depends on the board only is requested up front, in the same memory round trip as the view
+        // range: the factor, z, the damping, the current pose and its scaling (they are consumed after the view loop)
+        double L[21], zb[6], d2[6], xb[6], sb[6];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) L[i] = S.L[(size_t)21 * b + i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { zb[k] = S.z[6 * b + k]; d2[k] = S.D2[6 * b + k]; xb[k] = S.board_rt[cur][6 * b + k]; sb[k] = S.s_b[6 * b + k]; }
         if (q1 == q0 || fail) {
             if (a < 6) S.board_rt[cur ^ 1][6 * b + a] = S.board_rt[cur][6 * b + a];
         } else {
@@ -1622,10 +1629,9 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
                 p[k] += __shfl_xor(p[k], 1, 16); p[k] += __shfl_xor(p[k], 2, 16);
                 p[k] += __shfl_xor(p[k], 4, 16); p[k] += __shfl_xor(p[k], 8, 16);
             }
-            double t[6], y[6], L[21];
-            for (int i = 0; i < 21; ++i) L[i] = S.L[(size_t)21 * b + i];
+            double t[6], y[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) t[k] = S.z[6 * b + k] - p[k];
+            for (int k = 0; k < 6; ++k) t[k] = zb[k] - p[k];
 #pragma unroll
             for (int i = 5; i >= 0; --i) {
                 double w = t[i];
@@ -1636,9 +1642,9 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
             double m = 0.0, s = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                m += 0.5 * t[k] * t[k] + 0.5 * S.D2[6 * b + k] * y[k] * y[k];
-                const double x = S.board_rt[cur][6 * b + k];
-                const double xn = x + (-(S.s_b[6 * b + k] * y[k]));
+                m += 0.5 * t[k] * t[k] + 0.5 * d2[k] * y[k] * y[k];
+                const double x = xb[k];
+                const double xn = x + (-(sb[k] * y[k]));
                 const double d = x - xn;
                 s += d * d;
                 if (a == k) S.board_rt[cur ^ 1][6 * b + k] = xn;
