@@ -156,7 +156,7 @@ void tscm_default_options(tscm_options *opt, int mono);
  * list fits the 160 KiB LDS tile (several thousand corners), up to 3.7 M views / 536 M corners per GPU.
  */
 int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
-int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU */
+int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU, see below */
 int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *summary);
 /* Same as _solve but parameters start from / are left in device memory (used by the
  * benchmark to time the minimiser loop with inputs resident in HBM). reset=1 reloads
@@ -212,16 +212,38 @@ int tscm_unproject_pixels(const double *intr9, const double *pixels, int n, int 
 int tscm_reprojection_error(const tscm_problem *problem, int device, double *per_camera_mean,
                             double *global_mean, double *rmse);
 
-/* ------------------------------------------------------------------ multi-GPU (RCCL)
- * One process per GPU.  Rank 0 calls tscm_comm_unique_id and distributes the 128
- * bytes (e.g. over torch.distributed / MPI / a file); every rank then calls
- * tscm_comm_create.  Frames are sharded by the caller (tscm_shard_frames) so every
- * board's Schur block is rank-local; the solver all-reduces the reduced camera system
- * and a handful of scalars twice per LM iteration (ncclAllReduce, sum / max).       */
+/* ------------------------------------------------------------------ multi-GPU (frame sharding)
+ * The reference has no counterpart (multi_calib.cpp:209-212 never sets num_threads); this is north_star's
+ * "observations shard by image across the GPUs of one node with an RCCL all-reduce of J^T J / J^T r".
+ *
+ * Every rank passes the SAME whole problem to tscm_solver_create_sharded(problem, device, rank, world): the library
+ * assigns contiguous, corner-balanced ranges of boards (frames) to the ranks (tscm_shard_frames) and keeps on each
+ * GPU only the observations, Schur records and pose blocks of the boards that rank owns, so every board's 6x6 block
+ * is rank-local; camera poses and intrinsics are replicated.  What all ranks must agree on -- which cameras have
+ * views, which camera pairs share a board, the total corner count -- is derived from the whole problem.
+ * Per LM iteration the ranks exchange exactly two buffers with a sum all-reduce: the Schur-complement tiles
+ * (256 doubles per camera pair that shares a board) and the camera tiles + scalars (256 C + 8 + world doubles);
+ * every rank then solves the reduced camera system redundantly and takes identical accept / reject decisions.
+ *
+ * Two exchange back-ends:
+ *   RCCL   one process per GPU (the production path).  Rank 0 calls tscm_comm_unique_id and distributes the 128
+ *          bytes (a socket, a file, MPI ...); every rank calls tscm_comm_create, tscm_solver_set_comm, and then
+ *          tscm_solver_solve / _solve_resident like on one GPU.
+ *   LOCAL  all ranks in ONE process on ONE device (tscm_comm_create_local + tscm_solver_solve_group): the shards
+ *          run in lock step on one stream and the all-reduce is a kernel.  RCCL refuses two ranks on one device,
+ *          so this is how the sharded solver is exercised on a single-GPU machine; results are those of the RCCL
+ *          path with the same world size (same shards, same summation order: rank order).
+ * tscm_solver_download_params writes only the owned boards into board_rt; tscm_solver_gather_boards completes the
+ * caller's full-length array on every rank (tscm_solver_solve does both).                                        */
 #define TSCM_UNIQUE_ID_BYTES 128
+int tscm_solver_create_sharded(const tscm_problem *problem, int device, int rank, int world, tscm_solver **out);
 int tscm_comm_unique_id(unsigned char id[TSCM_UNIQUE_ID_BYTES]);
 int tscm_comm_create(const unsigned char id[TSCM_UNIQUE_ID_BYTES], int rank, int world, int device, tscm_comm **out);
+int tscm_comm_create_local(int world, int device, tscm_comm **out /* [world] */);
 void tscm_comm_destroy(tscm_comm *c);
+/* solvers[r] = shard r of n with the r-th communicator of one tscm_comm_create_local call; summaries [n]. */
+int tscm_solver_solve_group(tscm_solver **solvers, int n, const tscm_options *opt, tscm_summary *summaries, int reset);
+int tscm_solver_gather_boards(tscm_solver *s, double *board_rt);
 /* owner[b] = rank owning board b: contiguous ranges balanced by corner count.       */
 int tscm_shard_frames(const tscm_problem *problem, int world, int *owner);
 

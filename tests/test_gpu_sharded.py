@@ -1,0 +1,188 @@
+"""The frame-sharded (multi-GPU) solver on ONE GPU: `world` shards of a problem in one process, solved in lock step
+with the in-process exchange (tscm_comm_create_local / tscm_solver_solve_group).  Every line of the sharded HIP
+path runs here -- ownership of boards, rank-local Schur elimination, the two all-reduced buffers per iteration,
+redundant reduced solve and control on every rank; only the transport differs from the RCCL path (a summing kernel
+instead of ncclAllReduce).  The reference has no counterpart (single-threaded Ceres: multi_calib.cpp:209-212); the
+oracle of a sharded solve is the unsharded one.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from tscm_calib_amd import api, synth
+from tscm_calib_amd.problem import Problem
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve_unsharded(p, **opts):
+    q = p.copy().normalised()
+    with api.Solver(q) as s:
+        return q, s.solve(**opts)
+
+
+def _solve_group(p, world, **opts):
+    q = p.copy().normalised()
+    with api.Group(q, world) as g:
+        return q, g.solve(**opts)
+
+
+def _same_run(a, b, rtol=1e-9):
+    assert a["message"] == b["message"] and a["num_iterations"] == b["num_iterations"]
+    for x, y in zip(a["iterations"], b["iterations"]):
+        assert x["step_is_successful"] == y["step_is_successful"] and x["step_is_valid"] == y["step_is_valid"]
+        assert abs(x["cost"] - y["cost"]) <= rtol * abs(y["cost"])
+        assert abs(x["trust_region_radius"] - y["trust_region_radius"]) <= 1e-6 * y["trust_region_radius"]
+        assert abs(x["gradient_max_norm"] - y["gradient_max_norm"]) <= 1e-6 * max(y["gradient_max_norm"], 1e-12)
+        assert abs(x["step_norm"] - y["step_norm"]) <= 1e-6 * max(y["step_norm"], 1e-12)
+
+
+def _ranks_agree(sums):
+    """Every rank took its decisions from the same all-reduced bits."""
+    for s in sums[1:]:
+        assert s["message"] == sums[0]["message"] and s["num_iterations"] == sums[0]["num_iterations"]
+        for x, y in zip(s["iterations"], sums[0]["iterations"]):
+            assert x == y
+        assert s["final_cost"] == sums[0]["final_cost"] and s["rmse"] == sums[0]["rmse"]
+        assert s["n_residual_blocks"] == sums[0]["n_residual_blocks"]
+
+
+def permute_boards(p: Problem, perm) -> Problem:
+    """Board `perm[k]` of p becomes board k (views, observations and poses follow)."""
+    perm = np.asarray(perm)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    q = p.copy()
+    q.view_board = inv[p.view_board].astype(np.int32)
+    q.board_rt = p.board_rt[perm].copy()
+    return q.normalised()
+
+
+def test_group_of_one_is_the_single_gpu_solve(hip_device):
+    p = H.small_rig(4, 12, seed=3)
+    q1, s1 = _solve_unsharded(p)
+    q2, s2 = _solve_group(p, 1)
+    assert s2[0]["iterations"] == s1["iterations"] and s2[0]["message"] == s1["message"]
+    assert np.array_equal(q1.intr, q2.intr) and np.array_equal(q1.cam_rt, q2.cam_rt) and np.array_equal(q1.board_rt, q2.board_rt)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_equals_unsharded(hip_device, world):
+    p = H.small_rig(4, 30, seed=21)
+    q1, s1 = _solve_unsharded(p)
+    q2, sums = _solve_group(p, world)
+    _ranks_agree(sums)
+    _same_run(sums[0], s1)
+    assert sums[0]["n_residual_blocks"] == p.n_corners
+    e = H.param_rel_err(q2, q1)
+    assert max(e.values()) < 1e-8, e
+    assert abs(sums[0]["rmse"] - s1["rmse"]) <= 1e-10 * s1["rmse"]
+    # and against the CPU oracle, like the unsharded parity tests
+    po = p.copy().normalised()
+    os_ = orc.solve(po)
+    assert sums[0]["num_iterations"] == os_["num_iterations"]
+    assert max(H.param_rel_err(q2, po).values()) < 1e-6
+
+
+def test_shard_without_a_camera_and_without_a_camera_pair(hip_device):
+    """Boards sorted by the camera pair that sees them: with two ranks the first shard holds the pairs (0,1), (1,2) only
+    -- no view of camera 3, no board for the blocks (2,3), (0,3), (3,3) of T -- and the second shard never sees (0,1).
+    (Round-1 defect: stale tiles of T were re-added by the next all-reduce and a camera without local views was
+    treated as inactive, so the replicated parameters diverged between ranks.)"""
+    p = H.small_rig(4, 24, seed=8)
+    first_cam = np.full(p.n_boards, 99)
+    np.minimum.at(first_cam, p.view_board, p.view_camera)
+    pair_key = np.zeros(p.n_boards, dtype=np.int64)
+    for b in range(p.n_boards):
+        cams = np.sort(p.view_camera[p.view_board == b])
+        pair_key[b] = cams[0] * 10 + cams[-1]
+    p2 = permute_boards(p, np.argsort(pair_key, kind="stable"))
+    owner = api.shard_owner(p2, 2)
+    cams_of = [set(p2.view_camera[owner[p2.view_board] == r].tolist()) for r in range(2)]
+    assert cams_of[0] != cams_of[1] and any(len(c) < 4 for c in cams_of), cams_of
+    q1, s1 = _solve_unsharded(p2)
+    for world in (2, 4):
+        q2, sums = _solve_group(p2, world)
+        _ranks_agree(sums)
+        _same_run(sums[0], s1)
+        assert max(H.param_rel_err(q2, q1).values()) < 1e-8
+        assert s1["num_iterations"] > 3
+
+
+def test_sharded_mixed_visibility_and_rejected_steps(hip_device):
+    """Boards seen by 1..4 cameras (k_pair_gram path for the 4-camera boards) and a start far enough for rejected steps."""
+    p = H.mixed_visibility_rig(seed=5, n_frames=24)
+    p.intr[:, 0:2] *= 1.25
+    p.intr[:, 4] += 0.15
+    q1, s1 = _solve_unsharded(p)
+    q2, sums = _solve_group(p, 3)
+    _ranks_agree(sums)
+    _same_run(sums[0], s1, rtol=1e-8)
+    assert max(H.param_rel_err(q2, q1).values()) < 1e-7
+
+
+def test_sharded_mono(hip_device):
+    """TS.cpp:247-282 problem (one camera, a pose block per image) sharded by image."""
+    p = synth.make_problem(1, 40, 17)
+    q1, s1 = _solve_unsharded(p)
+    q2, sums = _solve_group(p, 4)
+    _ranks_agree(sums)
+    _same_run(sums[0], s1)
+    e = H.param_rel_err(q2, q1)
+    assert e["intr"] < 1e-8 and e["board_rt"] < 1e-8, e
+
+
+def test_more_ranks_than_boards(hip_device):
+    """Ranks that own nothing still take part in every exchange and reach the same decisions."""
+    p = H.small_rig(2, 3, seed=4)
+    assert p.n_boards < 8
+    q1, s1 = _solve_unsharded(p)
+    q2, sums = _solve_group(p, 8)
+    _ranks_agree(sums)
+    _same_run(sums[0], s1)
+    assert max(H.param_rel_err(q2, q1).values()) < 1e-8
+
+
+def test_sharded_fp32_jacobian_tier(hip_device):
+    p = H.small_rig(4, 30, seed=21)
+    q1, s1 = _solve_unsharded(p, jacobian_fp32=1)
+    q2, sums = _solve_group(p, 2, jacobian_fp32=1)
+    _ranks_agree(sums)
+    # north_star's fp32 tier is 1e-3 on cost / RMSE / poses; along the fx-xi-lambda-alpha valley the fp32
+    # step noise -- summed in a different order by the shards -- moves the intrinsics further (tests/test_gpu_fp32.py)
+    assert abs(sums[0]["rmse"] - s1["rmse"]) <= 1e-3 * s1["rmse"]
+    e = H.param_rel_err(q2, q1)
+    assert e["cam_rt"] < 1e-3 and e["board_rt"] < 1e-3, e
+
+
+def test_sharded_config3_vs_oracle(hip_device):
+    """BASELINE config 3 (4 cameras x 500 views) on 8 shards against the CPU oracle: the multi-GPU configuration of
+    north_star at a size the oracle solves in seconds."""
+    p = synth.make_config(3)
+    q2, sums = _solve_group(p, 8)
+    _ranks_agree(sums)
+    po = p.copy().normalised()
+    os_ = orc.solve(po)
+    assert sums[0]["num_iterations"] == os_["num_iterations"] and sums[0]["message"] == os_["message"]
+    for a, b in zip(sums[0]["iterations"], os_["iterations"]):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-6 * b["cost"]
+    assert max(H.param_rel_err(q2, po).values()) < 1e-6
+    assert abs(sums[0]["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
+
+
+def test_group_api_misuse_is_refused(hip_device):
+    from tscm_calib_amd.lib import TscmError
+    p = H.small_rig(4, 6, seed=1).normalised()
+    with api.Solver(p, rank=0, world=2) as s:
+        s.upload_params()
+        with pytest.raises(TscmError):          # a shard cannot solve without a communicator
+            s.solve_resident()
+        comms = api.Comm.local_group(3)
+        with pytest.raises(TscmError):          # communicator of another world size
+            s.set_comm(comms[0])
+        for c in comms:
+            c.close()
+    with pytest.raises(TscmError):
+        api.Solver(p, rank=2, world=2)

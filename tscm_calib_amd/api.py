@@ -25,12 +25,15 @@ from .problem import Problem
 class Solver:
     """RAII wrapper of tscm_solver (problem uploaded once, parameters in/out per solve)."""
 
-    def __init__(self, problem: Problem, device: int = 0):
+    def __init__(self, problem: Problem, device: int = 0, rank: int = 0, world: int = 1):
+        """rank / world: frame-sharded solve -- every rank passes the same WHOLE problem and keeps the boards it owns
+        (tscm_solver_create_sharded); attach a communicator with set_comm() before solving."""
         self.problem = problem.normalised() if not _is_normalised(problem) else problem
         self.problem.validate()
         self._cp = _l.c_problem(self.problem)
         self._h = C.c_void_p()
-        _l.check(_l.lib().tscm_solver_create(C.byref(self._cp), device, C.byref(self._h)))
+        self.rank, self.world = rank, world
+        _l.check(_l.lib().tscm_solver_create_sharded(C.byref(self._cp), device, rank, world, C.byref(self._h)))
         self._comm = None
 
     def close(self):
@@ -78,6 +81,12 @@ class Solver:
         _l.check(_l.lib().tscm_solver_download_params(self._h, _l.dptr(cam), _l.dptr(intr), _l.dptr(board)))
         return cam, intr, board
 
+    def gather_boards(self):
+        """Complete board_rt on every rank after a sharded solve_resident (tscm_solver_gather_boards)."""
+        board = self.problem.board_rt.copy()
+        _l.check(_l.lib().tscm_solver_gather_boards(self._h, _l.dptr(board)))
+        return board
+
     def kernel_time(self, enable: bool = True):
         """(launches, total_ms) of the dominant kernel since the last call; (re)arms the HIP-event timers."""
         n, ms = C.c_int(0), C.c_double(0.0)
@@ -88,11 +97,21 @@ class Solver:
 class Comm:
     """RCCL communicator (one per process/GPU)."""
 
-    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
-        buf = (C.c_ubyte * _l.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+    def __init__(self, unique_id: bytes | None, rank: int, world: int, device: int, _handle=None):
         self._h = C.c_void_p()
-        _l.check(_l.lib().tscm_comm_create(buf, rank, world, device, C.byref(self._h)))
         self.rank, self.world = rank, world
+        if _handle is not None:
+            self._h = _handle
+            return
+        buf = (C.c_ubyte * _l.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        _l.check(_l.lib().tscm_comm_create(buf, rank, world, device, C.byref(self._h)))
+
+    @staticmethod
+    def local_group(world: int, device: int = 0) -> "list[Comm]":
+        """The communicators of an in-process group on one device (tscm_comm_create_local)."""
+        hs = (C.c_void_p * world)()
+        _l.check(_l.lib().tscm_comm_create_local(world, device, hs))
+        return [Comm(None, r, world, device, _handle=C.c_void_p(hs[r])) for r in range(world)]
 
     @staticmethod
     def unique_id() -> bytes:
@@ -106,6 +125,53 @@ class Comm:
             self._h = C.c_void_p()
 
     __del__ = close
+
+
+class Group:
+    """`world` shards of one problem on ONE device, solved in lock step with the in-process exchange
+    (tscm_comm_create_local + tscm_solver_solve_group): the frame-sharded solver without RCCL, e.g. on a one-GPU box."""
+
+    def __init__(self, problem: Problem, world: int, device: int = 0):
+        self.problem = problem.normalised() if not _is_normalised(problem) else problem
+        self.world = world
+        self.comms = Comm.local_group(world, device)
+        self.solvers = [Solver(self.problem, device, r, world) for r in range(world)]
+        for s, c in zip(self.solvers, self.comms):
+            s.set_comm(c)
+
+    def solve(self, **options) -> "list[dict]":
+        """In/out through the problem's arrays, like Solver.solve; returns one summary per rank."""
+        for s in self.solvers:
+            s.upload_params()
+        out = self.solve_resident(reset=True, **options)
+        p = self.problem
+        cam, intr, _ = self.solvers[0].download_params()
+        if not p.mono:
+            p.cam_rt[:] = cam
+        p.intr[:] = intr
+        for s in self.solvers:                                  # every rank writes the boards it owns
+            _l.check(_l.lib().tscm_solver_download_params(s._h, None, None, _l.dptr(p.board_rt)))
+        return out
+
+    def solve_resident(self, reset: bool = True, **options) -> "list[dict]":
+        o = _l.default_options(self.problem.mono, **options)
+        hs = (C.c_void_p * self.world)(*[s._h for s in self.solvers])
+        sums = (_l.CSummary * self.world)()
+        _l.check(_l.lib().tscm_solver_solve_group(hs, self.world, C.byref(o), sums, 1 if reset else 0))
+        return [_l.summary_dict(sums[r]) for r in range(self.world)]
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+        for c in self.comms:
+            c.close()
+        self.solvers, self.comms = [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def _is_normalised(p: Problem) -> bool:

@@ -123,6 +123,14 @@ struct DevProblem {
     // compact [cam_pre[q], cam_pre[q + 1]) = padded cam_col0[q] + 0, 1, ...  (cam_pre[q] = n_act from q = C on).
     // Kernel arguments: the solver computes its operand addresses without a dependent table load.
     int cam_pre[9], cam_col0[8];
+    // frame sharding (tscm_solver_create_sharded): this rank / number of ranks; 0 / 1 on a single GPU
+    int rank, world;
+    // T is stored compact: one 16x16 tile per camera-pair block (mi <= mj) that ANY rank contributes to, numbered in
+    // lexicographic (mi, mj) order -- the same list on every rank, so the all-reduce is over n_bids * 256 doubles
+    // and every tile is rewritten in full each iteration.  Up to 8 cameras the tile of a pair follows from a 64-bit
+    // presence mask (bit mi * 8 + mj) by a population count: kernel arguments only, no dependent table load.
+    unsigned long long pair_mask;
+    const short *bid_lut;              // [C*C] tile of block (mi, mj), mi <= mj; -1 = no board is seen by both
 };
 
 struct DevState {
@@ -131,7 +139,7 @@ struct DevState {
     double *vconst, *cconst;
     double *rec[2];
     double *campart, *campart2;
-    double *H[2], *H_stage, *M_stage;
+    double *H[2], *H_stage;
     double *s_b, *s_c;
     double *L, *z, *D2, *Y;
     double *pairpart, *T;
@@ -282,8 +290,15 @@ __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 <<
 
 // ---------------------------------------------------------------------------------------------
 template <int RPC>   // RPC > 0: compile-time LDS pitch (HV = RPC - 2): all tile offsets become immediates
-__global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand, int ablate)
+__global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand)
 {
+    // profiling aid, COMPILE TIME only (make ABLATE=n: -DTSCM_ABLATE=n; 1 = no MFMA loops, 2 = no epilogue, 4 = no
+    // geometry; results invalid).  The release kernel carries neither the argument nor the branches.
+#ifdef TSCM_ABLATE
+    constexpr int ablate = TSCM_ABLATE;
+#else
+    constexpr int ablate = 0;
+#endif
     // the control block is read together with the static chunk tables (one memory round trip, not two);
     // the early exit is taken right before the first view
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
@@ -666,7 +681,9 @@ __global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, 
 }
 
 // level-2 camera reduction (raw u/v tiles -> [F|r]^T[F|r]) into H_stage + reduction of the per-block scalar partials.
-// grid (C + 1) x 256.  H_stage scal: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b ; M_stage[0] gmax_b
+// grid (C + 1) x 256.  H_stage = C camera tiles, then kScal scalars: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b
+// [4] e-block factorisation failures on this rank, then one slot per rank with that rank's board gradient max-norm
+// (zero in the other ranks' slots): ONE sum all-reduce carries sums, the failure flag and the maximum.
 __device__ void control_step(const DevProblem &P, const DevState &S, int init, double *sm);
 
 // fused_control: -1 = none (multi-GPU: the all-reduce sits between this kernel and k_control);
@@ -706,8 +723,8 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
         mb = red[0]; ss = red[1]; gs = red[2]; xs = red[3];
         if (t == 0) {
             double *sc = S.H_stage + 256 * P.C;
-            sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
-            S.M_stage[0] = gm;
+            sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = S.ctrl->lin_fail ? 1.0 : 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
+            for (int r = 0; r < P.world; ++r) sc[kScal + r] = r == P.rank ? gm : 0.0;
         }
     }
     if (fused_control < 0) return;
@@ -960,12 +977,27 @@ __global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
     red[slice][e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     __syncthreads();
     if (slice == 0) {
-        const int mi = P.bid_mi[bid], mj = P.bid_mj[bid];
-        const double v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        S.T[(size_t)(mi * 16 + (entry >> 4)) * P.n_pad + mj * 16 + (entry & 15)] = v;
-        // rigs of more than kMaxCamLds cameras: k_solve_reduced_big reads T row-wise, so the lower blocks are filled in too
-        if (P.n_pad > 16 * kMaxCamLds && mi != mj) S.T[(size_t)(mj * 16 + (entry & 15)) * P.n_pad + mi * 16 + (entry >> 4)] = v;
+        // tiles without a local partial (the pair is only seen on other ranks) are written as zeros
+        S.T[(size_t)256 * bid + entry] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
+}
+
+// T(i, j) for padded columns i, j of the camera side; the lower blocks are the transposed upper ones
+__device__ __forceinline__ double load_T_small(const DevProblem &P, const double *T, int i, int j)
+{
+    int lo = i >> 4, hi = j >> 4, a = i & 15, b = j & 15;
+    if (lo > hi) { const int t = lo; lo = hi; hi = t; const int u = a; a = b; b = u; }
+    const int bit = lo * 8 + hi;
+    const unsigned long long m = P.pair_mask;
+    const int tile = __popcll(m & ((1ull << bit) - 1ull));
+    return ((m >> bit) & 1ull) ? T[256 * tile + a * 16 + b] : 0.0;
+}
+__device__ __forceinline__ double load_T_lut(const DevProblem &P, const double *T, int i, int j)
+{
+    int lo = i >> 4, hi = j >> 4, a = i & 15, b = j & 15;
+    if (lo > hi) { const int t = lo; lo = hi; hi = t; const int u = a; a = b; b = u; }
+    const int tile = P.bid_lut[lo * P.C + hi];
+    return tile >= 0 ? T[(size_t)256 * tile + a * 16 + b] : 0.0;
 }
 
 // Common end of the reduced-system solvers: yhat = S_c y (camera step = -yhat), the candidate camera parameters, and
@@ -1091,8 +1123,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
             if (i >= 0 && j >= 0) {
                 const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
                 if (mi == mj) { h0[r][c] = S.H[0][256 * mi + ai * 16 + bj]; h1[r][c] = S.H[1][256 * mi + ai * 16 + bj]; }
-                // T holds the upper camera-pair blocks; (i, j) with mi > mj is block (mj, mi) transposed
-                tt[r][c] = (mi > mj) ? S.T[(size_t)j * n + i] : S.T[(size_t)i * n + j];
+                tt[r][c] = load_T_small(P, S.T, i, j);
             }
         }
     }
@@ -1100,7 +1131,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     for (int r = 0; r < TS; ++r) {
         const int i = diag ? mi_[r] : -1;
         g0[r] = 0.0; g1[r] = 0.0; tg[r] = 0.0;
-        if (i >= 0) { const int mj = i >> 4, b = i & 15; g0[r] = S.H[0][256 * mj + b * 16 + kFR]; g1[r] = S.H[1][256 * mj + b * 16 + kFR]; tg[r] = S.T[(size_t)i * n + mj * 16 + kFR]; }
+        if (i >= 0) { const int mj = i >> 4, b = i & 15; g0[r] = S.H[0][256 * mj + b * 16 + kFR]; g1[r] = S.H[1][256 * mj + b * 16 + kFR]; tg[r] = load_T_small(P, S.T, i, mj * 16 + kFR); }
     }
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
@@ -1395,13 +1426,13 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
                 v[u] = (r == c) ? 1.0 : 0.0;
                 if (r > N || c > r) continue;
                 if (r == N) {
-                    v[u] = j >= 0 ? scj * (H[256 * mj + bj * 16 + kFR] - S.T[(size_t)j * n + mj * 16 + kFR]) : 0.0;
+                    v[u] = j >= 0 ? scj * (H[256 * mj + bj * 16 + kFR] - load_T_lut(P, S.T, j, mj * 16 + kFR)) : 0.0;
                 } else {
                     const int i = s_map[r];
                     if (i >= 0 && j >= 0) {
                         const int mi = i >> 4, ai = i & 15;
                         const double h = (mi == mj) ? H[256 * mi + ai * 16 + bj] : 0.0;
-                        double t = s_sc[i] * scj * (h - S.T[(size_t)i * n + j]);
+                        double t = s_sc[i] * scj * (h - load_T_lut(P, S.T, i, j));
                         if (i == j) t += fmin(fmax(scj * scj * h, dmin), dmax) / radius;
                         v[u] = t;
                     }
@@ -1701,7 +1732,10 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
     { double red[3] = { gsq_c, xsq_c, cost }; block_reduce256<3>(red, gmax_c, sm); gsq_c = red[0]; xsq_c = red[1]; cost = red[2]; }
     if (t != 0) return;
     auto commit = [&]() { c.fin_count = 0; static_cast<CtrlHead &>(g) = c; };
-    const double gmax_t = fmax(gmax_c, S.M_stage[0]);
+    double gmax_b = 0.0;
+    for (int r = 0; r < P.world; ++r) gmax_b = fmax(gmax_b, sc[kScal + r]);
+    const double gmax_t = fmax(gmax_c, gmax_b);
+    if (sc[4] > 0.0) c.lin_fail = 1;          // an e-block factorisation failed on some rank: every rank rejects the step
     const double gnorm_t = sqrt(gsq_c + sc[3]);
     const double xnorm_t = sqrt(xsq_c + sc[2]);
 

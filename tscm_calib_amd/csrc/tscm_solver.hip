@@ -45,8 +45,18 @@ int tscm_set_error(int code, const std::string &msg) { return fail(code, msg); }
 
 static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Exchange backends of the frame-sharded solve.  RCCL: one process per GPU (the production path).  LOCAL: all ranks
+// live in ONE process on ONE device and share a stream -- the all-reduce is a kernel that sums the ranks' buffers in
+// rank order (tscm_comm_create_local / tscm_solver_solve_group): it runs every line of the sharded solver on a
+// one-GPU box (RCCL refuses two ranks on one device) and serves hosts that drive several shards from one thread.
+struct tscm_local_group {
+    int world = 0, device = 0, refs = 0;
+    hipStream_t stream = nullptr;
+    double **d_ptrs = nullptr;           // [world] device array of the members' exchange buffers (rewritten per exchange)
+};
 struct tscm_comm {
     ncclComm_t comm = nullptr;
+    tscm_local_group *group = nullptr;   // LOCAL backend
     int rank = 0, world = 1, device = 0;
 };
 
@@ -58,7 +68,11 @@ struct tscm_solver {
     std::vector<void *> allocs;
     tscm_comm *comm = nullptr;
     // host copies of the layout
-    int C = 0, B = 0, V = 0, N = 0, n_points = 0, n_pad = 0;
+    int C = 0, B = 0, V = 0, N = 0, n_points = 0, n_pad = 0;     // B, V, N: this rank's boards / views / corners
+    int rank = 0, world = 1;
+    int b0 = 0, B_total = 0;            // owned boards = [b0, b0 + B) of the caller's B_total
+    long N_total = 0;                   // corners of the whole job (RMSE, summary)
+    hipStream_t own_stream = nullptr;   // `stream` is replaced by the group's while a local group solve runs
     bool mono = false;
     std::vector<int> dev2orig;          // device view -> problem view
     std::vector<int> h_view_obs, h_view_count, h_view_cam, h_view_board, h_view_slot;
@@ -71,7 +85,6 @@ struct tscm_solver {
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0;
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
-    int ablate = 0;                     // TSCM_ABLATE: profiling aid (skips parts of k_eval_gram; results invalid)
     // dominant-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -159,6 +172,7 @@ extern "C" void tscm_solver_destroy(tscm_solver *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    s->stream = s->own_stream;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &e : s->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *q : s->allocs) (void)hipFree(q);
@@ -167,11 +181,32 @@ extern "C" void tscm_solver_destroy(tscm_solver *s)
     delete s;
 }
 
-extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver **out)
+// owner[b] = rank of board b: contiguous ranges balanced by corner count (shared by tscm_shard_frames and the solver)
+static void shard_owner(const tscm_problem *p, int world, std::vector<int> &owner)
+{
+    std::vector<double> per_board(p->n_boards, 0.0);
+    for (int v = 0; v < p->n_views; ++v) per_board[p->view_board[v]] += p->view_count[v];
+    double total = 0.0;
+    for (double x : per_board) total += x;
+    owner.assign(p->n_boards, 0);
+    double before = 0.0;
+    for (int b = 0; b < p->n_boards; ++b) {
+        const int r = total > 0.0 ? (int)(before * world / total) : 0;
+        owner[b] = std::min(r, world - 1);
+        before += per_board[b];
+    }
+}
+
+// Every rank is handed the WHOLE problem description (the view tables are small) and keeps the observations, records
+// and pose blocks of the boards it owns.  What the ranks must agree on is derived from the whole problem, identically
+// on every rank: which cameras have views at all (free columns of the reduced system), which camera pairs share a
+// board (tiles of T) and the total corner count.
+extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int rank, int world, tscm_solver **out)
 {
     if (!out) return fail(TSCM_E_INVALID, "out is NULL");
     *out = nullptr;
     if (int rc = validate(p)) return rc;
+    if (world < 1 || rank < 0 || rank >= world) return fail(TSCM_E_INVALID, "rank / world out of range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TSCM_E_NO_DEVICE, "no HIP device available (the TSCM solver has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "device index out of range");
@@ -180,16 +215,55 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     std::unique_ptr<tscm_solver, void (*)(tscm_solver *)> sp(new tscm_solver, tscm_solver_destroy);
     tscm_solver *s = sp.get();
     s->device = device;
-    if (const char *ab = std::getenv("TSCM_ABLATE")) s->ablate = std::atoi(ab);
-    s->C = p->n_cameras; s->B = p->n_boards; s->n_points = p->n_points; s->mono = p->mono != 0;
+    s->rank = rank; s->world = world;
+    // ---- frame ownership ------------------------------------------------------------------------
+    std::vector<int> owner;
+    shard_owner(p, world, owner);
+    int b0 = 0, b1 = 0;
+    {
+        while (b0 < p->n_boards && owner[b0] < rank) ++b0;
+        b1 = b0;
+        while (b1 < p->n_boards && owner[b1] == rank) ++b1;
+    }
+    s->b0 = b0; s->B_total = p->n_boards;
+    s->C = p->n_cameras; s->B = b1 - b0; s->n_points = p->n_points; s->mono = p->mono != 0;
     s->n_pad = 16 * s->C;
     s->h_cam_rt = p->cam_rt; s->h_intr = p->intr; s->h_board_rt = p->board_rt;
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->own_stream = s->stream;
     const int C = s->C, B = s->B;
 
-    // ---- device view order: views with corners, sorted by (camera, board) ----------------------
+    // ---- whole-problem facts (identical on every rank) -------------------------------------------
+    std::vector<unsigned char> cam_const(C, 0), cam_active(C, 0);
+    for (int m = 0; m < C; ++m) cam_const[m] = (p->mono || (p->cam_pose_constant && p->cam_pose_constant[m])) ? 1 : 0;
+    std::vector<unsigned char> pair_present((size_t)C * C, 0);
+    long N_total = 0;
+    {
+        // cameras per board, then every camera pair (mi <= mj) that shares a board
+        std::vector<int> ptr(p->n_boards + 1, 0), cams;
+        for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0) ptr[p->view_board[v] + 1]++;
+        for (int b = 0; b < p->n_boards; ++b) ptr[b + 1] += ptr[b];
+        cams.resize(ptr[p->n_boards]);
+        std::vector<int> fill(p->n_boards, 0);
+        for (int v = 0; v < p->n_views; ++v) {
+            if (p->view_count[v] <= 0) continue;
+            const int b = p->view_board[v];
+            cams[ptr[b] + fill[b]++] = p->view_camera[v];
+            cam_active[p->view_camera[v]] = 1;
+            N_total += p->view_count[v];
+        }
+        for (int b = 0; b < p->n_boards; ++b)
+            for (int i = ptr[b]; i < ptr[b + 1]; ++i)
+                for (int j = ptr[b]; j < ptr[b + 1]; ++j) {
+                    const int mi = std::min(cams[i], cams[j]), mj = std::max(cams[i], cams[j]);
+                    pair_present[(size_t)mi * C + mj] = 1;
+                }
+    }
+    s->N_total = N_total;
+
+    // ---- device view order: this rank's views with corners, sorted by (camera, board) -----------
     std::vector<int> order;
-    for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0) order.push_back(v);
+    for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0 && p->view_board[v] >= b0 && p->view_board[v] < b1) order.push_back(v);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (p->view_camera[a] != p->view_camera[b]) return p->view_camera[a] < p->view_camera[b];
         return p->view_board[a] < p->view_board[b];
@@ -203,7 +277,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     long N = 0;
     for (int i = 0; i < V; ++i) {
         const int v = order[i];
-        view_cam[i] = p->view_camera[v]; view_board[i] = p->view_board[v]; view_count[i] = p->view_count[v];
+        view_cam[i] = p->view_camera[v]; view_board[i] = p->view_board[v] - b0; view_count[i] = p->view_count[v];   // board index local to the rank
         view_obs[i] = (int)N; N += p->view_count[v];
     }
     if (N > 0x7fffffffL) return fail(TSCM_E_UNSUPPORTED, "more than 2^31 corners");
@@ -219,9 +293,6 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
         std::memcpy(u.data() + view_obs[i], p->obs_u + p->view_offset[v], sizeof(double) * view_count[i]);
         std::memcpy(w.data() + view_obs[i], p->obs_v + p->view_offset[v], sizeof(double) * view_count[i]);
     }
-    std::vector<unsigned char> cam_const(C, 0), cam_active(C, 0);
-    for (int m = 0; m < C; ++m) cam_const[m] = (p->mono || (p->cam_pose_constant && p->cam_pose_constant[m])) ? 1 : 0;
-    for (int i = 0; i < V; ++i) cam_active[view_cam[i]] = 1;
 
     // ---- chunks of views (one wave each), never straddling a camera ----------------------------
     // one round of resident waves: LDS admits floor(160 KiB / lds_eval) single-wave workgroups per CU
@@ -266,13 +337,12 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     for (int q = 0; q < V; ++q) { view_slot[bv_idx[q]] = q; slot_cam[q] = view_cam[bv_idx[q]]; }
     s->h_view_slot = view_slot;
     // ---- Schur-complement work lists ------------------------------------------------------------
-    // camera-pair blocks ("bids") of T that receive contributions
+    // camera-pair blocks ("bids") of T: every pair that shares a board on ANY rank, in lexicographic order
     std::vector<int> bid_of(C * C, -1), bid_mi, bid_mj;
-    auto get_bid = [&](int mi, int mj) {
-        const int key = mi * C + mj;
-        if (bid_of[key] < 0) { bid_of[key] = (int)bid_mi.size(); bid_mi.push_back(mi); bid_mj.push_back(mj); }
-        return bid_of[key];
-    };
+    for (int mi = 0; mi < C; ++mi)
+        for (int mj = mi; mj < C; ++mj)
+            if (pair_present[(size_t)mi * C + mj]) { bid_of[mi * C + mj] = (int)bid_mi.size(); bid_mi.push_back(mi); bid_mj.push_back(mj); }
+    auto get_bid = [&](int mi, int mj) { return bid_of[mi * C + mj]; };      // views of a board are sorted by camera: mi <= mj
     // boards grouped by camera-set signature (views of a board are already sorted by camera)
     std::vector<int> order_b;
     for (int b = 0; b < B; ++b) if (bv_ptr[b + 1] > bv_ptr[b]) order_b.push_back(b);
@@ -360,6 +430,10 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     DevProblem &P = s->P;
     DevState &S = s->S;
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
+    P.rank = rank; P.world = world;
+    P.pair_mask = 0;
+    if (C <= kMaxCamLds)
+        for (int mi = 0; mi < C; ++mi) for (int mj = mi; mj < C; ++mj) if (bid_of[mi * C + mj] >= 0) P.pair_mask |= 1ull << (mi * 8 + mj);
     P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double));
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
     P.n_bchunks = (int)bc_begin.size(); P.n_tiles = n_tiles;
@@ -392,6 +466,10 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_upload(s, &P.bc_tile, bc_tile))) return rc;
     if ((rc = dev_upload(s, &P.bid_mi, bid_mi))) return rc;
     if ((rc = dev_upload(s, &P.bid_mj, bid_mj))) return rc;
+    {
+        std::vector<short> lut(bid_of.begin(), bid_of.end());
+        if ((rc = dev_upload(s, &P.bid_lut, lut))) return rc;
+    }
     if ((rc = dev_upload(s, &P.cam_const, cam_const))) return rc;
     if ((rc = dev_upload(s, &P.cam_active, cam_active))) return rc;
     {
@@ -442,8 +520,7 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_alloc(s, &S.cconst, (size_t)kCStride * C))) return rc;
     if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)(P.n_chunks / 4)))) return rc;
     if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C * kCamG1))) return rc;
-    if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal))) return rc;
-    if ((rc = dev_alloc(s, &S.M_stage, 8))) return rc;
+    if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal + world))) return rc;
     if ((rc = dev_alloc(s, &S.s_b, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.s_c, (size_t)s->n_pad))) return rc;
     if ((rc = dev_alloc(s, &S.L, 21 * (size_t)B))) return rc;
@@ -451,16 +528,15 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     if ((rc = dev_alloc(s, &S.D2, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.Y, 96 * (size_t)V))) return rc;
     if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
-    if ((rc = dev_alloc(s, &S.T, (size_t)s->n_pad * s->n_pad))) return rc;
+    if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
     S.n_bs_blocks = (B + 15) / 16;
     S.n_st_blocks = (B + 255) / 256;
     if ((rc = dev_alloc(s, &S.bs_part, 2 * (size_t)S.n_bs_blocks))) return rc;
     if ((rc = dev_alloc(s, &S.st_part, 3 * (size_t)S.n_st_blocks))) return rc;
     if ((rc = dev_alloc(s, &S.ctrl, 1))) return rc;
-    HIP_TRY(hipMemset(S.T, 0, sizeof(double) * (size_t)s->n_pad * s->n_pad));
-    HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal)));
-    HIP_TRY(hipMemset(S.M_stage, 0, sizeof(double) * 8));
+    HIP_TRY(hipMemset(S.T, 0, sizeof(double) * 256 * (size_t)n_bids));
+    HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal + world)));
     HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 512 * (size_t)C * kCamG1));
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
@@ -491,26 +567,34 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     return 0;
 }
 
+extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver **out)
+{
+    return tscm_solver_create_sharded(p, device, 0, 1, out);
+}
+
 extern "C" int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm)
 {
     if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
     if (comm && comm->device != s->device) return fail(TSCM_E_INVALID, "communicator and solver live on different devices");
-    // a single-rank communicator is a no-op; TSCM_FORCE_COMM=1 keeps it anyway so that the RCCL code path
+    if (comm && (comm->world != s->world || comm->rank != s->rank))
+        return fail(TSCM_E_INVALID, "communicator rank / world differ from the solver's shard (tscm_solver_create_sharded)");
+    // a single-rank RCCL communicator is a no-op; TSCM_FORCE_COMM=1 keeps it anyway so that the RCCL code path
     // (separate k_control, stream-ordered all-reduces) can be exercised on one GPU
     const bool force = std::getenv("TSCM_FORCE_COMM") != nullptr;
-    s->comm = (comm && (comm->world > 1 || force)) ? comm : nullptr;
+    s->comm = (comm && (comm->world > 1 || force || comm->group)) ? comm : nullptr;
     return 0;
 }
 
 extern "C" int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, const double *intr, const double *board_rt)
 {
-    if (!s || !intr || (!board_rt && s->B)) return fail(TSCM_E_INVALID, "NULL argument");
+    if (!s || !intr || (!board_rt && s->B_total)) return fail(TSCM_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(s->device));
     std::vector<double> zero(6 * (size_t)s->C, 0.0);
     const double *c = (s->mono || !cam_rt) ? zero.data() : cam_rt;
     HIP_TRY(hipMemcpyAsync(s->d_init_cam, c, sizeof(double) * 6 * s->C, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_init_intr, intr, sizeof(double) * 9 * s->C, hipMemcpyHostToDevice, s->stream));
-    if (s->B) HIP_TRY(hipMemcpyAsync(s->d_init_board, board_rt, sizeof(double) * 6 * s->B, hipMemcpyHostToDevice, s->stream));
+    // board_rt is the caller's full-length array; this rank keeps the poses of the boards it owns
+    if (s->B) HIP_TRY(hipMemcpyAsync(s->d_init_board, board_rt + 6 * (size_t)s->b0, sizeof(double) * 6 * s->B, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->have_init = true;
     return 0;
@@ -533,8 +617,8 @@ static int launch_eval(tscm_solver *s, int cand)
     }
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
     if (s->f32_jacobian) hipLaunchKernelGGL(k_eval_gram_f32, dim3(P.n_chunks / 4), dim3(256), s->lds_eval32, s->stream, P, s->S, cand);
-    else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
-    else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand, s->ablate);
+    else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
+    else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
     if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
 }
@@ -560,40 +644,82 @@ extern "C" int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches
     return 0;
 }
 
-// evaluation of the target point: pose constants, Gram kernel, reductions, statistics (+ all-reduce)
-static int enqueue_eval(tscm_solver *s, int cand, int init, int have_backsub)
+// ------------------------------------------------------------------------------------------------
+// The LM loop over a set of shards.  `members` is ONE solver (single GPU, or one RCCL rank: the peers run the same
+// loop in their own processes) or all ranks of a LOCAL group (one process, one device, one stream, lock step).
+// Per iteration the ranks exchange exactly two buffers, each with a sum all-reduce:
+//   T        n_bids * 256 doubles   the Schur complement tiles, after k_T_reduce
+//   H_stage  256 C + kScal + world  camera tiles, cost, model-cost / norm partials, failure flag, per-rank max slots
+// ------------------------------------------------------------------------------------------------
+__global__ void k_xchg_sum(double *const *bufs, int world, size_t n)
 {
-    const DevProblem &P = s->P;
-    DevState &S = s->S;
-    hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
-    if (int rc = launch_eval(s, cand)) return rc;
-    hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1 + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
-    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub, s->comm ? -1 : init);
-    if (s->comm) {
-        NCCL_TRY(ncclGroupStart());
-        NCCL_TRY(ncclAllReduce(S.H_stage, S.H_stage, 256 * (size_t)P.C + kScal, ncclDouble, ncclSum, s->comm->comm, s->stream));
-        NCCL_TRY(ncclAllReduce(S.M_stage, S.M_stage, 1, ncclDouble, ncclMax, s->comm->comm, s->stream));
-        NCCL_TRY(ncclGroupEnd());
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int r = 0; r < world; ++r) a += bufs[r][i];       // rank order: every member receives the same bits
+    for (int r = 0; r < world; ++r) bufs[r][i] = a;
+}
+
+struct LmRun {
+    std::vector<tscm_solver *> m;
+    bool separate_control() const { return m[0]->comm != nullptr; }
+};
+
+static int exchange(LmRun &run, bool t_buffer)
+{
+    tscm_solver *s0 = run.m[0];
+    if (!s0->comm) return 0;
+    const size_t n = t_buffer ? 256 * (size_t)s0->P.n_bids : 256 * (size_t)s0->P.C + kScal + s0->P.world;
+    if (n == 0) return 0;
+    if (s0->comm->group) {
+        tscm_local_group *g = s0->comm->group;      // pointer tables: [0, world) the members' T, [world, 2 world) their H_stage (run_lm)
+        hipLaunchKernelGGL(k_xchg_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g->stream, g->d_ptrs + (t_buffer ? 0 : g->world), g->world, n);
+        return 0;
     }
-    if (s->comm) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, P, S, init);   // single GPU: fused into k_finalize_eval
+    double *buf = t_buffer ? s0->S.T : s0->S.H_stage;
+    NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, s0->comm->comm, s0->stream));
     return 0;
 }
 
-static int enqueue_iteration(tscm_solver *s)
+// evaluation of the target point: pose constants, Gram kernel, reductions, statistics (+ all-reduce + control)
+static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
 {
-    const DevProblem &P = s->P;
-    DevState &S = s->S;
-    if (S.n_bs_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
-    if (P.n_bchunks) hipLaunchKernelGGL(k_board_gram, dim3(P.n_bchunks), dim3(512), 0, s->stream, P, S);
-    if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
-    if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
-    if (s->comm) NCCL_TRY(ncclAllReduce(S.T, S.T, (size_t)P.n_pad * P.n_pad, ncclDouble, ncclSum, s->comm->comm, s->stream));
-    if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
-    else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
-    else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
-    else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
-    if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
-    return enqueue_eval(s, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
+    const bool sep = run.separate_control();
+    for (tscm_solver *s : run.m) {
+        const DevProblem &P = s->P;
+        DevState &S = s->S;
+        hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
+        if (int rc = launch_eval(s, cand)) return rc;
+        hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1 + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
+        hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub, sep ? -1 : init);
+    }
+    if (!sep) return 0;                   // single GPU: the control step is fused into k_finalize_eval
+    if (int rc = exchange(run, /*t_buffer=*/false)) return rc;
+    for (tscm_solver *s : run.m) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, init);
+    return 0;
+}
+
+static int enqueue_iteration(LmRun &run)
+{
+    for (tscm_solver *s : run.m) {
+        const DevProblem &P = s->P;
+        DevState &S = s->S;
+        if (S.n_bs_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+        if (P.n_bchunks) hipLaunchKernelGGL(k_board_gram, dim3(P.n_bchunks), dim3(512), 0, s->stream, P, S);
+        if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
+        if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
+    }
+    if (int rc = exchange(run, /*t_buffer=*/true)) return rc;
+    for (tscm_solver *s : run.m) {
+        const DevProblem &P = s->P;
+        DevState &S = s->S;
+        if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
+        else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
+        else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
+        if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+    }
+    return enqueue_eval(run, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
 
 static const char *reason_message(int r)
@@ -609,92 +735,165 @@ static const char *reason_message(int r)
     }
 }
 
-extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *opt_in, tscm_summary *sum, int reset)
-{
-    if (!s || !sum) return fail(TSCM_E_INVALID, "NULL argument");
-    if (!s->have_init) return fail(TSCM_E_INVALID, "tscm_solver_upload_params has not been called");
-    tscm_options opt;
-    if (opt_in) opt = *opt_in; else tscm_default_options(&opt, s->mono);
-    if (opt.max_num_iterations < 0 || opt.max_num_iterations > TSCM_MAX_ITERATIONS) return fail(TSCM_E_INVALID, "max_num_iterations must be in [0, 255]");
-    HIP_TRY(hipSetDevice(s->device));
-    DevState &S = s->S;
-    std::memset(sum, 0, sizeof(*sum));
-    s->f32_jacobian = opt.jacobian_fp32 != 0;
-    if (s->f32_jacobian && s->lds_eval32 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
-
-    // control block
-    Ctrl *h = s->h_ctrl;
-    std::memset(h, 0, sizeof(Ctrl));
-    h->radius = opt.initial_trust_region_radius;
-    h->decrease_factor = 2.0;
-    h->opt.max_num_iterations = opt.max_num_iterations;
-    h->opt.function_tolerance = opt.function_tolerance;
-    h->opt.gradient_tolerance = opt.gradient_tolerance;
-    h->opt.parameter_tolerance = opt.parameter_tolerance;
-    h->opt.initial_radius = opt.initial_trust_region_radius;
-    h->opt.max_radius = opt.max_trust_region_radius;
-    h->opt.min_radius = opt.min_trust_region_radius;
-    h->opt.min_relative_decrease = opt.min_relative_decrease;
-    h->opt.min_lm_diagonal = opt.min_lm_diagonal;
-    h->opt.max_lm_diagonal = opt.max_lm_diagonal;
-    h->opt.max_invalid = opt.max_num_consecutive_invalid_steps;
-    h->opt.jacobi_scaling = opt.jacobi_scaling;
-    const size_t header = sizeof(CtrlHead);
-    HIP_TRY(hipMemcpyAsync(S.ctrl, h, header, hipMemcpyHostToDevice, s->stream));
-    if (reset) {
-        HIP_TRY(hipMemcpyAsync(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice, s->stream));
-        HIP_TRY(hipMemcpyAsync(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice, s->stream));
-        if (s->B) HIP_TRY(hipMemcpyAsync(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice, s->stream));
+// restores the per-solve state of the members on every exit path (also the error returns inside the loop)
+struct LmRunGuard {
+    LmRun &run;
+    ~LmRunGuard()
+    {
+        for (tscm_solver *s : run.m) {
+            s->f32_jacobian = false;         // the operator-level entry points are always fp64
+            s->ev_used = 0;
+            s->stream = s->own_stream;
+        }
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));
+};
+
+static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset);
+
+// An RCCL rank that leaves the loop on an error would leave its peers blocked in their next all-reduce: abort the
+// communicator so that they fail too (the communicator is unusable afterwards, like after any RCCL error).
+static int run_lm(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset)
+{
+    const int rc = run_lm_inner(run, opt_in, sums, reset);
+    tscm_comm *c = run.m[0]->comm;
+    if (rc != 0 && rc != TSCM_E_INVALID && c && c->comm && c->world > 1) {
+        const std::string keep = g_err;
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+        g_err = keep + " (communicator aborted)";
+    }
+    return rc;
+}
+
+static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset)
+{
+    tscm_solver *s0 = run.m[0];
+    for (tscm_solver *s : run.m) if (!s->have_init) return fail(TSCM_E_INVALID, "tscm_solver_upload_params has not been called");
+    tscm_options opt;
+    if (opt_in) opt = *opt_in; else tscm_default_options(&opt, s0->mono);
+    if (opt.max_num_iterations < 0 || opt.max_num_iterations > TSCM_MAX_ITERATIONS) return fail(TSCM_E_INVALID, "max_num_iterations must be in [0, 255]");
+    HIP_TRY(hipSetDevice(s0->device));
+    LmRunGuard guard{ run };
+    if (s0->comm && !s0->comm->group && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
+    if (s0->comm && s0->comm->group) {
+        // a local group runs on ONE stream: lock step by stream order, no events
+        tscm_local_group *g = s0->comm->group;
+        if ((int)run.m.size() != g->world) return fail(TSCM_E_INVALID, "a local group solves with all of its members (tscm_solver_solve_group)");
+        std::vector<double *> ptrs(2 * (size_t)g->world);
+        for (int r = 0; r < g->world; ++r) { ptrs[r] = run.m[r]->S.T; ptrs[g->world + r] = run.m[r]->S.H_stage; }
+        HIP_TRY(hipMemcpy(g->d_ptrs, ptrs.data(), sizeof(double *) * ptrs.size(), hipMemcpyHostToDevice));
+        for (tscm_solver *s : run.m) { HIP_TRY(hipStreamSynchronize(s->own_stream)); s->stream = g->stream; }
+    }
+    for (size_t r = 0; r < run.m.size(); ++r) std::memset(&sums[r], 0, sizeof(tscm_summary));
+    for (tscm_solver *s : run.m) {
+        s->f32_jacobian = opt.jacobian_fp32 != 0;
+        if (s->f32_jacobian && s->lds_eval32 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
+    }
+
+    // control block (identical on every rank)
+    for (tscm_solver *s : run.m) {
+        DevState &S = s->S;
+        Ctrl *h = s->h_ctrl;
+        std::memset(h, 0, sizeof(Ctrl));
+        h->radius = opt.initial_trust_region_radius;
+        h->decrease_factor = 2.0;
+        h->opt.max_num_iterations = opt.max_num_iterations;
+        h->opt.function_tolerance = opt.function_tolerance;
+        h->opt.gradient_tolerance = opt.gradient_tolerance;
+        h->opt.parameter_tolerance = opt.parameter_tolerance;
+        h->opt.initial_radius = opt.initial_trust_region_radius;
+        h->opt.max_radius = opt.max_trust_region_radius;
+        h->opt.min_radius = opt.min_trust_region_radius;
+        h->opt.min_relative_decrease = opt.min_relative_decrease;
+        h->opt.min_lm_diagonal = opt.min_lm_diagonal;
+        h->opt.max_lm_diagonal = opt.max_lm_diagonal;
+        h->opt.max_invalid = opt.max_num_consecutive_invalid_steps;
+        h->opt.jacobi_scaling = opt.jacobi_scaling;
+        HIP_TRY(hipMemcpyAsync(S.ctrl, h, sizeof(CtrlHead), hipMemcpyHostToDevice, s->stream));
+        if (reset) {
+            HIP_TRY(hipMemcpyAsync(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice, s->stream));
+            HIP_TRY(hipMemcpyAsync(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice, s->stream));
+            if (s->B) HIP_TRY(hipMemcpyAsync(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice, s->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s0->stream));
     const double t0 = wall();
 
     int rc;
-    if ((rc = enqueue_eval(s, /*cand=*/0, /*init=*/1, /*have_backsub=*/0))) return rc;
+    if ((rc = enqueue_eval(run, /*cand=*/0, /*init=*/1, /*have_backsub=*/0))) return rc;
     const int check_every = std::max(1, opt.check_every);
     bool done = false;
     for (int it = 1; it <= opt.max_num_iterations && !done; ++it) {
-        if ((rc = enqueue_iteration(s))) return rc;
+        if ((rc = enqueue_iteration(run))) return rc;
         if (it % check_every == 0 || it == opt.max_num_iterations) {
-            HIP_TRY(hipMemcpyAsync(h, S.ctrl, 64, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            done = h->done != 0;
+            // every rank takes the same decisions from the same all-reduced bits: polling one member is enough
+            HIP_TRY(hipMemcpyAsync(s0->h_ctrl, s0->S.ctrl, 64, hipMemcpyDeviceToHost, s0->stream));
+            HIP_TRY(hipStreamSynchronize(s0->stream));
+            done = s0->h_ctrl->done != 0;
         }
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipStreamSynchronize(s0->stream));
     const double t1 = wall();
-    s->f32_jacobian = false;            // the other entry points (functor / normal-equation evaluation) are always fp64
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(h, S.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-    if ((rc = collect_timing(s))) return rc;
-    if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
-
-    // the accepted point lives in buffer `cur`; make it buffer 0 for the next resident solve
-    if (h->cur != 0) {
-        HIP_TRY(hipMemcpy(S.cam_rt[0], S.cam_rt[1], sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemcpy(S.intr[0], S.intr[1], sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
-        if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], S.board_rt[1], sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
+    for (size_t r = 0; r < run.m.size(); ++r) {
+        tscm_solver *s = run.m[r];
+        DevState &S = s->S;
+        Ctrl *h = s->h_ctrl;
+        tscm_summary *sum = &sums[r];
+        HIP_TRY(hipMemcpy(h, S.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+        if ((rc = collect_timing(s))) return rc;
+        if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
+        // the accepted point lives in buffer `cur`; make it buffer 0 for the next resident solve
+        if (h->cur != 0) {
+            HIP_TRY(hipMemcpy(S.cam_rt[0], S.cam_rt[1], sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(S.intr[0], S.intr[1], sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
+            if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], S.board_rt[1], sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
+        }
+        sum->termination_type = h->term_type;
+        sum->num_iterations = std::min(h->n_log, TSCM_MAX_ITERATIONS + 1);
+        sum->num_successful_steps = h->num_successful;
+        sum->num_unsuccessful_steps = h->num_unsuccessful;
+        sum->initial_cost = h->initial_cost;
+        sum->final_cost = h->x_cost;
+        sum->n_residual_blocks = (int)s->N_total;
+        sum->lm_iterations = h->lm_iterations;
+        for (int i = 0; i < sum->num_iterations; ++i) {
+            const IterLog &l = h->log[i];
+            tscm_iteration &o = sum->iterations[i];
+            o.iteration = l.iteration; o.step_is_valid = l.step_is_valid; o.step_is_successful = l.step_is_successful;
+            o.cost = l.cost; o.cost_change = l.cost_change; o.gradient_max_norm = l.gradient_max_norm; o.gradient_norm = l.gradient_norm;
+            o.step_norm = l.step_norm; o.relative_decrease = l.relative_decrease; o.trust_region_radius = l.radius;
+        }
+        std::snprintf(sum->message, sizeof(sum->message), "%s", reason_message(h->term_reason));
+        sum->seconds_solve = t1 - t0;
+        sum->seconds_total = t1 - t0;
+        sum->rmse = s->N_total ? std::sqrt(2.0 * h->x_cost / (double)s->N_total) : 0.0;     // cost and N of the WHOLE job
     }
-    sum->termination_type = h->term_type;
-    sum->num_iterations = std::min(h->n_log, TSCM_MAX_ITERATIONS + 1);
-    sum->num_successful_steps = h->num_successful;
-    sum->num_unsuccessful_steps = h->num_unsuccessful;
-    sum->initial_cost = h->initial_cost;
-    sum->final_cost = h->x_cost;
-    sum->n_residual_blocks = s->N;
-    sum->lm_iterations = h->lm_iterations;
-    for (int i = 0; i < sum->num_iterations; ++i) {
-        const IterLog &l = h->log[i];
-        tscm_iteration &o = sum->iterations[i];
-        o.iteration = l.iteration; o.step_is_valid = l.step_is_valid; o.step_is_successful = l.step_is_successful;
-        o.cost = l.cost; o.cost_change = l.cost_change; o.gradient_max_norm = l.gradient_max_norm; o.gradient_norm = l.gradient_norm;
-        o.step_norm = l.step_norm; o.relative_decrease = l.relative_decrease; o.trust_region_radius = l.radius;
-    }
-    std::snprintf(sum->message, sizeof(sum->message), "%s", reason_message(h->term_reason));
-    sum->seconds_solve = t1 - t0;
-    sum->seconds_total = t1 - t0;
-    sum->rmse = s->N ? std::sqrt(2.0 * h->x_cost / (double)s->N) : 0.0;
     return 0;
+}
+
+extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *opt_in, tscm_summary *sum, int reset)
+{
+    if (!s || !sum) return fail(TSCM_E_INVALID, "NULL argument");
+    if (s->comm && s->comm->group && s->world > 1) return fail(TSCM_E_INVALID, "member of a local group: use tscm_solver_solve_group");
+    if (s->world > 1 && !s->comm) return fail(TSCM_E_INVALID, "sharded solver without a communicator (tscm_solver_set_comm)");
+    LmRun run;
+    run.m.push_back(s);
+    return run_lm(run, opt_in, sum, reset);
+}
+
+extern "C" int tscm_solver_solve_group(tscm_solver **solvers, int n, const tscm_options *opt, tscm_summary *summaries, int reset)
+{
+    if (!solvers || !summaries || n < 1) return fail(TSCM_E_INVALID, "NULL argument");
+    LmRun run;
+    for (int r = 0; r < n; ++r) {
+        tscm_solver *s = solvers[r];
+        if (!s || s->world != n || s->rank != r) return fail(TSCM_E_INVALID, "solvers[r] must be shard r of n (tscm_solver_create_sharded)");
+        if (n > 1 && (!s->comm || !s->comm->group || s->comm->group != solvers[0]->comm->group))
+            return fail(TSCM_E_INVALID, "the solvers of a group need the communicators of ONE tscm_comm_create_local call");
+        run.m.push_back(s);
+    }
+    return run_lm(run, opt, summaries, reset);
 }
 
 extern "C" int tscm_solver_download_params(tscm_solver *s, double *cam_rt, double *intr, double *board_rt)
@@ -703,7 +902,29 @@ extern "C" int tscm_solver_download_params(tscm_solver *s, double *cam_rt, doubl
     HIP_TRY(hipSetDevice(s->device));
     if (cam_rt && !s->mono) HIP_TRY(hipMemcpy(cam_rt, s->S.cam_rt[0], sizeof(double) * 6 * s->C, hipMemcpyDeviceToHost));
     if (intr) HIP_TRY(hipMemcpy(intr, s->S.intr[0], sizeof(double) * 9 * s->C, hipMemcpyDeviceToHost));
-    if (board_rt && s->B) HIP_TRY(hipMemcpy(board_rt, s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToHost));
+    // only the owned boards: the other entries of the caller's array are left untouched (see tscm_solver_gather_boards)
+    if (board_rt && s->B) HIP_TRY(hipMemcpy(board_rt + 6 * (size_t)s->b0, s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// After a sharded solve every rank holds the poses of its own boards.  This makes the caller's full-length array
+// complete on every rank (what MultiCalib::calibrate() leaves behind: all chessboards_[i].rt_ updated): the owned
+// slice in a zeroed full-length device buffer, one sum all-reduce (x + 0 is exact), one download.
+extern "C" int tscm_solver_gather_boards(tscm_solver *s, double *board_rt)
+{
+    if (!s || (!board_rt && s->B_total)) return fail(TSCM_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->comm || s->world == 1 || s->comm->group) return tscm_solver_download_params(s, nullptr, nullptr, board_rt);   // local groups share the caller's array
+    if (s->B_total == 0) return 0;
+    double *full = nullptr;
+    const size_t n = 6 * (size_t)s->B_total;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&full), n * sizeof(double)));
+    std::unique_ptr<double, void (*)(double *)> guard(full, [](double *q) { (void)hipFree(q); });
+    HIP_TRY(hipMemsetAsync(full, 0, n * sizeof(double), s->stream));
+    if (s->B) HIP_TRY(hipMemcpyAsync(full + 6 * (size_t)s->b0, s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice, s->stream));
+    NCCL_TRY(ncclAllReduce(full, full, n, ncclDouble, ncclSum, s->comm->comm, s->stream));
+    HIP_TRY(hipMemcpyAsync(board_rt, full, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
 
@@ -714,7 +935,8 @@ extern "C" int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_s
     int rc;
     if ((rc = tscm_solver_upload_params(s, s->h_cam_rt, s->h_intr, s->h_board_rt))) return rc;
     if ((rc = tscm_solver_solve_resident(s, opt, sum, 1))) return rc;
-    if ((rc = tscm_solver_download_params(s, s->h_cam_rt, s->h_intr, s->h_board_rt))) return rc;
+    if ((rc = tscm_solver_download_params(s, s->h_cam_rt, s->h_intr, nullptr))) return rc;
+    if ((rc = tscm_solver_gather_boards(s, s->h_board_rt))) return rc;
     sum->seconds_total = wall() - t0;
     return 0;
 }
@@ -947,10 +1169,41 @@ extern "C" int tscm_comm_create(const unsigned char id[TSCM_UNIQUE_ID_BYTES], in
     return 0;
 }
 
+extern "C" int tscm_comm_create_local(int world, int device, tscm_comm **out)
+{
+    if (!out || world < 1) return fail(TSCM_E_INVALID, "bad communicator arguments");
+    for (int r = 0; r < world; ++r) out[r] = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<tscm_local_group> g(new tscm_local_group);
+    g->world = world; g->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    if (hipMalloc(reinterpret_cast<void **>(&g->d_ptrs), sizeof(double *) * 2 * (size_t)world) != hipSuccess) {
+        (void)hipStreamDestroy(g->stream);
+        return fail(TSCM_E_NOMEM, "hipMalloc of the group's pointer table failed");
+    }
+    for (int r = 0; r < world; ++r) {
+        tscm_comm *c = new tscm_comm;
+        c->rank = r; c->world = world; c->device = device; c->group = g.get();
+        out[r] = c;
+    }
+    g->refs = world;
+    g.release();
+    return 0;
+}
+
 extern "C" void tscm_comm_destroy(tscm_comm *c)
 {
     if (!c) return;
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->group && --c->group->refs == 0) {
+        (void)hipSetDevice(c->group->device);
+        (void)hipStreamSynchronize(c->group->stream);
+        (void)hipFree(c->group->d_ptrs);
+        (void)hipStreamDestroy(c->group->stream);
+        delete c->group;
+    }
     delete c;
 }
 
@@ -958,15 +1211,8 @@ extern "C" int tscm_shard_frames(const tscm_problem *p, int world, int *owner)
 {
     if (!p || !owner || world < 1) return fail(TSCM_E_INVALID, "bad arguments");
     if (int rc = validate(p)) return rc;
-    std::vector<double> per_board(p->n_boards, 0.0);
-    for (int v = 0; v < p->n_views; ++v) per_board[p->view_board[v]] += p->view_count[v];
-    double total = 0.0;
-    for (double x : per_board) total += x;
-    double before = 0.0;
-    for (int b = 0; b < p->n_boards; ++b) {
-        int r = total > 0.0 ? (int)(before * world / total) : 0;
-        owner[b] = std::min(r, world - 1);
-        before += per_board[b];
-    }
+    std::vector<int> o;
+    shard_owner(p, world, o);
+    std::copy(o.begin(), o.end(), owner);
     return 0;
 }

@@ -109,7 +109,8 @@ EXPORTS = [
     "tscm_solver_kernel_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
-    "tscm_shard_frames", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
+    "tscm_shard_frames", "tscm_solver_create_sharded", "tscm_comm_create_local", "tscm_solver_solve_group",
+    "tscm_solver_gather_boards", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
     "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
     "tscm_detect_corners", "tscm_detect_corners_batch", "tscm_corner_candidates_free", "tscm_chessboards_from_corners", "tscm_chessboards_free", "tscm_remap",
@@ -118,7 +119,8 @@ EXPORTS = [
 
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of csrc/ (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("tscm_solver.hip", "tscm_rig.hip", "tscm_maps.hip", "tscm_init.hip", "tscm_io.cpp", "tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h")]
+    import glob
+    srcs = [f for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(CSRC, pat))]     # same list as the Makefile
     srcs.append(os.path.join(_HERE, "..", "include", "tscm", "tscm.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
     if force or stale:
@@ -145,6 +147,10 @@ def lib():
     L.tscm_default_options.argtypes = [C.POINTER(COptions), C.c_int]
     L.tscm_default_options.restype = None
     L.tscm_solver_create.argtypes = [C.POINTER(CProblem), C.c_int, C.POINTER(vp)]
+    L.tscm_solver_create_sharded.argtypes = [C.POINTER(CProblem), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.tscm_comm_create_local.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.tscm_solver_solve_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(COptions), C.POINTER(CSummary), C.c_int]
+    L.tscm_solver_gather_boards.argtypes = [vp, dp]
     L.tscm_solver_set_comm.argtypes = [vp, vp]
     L.tscm_solver_solve.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary)]
     L.tscm_solver_upload_params.argtypes = [vp, dp, dp, dp]
