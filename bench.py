@@ -13,43 +13,120 @@ iteration does productive LM work; the iteration-0 evaluation of every solve is 
 timed region but not counted as a step).  Termination tests are disabled for the timed
 solves (tolerances < 0) so that exactly K iterations run.
 
-N > 1 (torchrun): frames are sharded across ranks (strong scaling: the job is fixed), one
-process per GPU, the reduced camera system is all-reduced with RCCL twice per iteration.
+N > 1: one process per GPU, frames sharded across the ranks (strong scaling: the job is fixed), two RCCL
+all-reduces per iteration.  The ranks are either started by `python -m torch.distributed.run ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or by this script itself: `python bench.py --gpus N`
+without WORLD_SIZE spawns N fresh child processes BEFORE anything touches the GPU.  No torch in any of them: the
+ncclUniqueId, the barriers and the max-over-ranks travel over a TCP side channel (tscm_calib_amd/rendezvous.py), so
+the only HIP runtime and RCCL in the process are the ones libtscm_hip.so links.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_eval_gram, timed
 with HIP events on the solver's own stream; `cpu_baseline` is the CPU oracle (a plain-C
-port of the reference's Ceres path, 1 thread like the reference) on a bounded sample.
+port of the reference's Ceres path) on the full workload, 1 thread like the reference, plus an all-cores figure.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from tscm_calib_amd import api, synth  # noqa: E402
-from tscm_calib_amd.problem import shard_frames  # noqa: E402
-
 ITERS_PER_SOLVE = 10
 # algorithmic work of one k_eval_gram launch (SURVEY 8d, DESIGN.md "roofline accounting")
-FLOP_PER_CORNER = 836 + 600          # Gram contraction 2P(P+1)+4P with P=19, + hand-structured geometry
+FLOP_MFMA_PER_CORNER = 836           # Gram contraction 2P(P+1)+4P with P=19
+FLOP_VALU_PER_CORNER = 600           # hand-structured residual + analytic Jacobian
+FLOP_PER_CORNER = FLOP_MFMA_PER_CORNER + FLOP_VALU_PER_CORNER
 BYTES_PER_CORNER = 16.0 + 168.0 / 54.0
 FP64_PEAK_TFLOPS = 78.6              # MI355X FP64 vector = matrix peak (AMD datasheet; not in MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3             # MI355X FP32 vector (packed) = FP32 matrix peak, same datasheet
 HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
+CPU_BASELINE_ITERS = 8
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start n rank processes of this script (one per GPU) and wait for them.  Runs in a parent that has not loaded
+    the library or touched HIP; the children are fresh interpreters (subprocess, never exec after GPU init)."""
+    import uuid
+    port = _free_port()
+    run = uuid.uuid4().hex
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TSCM_RDZV_PORT=str(port), TSCM_RDZV_RUN=run)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in pending:             # a rank died: its peers would wait for it forever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ stub (CPU tests)
+class _StubSolver:
+    """TSCM_BENCH_STUB=1: stands in for the GPU solver so that the launcher, the side channel, the timing protocol and
+    the JSON line can be exercised by the CPU test suite (tests/test_bench_launcher.py).  Never used otherwise."""
+
+    def __init__(self, problem, device=0, rank=0, world=1):
+        self.problem, self.rank, self.world = problem, rank, world
+
+    def set_comm(self, comm):
+        pass
+
+    def upload_params(self):
+        pass
+
+    def solve_resident(self, reset=True, max_num_iterations=50, **kw):
+        time.sleep(1e-3 * max_num_iterations * (1 + self.rank))      # rank r is (r + 1) x slower: max-over-ranks is visible
+        return dict(lm_iterations=max_num_iterations, num_iterations=max_num_iterations + 1, message="stub", rmse=0.0,
+                    seconds_solve=0.0)
+
+    def kernel_time(self, enable=True):
+        return 0, 0.0
+
+    def close(self):
+        pass
+
+
+def _kernel_src_sha() -> str:
+    """Identity of the hot kernel's sources: profiles/pmc_eval_gram.json records it with the traffic measurement."""
+    h = hashlib.sha256()
+    for f in ("tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h", "tscm_eval_f32.h"):
+        with open(os.path.join(ROOT, "tscm_calib_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def run_iterations(solver, n_iter, **extra):
     """Run exactly n_iter LM iterations as solves of <= ITERS_PER_SOLVE iterations."""
     done = 0
+    s = None
     while done < n_iter:
         k = min(ITERS_PER_SOLVE, n_iter - done)
         s = solver.solve_resident(reset=True, max_num_iterations=k, **BENCH_OPTS, **extra)
@@ -59,9 +136,10 @@ def run_iterations(solver, n_iter, **extra):
     return s
 
 
-def _grid_delta(intr_gpu, intr_cpu, device):
+def _grid_delta(api, intr_gpu, intr_cpu, device):
     """Rays of a 25 x 21 grid of pixels (1280 x 1080 image) under the GPU-fitted model, projected with the CPU-fitted
     one: the largest pixel displacement, over all cameras."""
+    import numpy as np
     uu, vv = np.meshgrid(np.linspace(40, 1240, 25), np.linspace(40, 1040, 21))
     px = np.stack([uu.ravel(), vv.ravel()], axis=1)
     worst = 0.0
@@ -73,34 +151,47 @@ def _grid_delta(intr_gpu, intr_cpu, device):
     return worst
 
 
-def cpu_baseline(full_problem, device):
-    """Oracle (port of the reference's Ceres DENSE_SCHUR LM, 1 thread) on the first 1/8 of the
-    frames of the same workload, termination disabled, scaled to the full corner count.  The GPU
-    runs the same sample with the same options: that is the "RMSE delta vs CPU" of the metric."""
+def cpu_baseline(full_problem, device, iters=CPU_BASELINE_ITERS):
+    """The CPU oracle (port of the reference's Ceres DENSE_SCHUR LM) on the FULL workload, termination tests disabled,
+    a fixed number of iterations: once with 1 thread (what the reference uses: num_threads is never set) and once
+    with all host cores (OpenMP over residual blocks / e-blocks: SURVEY 8d's generous baseline).  The GPU runs the
+    same iterations from the same start: that is the "RMSE delta vs CPU" of the metric."""
+    import numpy as np
     from oracle import pyoracle as orc
-    frac = 8
-    sub = shard_frames(full_problem, 0, frac).normalised()
-    iters = 8
+    from tscm_calib_amd import api
     opts = dict(max_num_iterations=iters, function_tolerance=-1.0, parameter_tolerance=-1.0,
                 gradient_tolerance=-1.0, min_trust_region_radius=0.0)
-    gsub = sub.copy().normalised()
-    with api.Solver(gsub, device=device) as gs:
+    pg = full_problem.copy().normalised()
+    with api.Solver(pg, device=device) as gs:
         g = gs.solve(**opts)
+    L = orc.lib()
+    po = full_problem.copy().normalised()
+    L.orc_set_num_threads(1)
     t0 = time.time()
-    s = orc.solve(sub, **opts)
-    wall = time.time() - t0
+    s = orc.solve(po, **opts)
+    wall1 = time.time() - t0
     n_it = s["num_iterations"] - 1
-    scale = sub.n_corners / full_problem.n_corners
-    rmse_cpu = math.sqrt(2.0 * s["final_cost"] / sub.n_corners)
+    cores = min(int(L.orc_max_threads()), os.cpu_count() or 1)
+    pm = full_problem.copy().normalised()
+    L.orc_set_num_threads(cores)
+    t0 = time.time()
+    sm = orc.solve(pm, **opts)
+    wallm = time.time() - t0
+    L.orc_set_num_threads(1)
+    n = full_problem.n_corners
+    rmse_cpu = math.sqrt(2.0 * s["final_cost"] / n)
     return {
-        "value": n_it / s["seconds_total"] * scale, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-        "sample": f"first 1/{frac} of the config-4 frames ({sub.n_corners} corners), {n_it} LM iterations in "
-                  f"{s['seconds_total']:.1f} s (wall {wall:.1f} s), scaled by corner count to 2.16 M corners",
-        "rmse_px_cpu": rmse_cpu, "rmse_px_gpu_same_sample": g["rmse"],
+        "value": n_it / s["seconds_total"], "unit": "LM iterations/s", "cores": 1, "kind": "port",
+        "sample": f"the full workload ({n} corners), {n_it} LM iterations with the termination tests off: "
+                  f"{s['seconds_total']:.1f} s in the minimiser (wall {wall1:.1f} s), 1 thread as in the reference",
+        "all_cores": {"value": (sm["num_iterations"] - 1) / sm["seconds_total"], "cores": cores,
+                      "seconds": sm["seconds_total"], "wall_seconds": wallm,
+                      "rmse_rel_delta_vs_1_thread": abs(math.sqrt(2.0 * sm["final_cost"] / n) - rmse_cpu) / rmse_cpu},
+        "rmse_px_cpu": rmse_cpu, "rmse_px_gpu_same_iterations": g["rmse"],
         "rmse_rel_delta": abs(g["rmse"] - rmse_cpu) / rmse_cpu,
-        "max_rel_intrinsics_delta": float(np.max(np.abs(gsub.intr[:, :7] - sub.intr[:, :7]) / np.abs(sub.intr[:, :7]))),
+        "max_rel_intrinsics_delta": float(np.max(np.abs(pg.intr[:, :7] - po.intr[:, :7]) / np.abs(po.intr[:, :7]))),
         # SURVEY 8d parity procedure: pixel-space difference of the two fitted models over a 25 x 21 image grid
-        "max_pixel_delta_25x21_grid": _grid_delta(gsub.intr, sub.intr, device),
+        "max_pixel_delta_25x21_grid": _grid_delta(api, pg.intr, po.intr, device),
     }
 
 
@@ -115,77 +206,111 @@ def main():
                     help="north_star's 1e-3 tier: fp32 derivatives + fp32 MFMA contraction (default: all fp64, the headline)")
     args = ap.parse_args()
 
+    force_dist = os.environ.get("TSCM_BENCH_FORCE_DIST") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        # not under a launcher: become one.  Nothing in this process has loaded the library or initialised the GPU.
+        sys.exit(launch_ranks(max(1, args.gpus), sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # TSCM_BENCH_FORCE_DIST=1 runs the multi-process code path (gloo side channel + RCCL communicator) with a
+    stub = os.environ.get("TSCM_BENCH_STUB") == "1"
+    if stub and os.environ.get("TSCM_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(7)                                            # tests/test_bench_launcher.py: a rank that dies early
+    # TSCM_BENCH_FORCE_DIST=1 runs the multi-process code path (launcher, side channel, RCCL communicator) with a
     # single rank, so that it can be exercised on a one-GPU box
-    multi = world > 1 or os.environ.get("TSCM_BENCH_FORCE_DIST") == "1"
-    if multi:
-        # torch is used for the CPU-side rendezvous only (gloo) and is imported BEFORE the library is first loaded
-        # (api.Solver below): the torch wheel carries its own HIP / RCCL runtime, and the library then binds to the
-        # copies that are already in the process.  torch.cuda is deliberately never touched -- device selection and
-        # fencing go through the C ABI instead.
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    multi = world > 1 or force_dist
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}: running {world} rank(s)", file=sys.stderr)
 
-    full = synth.make_config(args.config)
-    prob = shard_frames(full, rank, world).normalised() if world > 1 else full
+    from tscm_calib_amd import synth
+    chan = None
+    if multi:
+        from tscm_calib_amd.rendezvous import SideChannel
+        chan = SideChannel(rank, world)
+
+    if stub:
+        full = synth.make_problem(4, 8, 123)
+        api = lib = None
+        Solver = _StubSolver
+    else:
+        from tscm_calib_amd import api, lib
+        full = synth.make_config(args.config)
+        Solver = api.Solver
+        if lib.lib().tscm_device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: HIP device {local_rank} does not exist ({lib.lib().tscm_device_count()} visible): "
+                             f"--gpus {world} needs {world} GPUs (one process per GPU; RCCL refuses two ranks on one device)")
+
     t_create = time.perf_counter()
-    solver = api.Solver(prob, device=local_rank)          # H2D of the observations + layout build
+    solver = Solver(full, device=local_rank, rank=rank, world=world)          # H2D of this rank's observations + layout build
     t_create = time.perf_counter() - t_create
     comm = None
-    if multi:
-        uid = [api.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = api.Comm(uid[0], rank, world, local_rank)
+    rccl_ranks = world if stub else 1
+    if multi and not stub:
+        uid = chan.bcast(api.Comm.unique_id() if rank == 0 else None)
+        comm = api.Comm(uid, rank, world, local_rank)
         solver.set_comm(comm)
+        rccl_ranks = comm.backend_ranks()
     solver.upload_params()
 
     def barrier():
         # device fence (the job of torch.cuda.synchronize() in the contract) + process barrier
-        from tscm_calib_amd import lib as _lib
-        _lib.check(_lib.lib().tscm_device_synchronize(local_rank))
-        if multi:
-            dist.barrier()
+        if not stub:
+            lib.check(lib.lib().tscm_device_synchronize(local_rank))
+        if chan:
+            chan.barrier()
 
     # natural solve (reference options, termination tests on): untimed, doubles as warmup
     extra = dict(jacobian_fp32=1) if args.jacobian_fp32 else {}
     natural = solver.solve_resident(reset=True, **extra)
-    # warmup (untimed)
     if args.warmup > 0:
         run_iterations(solver, args.warmup, **extra)
     solver.kernel_time(enable=os.environ.get("TSCM_BENCH_NO_EVENTS") is None)
     barrier()
     t0 = time.perf_counter()
-    last = run_iterations(solver, args.steps, **extra)
+    run_iterations(solver, args.steps, **extra)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     launches, kms = solver.kernel_time(enable=False)
-    if multi:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = chan.allreduce_max(elapsed_local) if chan else elapsed_local
 
     if rank == 0:
-        n_local = prob.n_corners
+        n_local = int(full.n_corners / world) if stub else None
+        if not stub:
+            from tscm_calib_amd.problem import shard_frames
+            n_local = full.n_corners if world == 1 else shard_frames(full, rank, world).n_corners
         avg_ms = kms / max(launches, 1)
         flops = n_local * FLOP_PER_CORNER
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
-        if os.path.exists(pmc) and world == 1:
-            try:
-                traffic = json.load(open(pmc)).get(f"config{args.config}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        peak = FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS
+        roof = {
+            "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else "k_eval_gram", "bound": "mfma",
+            "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
+            "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
+            "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
+            "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+        }
+        if not stub and not args.jacobian_fp32:
+            # measured ceilings of THIS device, outside the timed region.  fp64 MFMA and fp64 VALU share the DP pipe
+            # (no overlap: tools/ubench_fp64.hip), so the kernel's floor is the SUM of its two parts at their own rates
+            import ctypes
+            pm, pv = ctypes.c_double(0.0), ctypes.c_double(0.0)
+            lib.check(lib.lib().tscm_device_peak_fp64(local_rank, ctypes.byref(pm), ctypes.byref(pv)))
+            floor_ms = 1e3 * n_local * (FLOP_MFMA_PER_CORNER / (pm.value * 1e12) + FLOP_VALU_PER_CORNER / (pv.value * 1e12))
+            roof.update(peak_measured_mfma_f64=pm.value, peak_measured_valu_f64=pv.value,
+                        measured_floor_ms=floor_ms, frac_of_measured_ceiling=floor_ms / avg_ms if avg_ms > 0 else 0.0)
+            pmc = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
+            if os.path.exists(pmc) and world == 1:
+                try:
+                    rec = json.load(open(pmc)).get(f"config{args.config}", {})
+                    # the PMC passes are separate runs: their figure only describes THIS kernel if the sources are unchanged
+                    if rec.get("kernel_src_sha") == _kernel_src_sha():
+                        roof["traffic"] = rec.get("hbm_bytes_per_launch")
+                        roof["traffic_source"] = "profiles/pmc_eval_gram.json (same kernel sources)"
+                    else:
+                        roof["traffic_source"] = "none: profiles/pmc_eval_gram.json was measured on other kernel sources"
+                except Exception:
+                    pass
         out = {
             "metric": "LM iterations/sec at 4 cams x 10k views (joint intrinsics+extrinsics, fp64)",
             "value": args.steps / elapsed,
@@ -197,31 +322,26 @@ def main():
             "vs_baseline": None,
             "dtype": "f64 (fp32 Jacobian + fp32 MFMA contraction)" if args.jacobian_fp32 else "f64",
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": f"BASELINE config {args.config}: {full.n_cameras} cams x "
-                                   f"{full.meta['views_per_cam']} views/cam, {full.n_boards} frames, "
-                                   f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta['seed']})",
+                                   f"{full.meta.get('views_per_cam')} views/cam, {full.n_boards} frames, "
+                                   f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta.get('seed')})",
                        "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)"},
             "natural_solve": {"termination": natural["message"], "iterations": natural["num_iterations"] - 1,
                               "rmse_px": natural["rmse"], "seconds": natural["seconds_solve"],
                               "create_seconds_incl_H2D_of_observations": t_create},
-            "roofline": {
-                "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else "k_eval_gram", "bound": "mfma",
-                "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tf / (FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS),
-                "traffic": None if args.jacobian_fp32 else traffic,
-                "launches": launches, "avg_launch_ms": avg_ms,
-                "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
-                "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
-            },
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(full, local_rank)
-        print(json.dumps(out))
-    if multi:
-        dist.barrier()
-        solver.close()
+        print(json.dumps(out), flush=True)
+    if chan:
+        chan.barrier()
+    solver.close()
+    if comm:
         comm.close()
-        dist.destroy_process_group()
+    if chan:
+        chan.close()
 
 
 if __name__ == "__main__":

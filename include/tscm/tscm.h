@@ -140,6 +140,9 @@ int tscm_device_count(void);
 /* hipSetDevice(device) + hipDeviceSynchronize(): lets a host (e.g. the multi-process benchmark) fence the
  * GPU without loading a second HIP runtime of its own. */
 int tscm_device_synchronize(int device);
+/* Measured fp64 ceilings of the device, every CU busy: v_mfma_f64_16x16x4_f64 and v_fma_f64 throughput in TFLOP/s
+ * (a few milliseconds of micro-kernels; benchmark / roofline reporting only, not on any solver path). */
+int tscm_device_peak_fp64(int device, double *mfma_tflops, double *valu_tflops);
 
 void tscm_default_options(tscm_options *opt, int mono);
 
@@ -241,6 +244,9 @@ int tscm_comm_unique_id(unsigned char id[TSCM_UNIQUE_ID_BYTES]);
 int tscm_comm_create(const unsigned char id[TSCM_UNIQUE_ID_BYTES], int rank, int world, int device, tscm_comm **out);
 int tscm_comm_create_local(int world, int device, tscm_comm **out /* [world] */);
 void tscm_comm_destroy(tscm_comm *c);
+/* rank / world the communicator was created with and the number of ranks the back-end itself reports
+ * (ncclCommCount for RCCL, the group size for LOCAL); any output may be NULL. */
+int tscm_comm_info(const tscm_comm *c, int *rank, int *world, int *backend_ranks);
 /* solvers[r] = shard r of n with the r-th communicator of one tscm_comm_create_local call; summaries [n]. */
 int tscm_solver_solve_group(tscm_solver **solvers, int n, const tscm_options *opt, tscm_summary *summaries, int reset);
 int tscm_solver_gather_boards(tscm_solver *s, double *board_rt);

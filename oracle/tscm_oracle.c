@@ -261,6 +261,32 @@ void orc_unproject(const double *I, const double *uv, double *ray)
 }
 
 /* ======================================================================== *
+ *  Optional multi-threading (OpenMP).  The reference never sets
+ *  Solver::Options::num_threads (TS.cpp:271-274, multi_calib.cpp:209-212), so
+ *  the checker and the 1-core CPU baseline run with ONE thread -- that path
+ *  is the sequential code below, untouched.  orc_set_num_threads(n > 1)
+ *  switches the O(N) passes to OpenMP loops (what Ceres does with
+ *  num_threads = n: evaluation over residual blocks, Schur elimination over
+ *  e-blocks with per-thread accumulators): the "all host cores" baseline of
+ *  SURVEY 8d.  Sums are then associated per thread / per view, so results
+ *  agree with the sequential path to rounding, not bit for bit.
+ * ======================================================================== */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int g_orc_threads = 1;
+void orc_set_num_threads(int n) { g_orc_threads = n < 1 ? 1 : n; }
+int orc_get_num_threads(void) { return g_orc_threads; }
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ======================================================================== *
  *  Batched evaluation
  * ======================================================================== */
 static int total_corners(const orc_problem *p)
@@ -273,34 +299,54 @@ static int total_corners(const orc_problem *p)
 /* Evaluate into caller arrays indexed by the *program order* used by the solver:
  * views in the given order, corners in order.  Row index = position in obs arrays is
  * NOT assumed contiguous, so outputs are indexed by a running counter. */
+static double evaluate_view(const orc_problem *p, int v, long k, int use_jets, double *residuals,
+                            double *J_cam, double *J_board, double *J_intr, double cost)
+{
+    const int m = p->view_camera[v], b = p->view_board[v];
+    const double *crt = p->cam_rt ? p->cam_rt + 6 * m : NULL;
+    const double *brt = p->board_rt + 6 * b;
+    const double *I = p->intr + 9 * m;
+    for (int j = 0; j < p->view_count[v]; ++j, ++k) {
+        const double obs[2] = { p->obs_u[p->view_offset[v] + j], p->obs_v[p->view_offset[v] + j] };
+        const double *bp = p->board_xy + 2 * j;
+        double r[2];
+        if (!use_jets) {
+            if (p->mono) orc_mono_residual(I, brt, obs, bp, r);
+            else orc_multi_residual(crt, brt, I, obs, bp, r);
+        } else if (p->mono) {
+            orc_mono_autodiff(I, brt, obs, bp, r, J_intr ? J_intr + 18 * k : NULL, J_board ? J_board + 12 * k : NULL);
+            if (J_cam) memset(J_cam + 12 * k, 0, 12 * sizeof(double));
+        } else {
+            orc_multi_autodiff(crt, brt, I, obs, bp, r, J_cam ? J_cam + 12 * k : NULL,
+                               J_board ? J_board + 12 * k : NULL, J_intr ? J_intr + 18 * k : NULL);
+        }
+        if (residuals) { residuals[2 * k] = r[0]; residuals[2 * k + 1] = r[1]; }
+        /* ResidualBlock::Evaluate: cost = 0.5 * squaredNorm; evaluator sums block costs */
+        cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    }
+    return cost;
+}
+
 double orc_evaluate(const orc_problem *p, int use_jets, double *residuals,
                     double *J_cam, double *J_board, double *J_intr)
 {
+    if (g_orc_threads > 1 && p->n_views > 1) {
+        long *row = (long *)malloc(sizeof(long) * (size_t)p->n_views);
+        double *part = (double *)malloc(sizeof(double) * (size_t)p->n_views);
+        if (!row || !part) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+        { long k = 0; for (int v = 0; v < p->n_views; ++v) { row[v] = k; k += p->view_count[v]; } }
+#pragma omp parallel for schedule(static) num_threads(g_orc_threads)
+        for (int v = 0; v < p->n_views; ++v) part[v] = evaluate_view(p, v, row[v], use_jets, residuals, J_cam, J_board, J_intr, 0.0);
+        double cost = 0.0;
+        for (int v = 0; v < p->n_views; ++v) cost += part[v];
+        free(row); free(part);
+        return cost;
+    }
     double cost = 0.0;
     long k = 0;
     for (int v = 0; v < p->n_views; ++v) {
-        const int m = p->view_camera[v], b = p->view_board[v];
-        const double *crt = p->cam_rt ? p->cam_rt + 6 * m : NULL;
-        const double *brt = p->board_rt + 6 * b;
-        const double *I = p->intr + 9 * m;
-        for (int j = 0; j < p->view_count[v]; ++j, ++k) {
-            const double obs[2] = { p->obs_u[p->view_offset[v] + j], p->obs_v[p->view_offset[v] + j] };
-            const double *bp = p->board_xy + 2 * j;
-            double r[2];
-            if (!use_jets) {
-                if (p->mono) orc_mono_residual(I, brt, obs, bp, r);
-                else orc_multi_residual(crt, brt, I, obs, bp, r);
-            } else if (p->mono) {
-                orc_mono_autodiff(I, brt, obs, bp, r, J_intr ? J_intr + 18 * k : NULL, J_board ? J_board + 12 * k : NULL);
-                if (J_cam) memset(J_cam + 12 * k, 0, 12 * sizeof(double));
-            } else {
-                orc_multi_autodiff(crt, brt, I, obs, bp, r, J_cam ? J_cam + 12 * k : NULL,
-                                   J_board ? J_board + 12 * k : NULL, J_intr ? J_intr + 18 * k : NULL);
-            }
-            if (residuals) { residuals[2 * k] = r[0]; residuals[2 * k + 1] = r[1]; }
-            /* ResidualBlock::Evaluate: cost = 0.5 * squaredNorm; evaluator sums block costs */
-            cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-        }
+        cost = evaluate_view(p, v, k, use_jets, residuals, J_cam, J_board, J_intr, cost);     /* one running sum, program order */
+        k += p->view_count[v];
     }
     return cost;
 }
@@ -423,50 +469,95 @@ static double lm_eval(lm_state *S, const double *cam, const double *intr, const 
 }
 
 /* gradient = J^T r (unscaled Jacobian) */
+static void gradient_view(lm_state *S, int v, double *g_f, double *g_b)
+{
+    const orc_problem *p = S->p;
+    const int m = p->view_camera[v], b = p->view_board[v];
+    const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+    for (int j = 0; j < p->view_count[v]; ++j) {
+        const long k = S->view_row[v] + j;
+        for (int r = 0; r < 2; ++r) {
+            const double rr = S->res[2 * k + r];
+            if (cc >= 0) for (int i = 0; i < 6; ++i) g_f[cc + i] += S->Jc[12 * k + 6 * r + i] * rr;
+            for (int i = 0; i < 9; ++i) g_f[ic + i] += S->Ji[18 * k + 9 * r + i] * rr;
+            for (int i = 0; i < 6; ++i) g_b[6 * b + i] += S->Jb[12 * k + 6 * r + i] * rr;
+        }
+    }
+}
+
+/* threads > 1: boards are dealt to the threads in contiguous blocks (a board's rows are written by one thread), the
+ * f-part is accumulated per thread and the per-thread sums are added in thread order */
+#define ORC_MT_BOARD_LOOP(NF_ACC, BODY)                                                          \
+    do {                                                                                         \
+        const int T_ = g_orc_threads;                                                            \
+        double *acc_ = (double *)xcalloc((size_t)T_ * (size_t)(NF_ACC), sizeof(double));         \
+        _Pragma("omp parallel num_threads(T_)")                                                  \
+        {                                                                                        \
+            int t_ = 0;                                                                          \
+            ORC_THREAD_ID(t_);                                                                   \
+            double *accf = acc_ + (size_t)t_ * (size_t)(NF_ACC);                                 \
+            _Pragma("omp for schedule(static)")                                                  \
+            for (int b = 0; b < S->B; ++b)                                                       \
+                for (int q_ = S->bv_ptr[b]; q_ < S->bv_ptr[b + 1]; ++q_) { const int v = S->bv_idx[q_]; BODY; } \
+        }                                                                                        \
+        for (int t_ = 0; t_ < T_; ++t_) for (int i_ = 0; i_ < (NF_ACC); ++i_) ORC_MT_OUT[i_] += acc_[(size_t)t_ * (size_t)(NF_ACC) + i_]; \
+        free(acc_);                                                                              \
+    } while (0)
+#ifdef _OPENMP
+#define ORC_THREAD_ID(t) (t) = omp_get_thread_num()
+#else
+#define ORC_THREAD_ID(t) (t) = 0
+#endif
+
 static void lm_gradient(lm_state *S)
 {
     const orc_problem *p = S->p;
     memset(S->g_f, 0, sizeof(double) * (size_t)S->nf);
     memset(S->g_b, 0, sizeof(double) * 6 * (size_t)S->B);
-    for (int v = 0; v < p->n_views; ++v) {
-        const int m = p->view_camera[v], b = p->view_board[v];
-        const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
-        for (int j = 0; j < p->view_count[v]; ++j) {
-            const long k = S->view_row[v] + j;
-            for (int r = 0; r < 2; ++r) {
-                const double rr = S->res[2 * k + r];
-                if (cc >= 0) for (int i = 0; i < 6; ++i) S->g_f[cc + i] += S->Jc[12 * k + 6 * r + i] * rr;
-                for (int i = 0; i < 9; ++i) S->g_f[ic + i] += S->Ji[18 * k + 9 * r + i] * rr;
-                for (int i = 0; i < 6; ++i) S->g_b[6 * b + i] += S->Jb[12 * k + 6 * r + i] * rr;
-            }
+    if (g_orc_threads > 1) {
+#define ORC_MT_OUT S->g_f
+        ORC_MT_BOARD_LOOP(S->nf, gradient_view(S, v, accf, S->g_b));
+#undef ORC_MT_OUT
+        return;
+    }
+    for (int v = 0; v < p->n_views; ++v) gradient_view(S, v, S->g_f, S->g_b);
+}
+
+/* SquaredColumnNorm of the Jacobian currently stored */
+static void sq_col_norm_view(lm_state *S, int v, double *nf, double *nb)
+{
+    const orc_problem *p = S->p;
+    const int m = p->view_camera[v], b = p->view_board[v];
+    const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+    for (int j = 0; j < p->view_count[v]; ++j) {
+        const long k = S->view_row[v] + j;
+        for (int r = 0; r < 2; ++r) {
+            if (cc >= 0) for (int i = 0; i < 6; ++i) { const double a = S->Jc[12 * k + 6 * r + i]; nf[cc + i] += a * a; }
+            for (int i = 0; i < 9; ++i) { const double a = S->Ji[18 * k + 9 * r + i]; nf[ic + i] += a * a; }
+            for (int i = 0; i < 6; ++i) { const double a = S->Jb[12 * k + 6 * r + i]; nb[6 * b + i] += a * a; }
         }
     }
 }
 
-/* SquaredColumnNorm of the Jacobian currently stored */
 static void lm_sq_col_norm(lm_state *S, double *nf, double *nb)
 {
     const orc_problem *p = S->p;
     memset(nf, 0, sizeof(double) * (size_t)S->nf);
     memset(nb, 0, sizeof(double) * 6 * (size_t)S->B);
-    for (int v = 0; v < p->n_views; ++v) {
-        const int m = p->view_camera[v], b = p->view_board[v];
-        const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
-        for (int j = 0; j < p->view_count[v]; ++j) {
-            const long k = S->view_row[v] + j;
-            for (int r = 0; r < 2; ++r) {
-                if (cc >= 0) for (int i = 0; i < 6; ++i) { const double a = S->Jc[12 * k + 6 * r + i]; nf[cc + i] += a * a; }
-                for (int i = 0; i < 9; ++i) { const double a = S->Ji[18 * k + 9 * r + i]; nf[ic + i] += a * a; }
-                for (int i = 0; i < 6; ++i) { const double a = S->Jb[12 * k + 6 * r + i]; nb[6 * b + i] += a * a; }
-            }
-        }
+    if (g_orc_threads > 1) {
+#define ORC_MT_OUT nf
+        ORC_MT_BOARD_LOOP(S->nf, sq_col_norm_view(S, v, accf, nb));
+#undef ORC_MT_OUT
+        return;
     }
+    for (int v = 0; v < p->n_views; ++v) sq_col_norm_view(S, v, nf, nb);
 }
 
 /* jacobian->ScaleColumns(jacobian_scaling) */
 static void lm_scale_columns(lm_state *S)
 {
     const orc_problem *p = S->p;
+#pragma omp parallel for schedule(static) num_threads(g_orc_threads) if (g_orc_threads > 1)
     for (int v = 0; v < p->n_views; ++v) {
         const int m = p->view_camera[v], b = p->view_board[v];
         const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
@@ -485,6 +576,121 @@ static void lm_scale_columns(lm_state *S)
  * SchurEliminator::BackSubstitute.  Solves (J^T J + D^T D) y = J^T r for the scaled
  * Jacobian; y goes to step_f / step_b (sign flipped by the caller).
  * Returns 0 ok, -1 LINEAR_SOLVER_FAILURE. */
+/* Elimination of ONE e-block (board b): accumulates F^T F, F^T b and the Schur complement terms into lhs / rhs.
+ * `buffer` [6 * nf] and `touched` [C] are scratch.  Returns 0, or -1 if E^T E + D^2 is not positive definite. */
+static int schur_eliminate_board(lm_state *S, int b, double radius, double *lhs, double *rhs, double *buffer, int *touched)
+{
+    const orc_problem *p = S->p;
+    const int nf = S->nf;
+    if (!S->board_active[b]) return 0;
+    double ete[36], g[6];
+    memset(ete, 0, sizeof(ete)); memset(g, 0, sizeof(g));
+    for (int i = 0; i < 6; ++i) { const double D = sqrt(S->d_b[6 * b + i] / radius); ete[i * 6 + i] = D * D; }
+    int nt = 0;
+    for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
+        const int v = S->bv_idx[q];
+        const int m = p->view_camera[v];
+        const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+        touched[nt++] = m;
+        if (cc >= 0) for (int i = 0; i < 6; ++i) memset(buffer + i * nf + cc, 0, 6 * sizeof(double));
+        for (int i = 0; i < 6; ++i) memset(buffer + i * nf + ic, 0, 9 * sizeof(double));
+    }
+    for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
+        const int v = S->bv_idx[q];
+        const int m = p->view_camera[v];
+        const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+        for (int j = 0; j < p->view_count[v]; ++j) {
+            const long k = S->view_row[v] + j;
+            for (int r = 0; r < 2; ++r) {
+                const double *E = S->Jb + 12 * k + 6 * r;
+                const double *Fc = S->Jc + 12 * k + 6 * r;
+                const double *Fi = S->Ji + 18 * k + 9 * r;
+                const double rr = S->res[2 * k + r];
+                for (int i = 0; i < 6; ++i) {
+                    for (int l = 0; l < 6; ++l) ete[i * 6 + l] += E[i] * E[l];
+                    g[i] += E[i] * rr;
+                    if (cc >= 0) for (int l = 0; l < 6; ++l) buffer[i * nf + cc + l] += E[i] * Fc[l];
+                    for (int l = 0; l < 9; ++l) buffer[i * nf + ic + l] += E[i] * Fi[l];
+                }
+                /* lhs += F^T F ; rhs += F^T b */
+                if (cc >= 0) {
+                    for (int i = 0; i < 6; ++i) {
+                        for (int l = 0; l < 6; ++l) lhs[(cc + i) * nf + cc + l] += Fc[i] * Fc[l];
+                        for (int l = 0; l < 9; ++l) { const double t = Fc[i] * Fi[l]; lhs[(cc + i) * nf + ic + l] += t; lhs[(ic + l) * nf + cc + i] += t; }
+                        rhs[cc + i] += Fc[i] * rr;
+                    }
+                }
+                for (int i = 0; i < 9; ++i) {
+                    for (int l = 0; l < 9; ++l) lhs[(ic + i) * nf + ic + l] += Fi[i] * Fi[l];
+                    rhs[ic + i] += Fi[i] * rr;
+                }
+            }
+        }
+    }
+    double *inv = S->inv_ete + 36 * b;
+    if (invert_psd6(ete, inv) != 0) return -1;
+    /* lhs -= buffer^T inv buffer ; rhs -= buffer^T inv g   (only over touched f-blocks) */
+    double ig[6];
+    for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += inv[i * 6 + l] * g[l]; ig[i] = s; }
+    for (int t1 = 0; t1 < nt; ++t1) {
+        const int m1 = touched[t1];
+        for (int part1 = 0; part1 < 2; ++part1) {
+            const int c1 = part1 ? S->intr_col[m1] : S->cam_pose_col[m1];
+            const int w1 = part1 ? 9 : 6;
+            if (c1 < 0) continue;
+            for (int a = 0; a < w1; ++a) {
+                double ib[6]; /* inv * buffer[:, c1+a] */
+                for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += inv[i * 6 + l] * buffer[l * nf + c1 + a]; ib[i] = s; }
+                double sg = 0; for (int i = 0; i < 6; ++i) sg += buffer[i * nf + c1 + a] * ig[i];
+                rhs[c1 + a] -= sg;
+                for (int t2 = 0; t2 < nt; ++t2) {
+                    const int m2 = touched[t2];
+                    for (int part2 = 0; part2 < 2; ++part2) {
+                        const int c2 = part2 ? S->intr_col[m2] : S->cam_pose_col[m2];
+                        const int w2 = part2 ? 9 : 6;
+                        if (c2 < 0) continue;
+                        for (int bcol = 0; bcol < w2; ++bcol) {
+                            double s = 0; for (int i = 0; i < 6; ++i) s += buffer[i * nf + c2 + bcol] * ib[i];
+                            lhs[(c2 + bcol) * nf + c1 + a] -= s;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* SchurEliminator::BackSubstitute for ONE e-block: y_e = inv_ete * sum_rows E^T (b - F z) */
+static void schur_backsubstitute_board(lm_state *S, int b)
+{
+    const orc_problem *p = S->p;
+    double *y = S->step_b + 6 * b;
+    for (int i = 0; i < 6; ++i) y[i] = 0.0;
+    if (!S->board_active[b]) return;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
+        const int v = S->bv_idx[q];
+        const int m = p->view_camera[v];
+        const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+        for (int j = 0; j < p->view_count[v]; ++j) {
+            const long k = S->view_row[v] + j;
+            for (int r = 0; r < 2; ++r) {
+                double sj = S->res[2 * k + r];
+                if (cc >= 0) for (int l = 0; l < 6; ++l) sj -= S->Jc[12 * k + 6 * r + l] * S->step_f[cc + l];
+                for (int l = 0; l < 9; ++l) sj -= S->Ji[18 * k + 9 * r + l] * S->step_f[ic + l];
+                for (int i = 0; i < 6; ++i) acc[i] += S->Jb[12 * k + 6 * r + i] * sj;
+            }
+        }
+    }
+    const double *inv = S->inv_ete + 36 * b;
+    for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += inv[i * 6 + l] * acc[l]; y[i] = s; }
+}
+
+/* SchurEliminator::Eliminate + dense Cholesky of the reduced system +
+ * SchurEliminator::BackSubstitute.  Solves (J^T J + D^T D) y = J^T r for the scaled
+ * Jacobian; y goes to step_f / step_b (sign flipped by the caller).
+ * Returns 0 ok, -1 LINEAR_SOLVER_FAILURE. */
 static int lm_schur_solve(lm_state *S, double radius)
 {
     const orc_problem *p = S->p;
@@ -494,87 +700,41 @@ static int lm_schur_solve(lm_state *S, double radius)
     /* lm_diagonal = sqrt(diagonal / radius); D^T D = diagonal / radius */
     for (int i = 0; i < nf; ++i) { const double D = sqrt(S->d_f[i] / radius); S->lhs[i * nf + i] = D * D; }
 
-    double *buffer = (double *)xcalloc((size_t)6 * nf, sizeof(double)); /* E^T F, dense over f-columns */
-    int *touched = (int *)xcalloc((size_t)p->n_cameras, sizeof(int));
-    for (int b = 0; b < S->B; ++b) {
-        if (!S->board_active[b]) continue;
-        double ete[36], g[6];
-        memset(ete, 0, sizeof(ete)); memset(g, 0, sizeof(g));
-        for (int i = 0; i < 6; ++i) { const double D = sqrt(S->d_b[6 * b + i] / radius); ete[i * 6 + i] = D * D; }
-        int nt = 0;
-        for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
-            const int v = S->bv_idx[q];
-            const int m = p->view_camera[v];
-            const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
-            touched[nt++] = m;
-            if (cc >= 0) for (int i = 0; i < 6; ++i) memset(buffer + i * nf + cc, 0, 6 * sizeof(double));
-            for (int i = 0; i < 6; ++i) memset(buffer + i * nf + ic, 0, 9 * sizeof(double));
-        }
-        for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
-            const int v = S->bv_idx[q];
-            const int m = p->view_camera[v];
-            const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
-            for (int j = 0; j < p->view_count[v]; ++j) {
-                const long k = S->view_row[v] + j;
-                for (int r = 0; r < 2; ++r) {
-                    const double *E = S->Jb + 12 * k + 6 * r;
-                    const double *Fc = S->Jc + 12 * k + 6 * r;
-                    const double *Fi = S->Ji + 18 * k + 9 * r;
-                    const double rr = S->res[2 * k + r];
-                    for (int i = 0; i < 6; ++i) {
-                        for (int l = 0; l < 6; ++l) ete[i * 6 + l] += E[i] * E[l];
-                        g[i] += E[i] * rr;
-                        if (cc >= 0) for (int l = 0; l < 6; ++l) buffer[i * nf + cc + l] += E[i] * Fc[l];
-                        for (int l = 0; l < 9; ++l) buffer[i * nf + ic + l] += E[i] * Fi[l];
-                    }
-                    /* lhs += F^T F ; rhs += F^T b */
-                    if (cc >= 0) {
-                        for (int i = 0; i < 6; ++i) {
-                            for (int l = 0; l < 6; ++l) S->lhs[(cc + i) * nf + cc + l] += Fc[i] * Fc[l];
-                            for (int l = 0; l < 9; ++l) { const double t = Fc[i] * Fi[l]; S->lhs[(cc + i) * nf + ic + l] += t; S->lhs[(ic + l) * nf + cc + i] += t; }
-                            S->rhs[cc + i] += Fc[i] * rr;
-                        }
-                    }
-                    for (int i = 0; i < 9; ++i) {
-                        for (int l = 0; l < 9; ++l) S->lhs[(ic + i) * nf + ic + l] += Fi[i] * Fi[l];
-                        S->rhs[ic + i] += Fi[i] * rr;
-                    }
+    if (g_orc_threads > 1) {
+        /* e-blocks dealt to the threads in contiguous blocks, per-thread lhs / rhs added in thread order */
+        const int T = g_orc_threads;
+        const size_t stride = (size_t)nf * nf + (size_t)nf;
+        double *acc = (double *)xcalloc((size_t)T * stride, sizeof(double));
+        int failed = 0;
+#pragma omp parallel num_threads(T)
+        {
+            int t = 0;
+            ORC_THREAD_ID(t);
+            double *buffer = (double *)xcalloc((size_t)6 * nf, sizeof(double));
+            int *touched = (int *)xcalloc((size_t)p->n_cameras, sizeof(int));
+            double *lhs = acc + (size_t)t * stride, *rhs = lhs + (size_t)nf * nf;
+#pragma omp for schedule(static)
+            for (int b = 0; b < S->B; ++b)
+                if (schur_eliminate_board(S, b, radius, lhs, rhs, buffer, touched) != 0) {
+#pragma omp atomic write
+                    failed = 1;
                 }
-            }
+            free(buffer); free(touched);
         }
-        double *inv = S->inv_ete + 36 * b;
-        if (invert_psd6(ete, inv) != 0) { free(buffer); free(touched); return -1; }
-        /* lhs -= buffer^T inv buffer ; rhs -= buffer^T inv g   (only over touched f-blocks) */
-        double ig[6];
-        for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += inv[i * 6 + l] * g[l]; ig[i] = s; }
-        for (int t1 = 0; t1 < nt; ++t1) {
-            const int m1 = touched[t1];
-            for (int part1 = 0; part1 < 2; ++part1) {
-                const int c1 = part1 ? S->intr_col[m1] : S->cam_pose_col[m1];
-                const int w1 = part1 ? 9 : 6;
-                if (c1 < 0) continue;
-                for (int a = 0; a < w1; ++a) {
-                    double ib[6]; /* inv * buffer[:, c1+a] */
-                    for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += inv[i * 6 + l] * buffer[l * nf + c1 + a]; ib[i] = s; }
-                    double sg = 0; for (int i = 0; i < 6; ++i) sg += buffer[i * nf + c1 + a] * ig[i];
-                    S->rhs[c1 + a] -= sg;
-                    for (int t2 = 0; t2 < nt; ++t2) {
-                        const int m2 = touched[t2];
-                        for (int part2 = 0; part2 < 2; ++part2) {
-                            const int c2 = part2 ? S->intr_col[m2] : S->cam_pose_col[m2];
-                            const int w2 = part2 ? 9 : 6;
-                            if (c2 < 0) continue;
-                            for (int bcol = 0; bcol < w2; ++bcol) {
-                                double s = 0; for (int i = 0; i < 6; ++i) s += buffer[i * nf + c2 + bcol] * ib[i];
-                                S->lhs[(c2 + bcol) * nf + c1 + a] -= s;
-                            }
-                        }
-                    }
-                }
-            }
+        for (int t = 0; t < T; ++t) {
+            const double *lhs = acc + (size_t)t * stride, *rhs = lhs + (size_t)nf * nf;
+            for (size_t i = 0; i < (size_t)nf * nf; ++i) S->lhs[i] += lhs[i];
+            for (int i = 0; i < nf; ++i) S->rhs[i] += rhs[i];
         }
+        free(acc);
+        if (failed) return -1;
+    } else {
+        double *buffer = (double *)xcalloc((size_t)6 * nf, sizeof(double)); /* E^T F, dense over f-columns */
+        int *touched = (int *)xcalloc((size_t)p->n_cameras, sizeof(int));
+        for (int b = 0; b < S->B; ++b)
+            if (schur_eliminate_board(S, b, radius, S->lhs, S->rhs, buffer, touched) != 0) { free(buffer); free(touched); return -1; }
+        free(buffer); free(touched);
     }
-    free(buffer); free(touched);
 
     /* DenseSchurComplementSolver::SolveReducedLinearSystem: Eigen LLT */
     double *L = (double *)xcalloc((size_t)nf * nf, sizeof(double));
@@ -584,51 +744,43 @@ static int lm_schur_solve(lm_state *S, double radius)
     chol_solve(L, nf, S->step_f);
     free(L);
 
-    /* BackSubstitute: y_e = inv_ete * sum_rows E^T (b - F z) */
-    for (int b = 0; b < S->B; ++b) {
-        double *y = S->step_b + 6 * b;
-        for (int i = 0; i < 6; ++i) y[i] = 0.0;
-        if (!S->board_active[b]) continue;
-        double acc[6] = { 0, 0, 0, 0, 0, 0 };
-        for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
-            const int v = S->bv_idx[q];
-            const int m = p->view_camera[v];
-            const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
-            for (int j = 0; j < p->view_count[v]; ++j) {
-                const long k = S->view_row[v] + j;
-                for (int r = 0; r < 2; ++r) {
-                    double sj = S->res[2 * k + r];
-                    if (cc >= 0) for (int l = 0; l < 6; ++l) sj -= S->Jc[12 * k + 6 * r + l] * S->step_f[cc + l];
-                    for (int l = 0; l < 9; ++l) sj -= S->Ji[18 * k + 9 * r + l] * S->step_f[ic + l];
-                    for (int i = 0; i < 6; ++i) acc[i] += S->Jb[12 * k + 6 * r + i] * sj;
-                }
-            }
-        }
-        const double *inv = S->inv_ete + 36 * b;
-        for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += inv[i * 6 + l] * acc[l]; y[i] = s; }
-    }
+#pragma omp parallel for schedule(static) num_threads(g_orc_threads) if (g_orc_threads > 1)
+    for (int b = 0; b < S->B; ++b) schur_backsubstitute_board(S, b);
     return 0;
 }
 
 /* model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step) */
+static double model_cost_change_view(lm_state *S, int v, double acc)
+{
+    const orc_problem *p = S->p;
+    const int m = p->view_camera[v], b = p->view_board[v];
+    const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+    for (int j = 0; j < p->view_count[v]; ++j) {
+        const long k = S->view_row[v] + j;
+        for (int r = 0; r < 2; ++r) {
+            double mr = 0.0;
+            if (cc >= 0) for (int l = 0; l < 6; ++l) mr += S->Jc[12 * k + 6 * r + l] * S->step_f[cc + l];
+            for (int l = 0; l < 9; ++l) mr += S->Ji[18 * k + 9 * r + l] * S->step_f[ic + l];
+            for (int l = 0; l < 6; ++l) mr += S->Jb[12 * k + 6 * r + l] * S->step_b[6 * b + l];
+            acc += mr * (S->res[2 * k + r] + mr / 2.0);
+        }
+    }
+    return acc;
+}
+
 static double lm_model_cost_change(lm_state *S)
 {
     const orc_problem *p = S->p;
     double acc = 0.0;
-    for (int v = 0; v < p->n_views; ++v) {
-        const int m = p->view_camera[v], b = p->view_board[v];
-        const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
-        for (int j = 0; j < p->view_count[v]; ++j) {
-            const long k = S->view_row[v] + j;
-            for (int r = 0; r < 2; ++r) {
-                double mr = 0.0;
-                if (cc >= 0) for (int l = 0; l < 6; ++l) mr += S->Jc[12 * k + 6 * r + l] * S->step_f[cc + l];
-                for (int l = 0; l < 9; ++l) mr += S->Ji[18 * k + 9 * r + l] * S->step_f[ic + l];
-                for (int l = 0; l < 6; ++l) mr += S->Jb[12 * k + 6 * r + l] * S->step_b[6 * b + l];
-                acc += mr * (S->res[2 * k + r] + mr / 2.0);
-            }
-        }
+    if (g_orc_threads > 1) {
+        double *part = (double *)xcalloc((size_t)p->n_views, sizeof(double));
+#pragma omp parallel for schedule(static) num_threads(g_orc_threads)
+        for (int v = 0; v < p->n_views; ++v) part[v] = model_cost_change_view(S, v, 0.0);
+        for (int v = 0; v < p->n_views; ++v) acc += part[v];
+        free(part);
+        return -acc;
     }
+    for (int v = 0; v < p->n_views; ++v) acc = model_cost_change_view(S, v, acc);
     return -acc;
 }
 

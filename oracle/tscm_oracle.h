@@ -130,6 +130,11 @@ void orc_multi_autodiff(const double *cam_rt, const double *board_rt, const doub
 /* residuals [2N] interleaved (u,v per corner); J_* may be NULL; layout per corner:
  * J_cam[2*6], J_board[2*6], J_intr[2*9] row-major.  Returns cost = 0.5*sum r^2.
  * use_jets=0 evaluates the double functor (cost-only path of Ceres).           */
+/* threads of the O(N) passes (default 1 = the sequential checker path; see tscm_oracle.c) */
+void orc_set_num_threads(int n);
+int orc_get_num_threads(void);
+int orc_max_threads(void);
+
 double orc_evaluate(const orc_problem *p, int use_jets, double *residuals,
                     double *J_cam, double *J_board, double *J_intr);
 

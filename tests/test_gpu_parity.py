@@ -167,6 +167,54 @@ def test_lm_multi_config3(hip_device):
     assert abs(rmse - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
 
 
+def test_lm_mono_config2(hip_device):
+    """BASELINE config 2: single fisheye, 2000 views x 54 corners -- the reference's mono problem (TS.cpp:247-282:
+    9 intrinsics + a pose block per view) at full size, trace and parameters against the oracle."""
+    p = synth.make_config(2)
+    assert p.mono and p.n_views == 2000 and p.n_corners == 108000
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    e = H.param_rel_err(pg, po)
+    assert e["intr"] < 1e-6 and e["board_rt"] < 1e-6, e
+    assert abs(gs["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
+    assert gs["termination"] == "CONVERGENCE"
+
+
+def test_lm_multi_config4_vs_oracle(hip_device):
+    """BASELINE config 4 (the headline: 4 cameras x 10k views, 2.16 M corners) at FULL size against the sequential
+    oracle: whole iteration trace, termination, every parameter block and the error report.  ~30 s of oracle."""
+    p = synth.make_config(4)
+    assert p.n_corners == 2160000
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    e = H.param_rel_err(pg, po)
+    assert max(e.values()) < 1e-6, e
+    og, oper = orc.mean_reprojection_error(po)
+    per, g, rmse = api.reprojection_error(pg)
+    assert abs(g - og) <= 1e-6 * og and np.max(np.abs(per - oper) / oper) < 1e-6
+    assert abs(rmse - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
+    assert abs(gs["rmse"] - rmse) <= 1e-9 * rmse
+
+
+def test_lm_multi_config5_vs_oracle(hip_device):
+    """BASELINE config 5 (8 cameras x 20k views, 8.64 M corners, 114-column reduced system) at FULL size.  The oracle
+    runs its OpenMP passes here (orc_set_num_threads: same arithmetic, sums associated per thread -- checked against
+    the sequential path in tests/test_oracle.py) so that the 2.9 GB Jacobian is processed in seconds, not minutes."""
+    import os
+    p = synth.make_config(5)
+    assert p.n_cameras == 8 and p.n_corners == 8640000
+    L = orc.lib()
+    L.orc_set_num_threads(min(int(L.orc_max_threads()), os.cpu_count() or 1, 64))
+    try:
+        pg, po, gs, os_ = _solve_both(p)
+    finally:
+        L.orc_set_num_threads(1)
+    _cmp_trace(gs, os_)
+    e = H.param_rel_err(pg, po)
+    assert max(e.values()) < 1e-6, e
+    assert abs(gs["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
+
+
 def test_lm_one_shot_entry_points(hip_device):
     """tscm_solve_mono / tscm_solve_multi (the drop-in calls of INTEGRATION.md)."""
     p = synth.make_config(1)

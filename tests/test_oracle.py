@@ -198,3 +198,23 @@ def test_invalid_steps_fail_like_ceres():
     q.obs_u[3] = np.nan
     s = orc.solve(q)
     assert s["termination_type"] == 2
+
+
+def test_openmp_passes_agree_with_the_sequential_checker():
+    """orc_set_num_threads(n > 1) (the all-cores CPU baseline of bench.py, and the config-5 parity test) re-associates
+    sums per thread: same iterations and decisions, parameters equal to rounding."""
+    L = orc.lib()
+    for p in (synth.make_problem(4, 40, 5), synth.make_problem(1, 60, 6)):
+        a, b = p.copy().normalised(), p.copy().normalised()
+        sa = orc.solve(a)
+        L.orc_set_num_threads(4)
+        try:
+            sb = orc.solve(b)
+        finally:
+            L.orc_set_num_threads(1)
+        assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+        for x, y in zip(sa["iterations"], sb["iterations"]):
+            assert x["step_is_successful"] == y["step_is_successful"]
+            assert abs(x["cost"] - y["cost"]) <= 1e-11 * abs(y["cost"])
+        assert np.max(np.abs(a.intr - b.intr) / np.maximum(np.abs(a.intr), 1e-3)) < 1e-9
+        assert np.max(np.abs(a.board_rt - b.board_rt)) < 1e-7

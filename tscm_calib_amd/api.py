@@ -113,6 +113,12 @@ class Comm:
         _l.check(_l.lib().tscm_comm_create_local(world, device, hs))
         return [Comm(None, r, world, device, _handle=C.c_void_p(hs[r])) for r in range(world)]
 
+    def backend_ranks(self) -> int:
+        """Number of ranks the exchange back-end itself reports (ncclCommCount for RCCL)."""
+        n = C.c_int(0)
+        _l.check(_l.lib().tscm_comm_info(self._h, None, None, C.byref(n)))
+        return n.value
+
     @staticmethod
     def unique_id() -> bytes:
         buf = (C.c_ubyte * _l.UNIQUE_ID_BYTES)()

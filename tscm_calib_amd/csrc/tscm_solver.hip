@@ -1193,6 +1193,19 @@ extern "C" int tscm_comm_create_local(int world, int device, tscm_comm **out)
     return 0;
 }
 
+extern "C" int tscm_comm_info(const tscm_comm *c, int *rank, int *world, int *backend_ranks)
+{
+    if (!c) return fail(TSCM_E_INVALID, "communicator is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (backend_ranks) {
+        int n = c->group ? c->group->world : 0;
+        if (c->comm) NCCL_TRY(ncclCommCount(c->comm, &n));      // what RCCL itself reports for the communicator
+        *backend_ranks = n;
+    }
+    return 0;
+}
+
 extern "C" void tscm_comm_destroy(tscm_comm *c)
 {
     if (!c) return;

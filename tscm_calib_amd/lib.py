@@ -103,14 +103,14 @@ class CCornerSet(C.Structure):
 
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
-    "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_default_options",
+    "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_default_options",
     "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
     "tscm_solver_kernel_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
     "tscm_shard_frames", "tscm_solver_create_sharded", "tscm_comm_create_local", "tscm_solver_solve_group",
-    "tscm_solver_gather_boards", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
+    "tscm_solver_gather_boards", "tscm_comm_info", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
     "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
     "tscm_detect_corners", "tscm_detect_corners_batch", "tscm_corner_candidates_free", "tscm_chessboards_from_corners", "tscm_chessboards_free", "tscm_remap",
@@ -144,6 +144,7 @@ def lib():
     L.tscm_last_error.restype = C.c_char_p
     L.tscm_device_count.restype = C.c_int
     L.tscm_device_synchronize.argtypes = [C.c_int]
+    L.tscm_device_peak_fp64.argtypes = [C.c_int, dp, dp]
     L.tscm_default_options.argtypes = [C.POINTER(COptions), C.c_int]
     L.tscm_default_options.restype = None
     L.tscm_solver_create.argtypes = [C.POINTER(CProblem), C.c_int, C.POINTER(vp)]
@@ -151,6 +152,7 @@ def lib():
     L.tscm_comm_create_local.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     L.tscm_solver_solve_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(COptions), C.POINTER(CSummary), C.c_int]
     L.tscm_solver_gather_boards.argtypes = [vp, dp]
+    L.tscm_comm_info.argtypes = [vp, ip, ip, ip]
     L.tscm_solver_set_comm.argtypes = [vp, vp]
     L.tscm_solver_solve.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary)]
     L.tscm_solver_upload_params.argtypes = [vp, dp, dp, dp]
