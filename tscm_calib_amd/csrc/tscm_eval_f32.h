@@ -40,7 +40,6 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
     // wave-uniform constants through the constant address space: scalar loads into SGPR operands; the
     // float copies k_view_prep stores behind the doubles feed the fp32 derivative math directly
-    typedef const double __attribute__((address_space(4))) *cptr4;
     typedef const float __attribute__((address_space(4))) *fptr4;
     const cptr4 cc = (cptr4)(S.cconst + kCStride * cam);
     const fptr4 cf = (fptr4)(S.cconst + kCStride * cam + kCConst);
@@ -212,59 +211,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
         }
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
         camU += accU; camV += accV;
-        // ---- epilogue: identical to k_eval_gram (fp64, registers + shuffles) ----------------------------
-        {
-            // lane-constant record offsets are rebuilt per view from an opaque copy of the lane id: ~15 integer
-            // instructions instead of registers that stay live (and get spilled) across the whole view loop
-            int le = lane;
-            asm volatile("" : "+v"(le));
-            const int col = le & 15, kq = le >> 4;
-            const unsigned oA = 8u * (unsigned)(col <= 2 ? kRecEE + 6 * kq + col
-                                              : col <= 8 ? 16 * kq + col - 3
-                                              : col == 9 ? 16 * kq + 6 : col == 10 ? 16 * kq + 8
-                                              : col <= 14 ? 16 * kq + col - 1 : 16 * kq + 14);
-            const unsigned oB = 8u * (unsigned)(kRecEE + 6 * kq + 3);
-            const d4 sT = accU + accV;
-            const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
-            const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
-            const int l = kq < 3 ? kq : 0;
-            const double r0 = l == 0 ? cc[0] : l == 1 ? cc[1] : cc[2];
-            const double r1 = l == 0 ? cc[3] : l == 1 ? cc[4] : cc[5];
-            const double r2 = l == 0 ? cc[6] : l == 1 ? cc[7] : cc[8];
-            const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;
-            const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8;
-            const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
-            const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
-            const unsigned rec_off = 8u * (unsigned)kRec * (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase);   // wave-uniform
-            // Thirteen UNCONDITIONAL buffer stores: a lane without an entry for a slot stores to an offset past
-            // the end of the record array, which the buffer bounds check drops.  No divergent branch around a
-            // memory instruction is left in the view loop, so the compiler knows exactly how many stores follow
-            // the prefetch loads and waits for those loads with vmcnt(13) -- not for the stores themselves.
-            constexpr unsigned BAD = 0xffffe000u;
-            auto st = [&](bool ok, unsigned byte_off, double v) { buf_store_f64(r_rec, ok ? byte_off : BAD, rec_off, v); };
-            const bool k3 = kq < 3, split = col == 9 || col == 10, zero = col == 15, c6 = k3 && col == 6, c14 = k3 && col == 14;
-            // main entries: rows kq (lo) and 3 + kq (hi) of this lane's column; fx|fy and cx|cy store their u-part here
-            st(k3, oA, split ? mU_lo : (zero ? 0.0 : mT_lo));
-            st(k3, oA + (col <= 2 ? 144u : 384u), split ? mU_hi : (zero ? 0.0 : mT_hi));
-            // ... and their v-part (= total - u-part) next to it; column 15 zeroes the two padding columns
-            st(k3 && (split || zero), oA + 8, zero ? 0.0 : mT_lo - mU_lo);
-            st(k3 && (split || zero), oA + 392, zero ? 0.0 : mT_hi - mU_hi);
-            // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]   (lanes of tile column 6)
-            double vhi_kq = 0.0;
-#pragma unroll
-            for (int lp = 0; lp < 3; ++lp) {
-                const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
-                const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
-                st(c6, oB + 8 * lp, vlo);
-                st(c6, oB + 144 + 8 * lp, vhi);
-                if (lp == kq) vhi_kq = vhi;
-            }
-            // diag(E^T E): w_b part from the lanes (col == kq), t_b part from the lanes of column 6
-            st((k3 && col == kq) || c6, 8u * (unsigned)(kRecG + (col == 6 ? 9 : 6)) + 8u * (unsigned)kq, col == 6 ? vhi_kq : mT_lo);
-            // compact E^T r
-            st(c14, 8u * (unsigned)kRecG + 8u * (unsigned)kq, mT_lo);
-            st(c14, 8u * (unsigned)(kRecG + 3) + 8u * (unsigned)kq, mT_hi);
-        }
+        store_view_record(r_rec, lane, accU, accV, cc, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), (unsigned)P.V);
     }
     }   // block of <= 64 views
     // r^T r of the camera tile (entry [14][14] = lane (col 14, kq 2), reg 3) comes from the fp64 sum

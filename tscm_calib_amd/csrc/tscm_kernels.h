@@ -3,16 +3,19 @@
 // HBM layout (all fp64, device-resident for the whole solve):
 //   obs_u/obs_v      SoA corner observations, re-packed so the views of one camera are
 //                    contiguous and sorted by board: a wave streams them with unit stride.
-//   rec[2][V][132]   per-view Schur pieces written by the Gram kernel:
-//                      [0..95]   E^T [F | r]   6 x 16  (cols 0-12 = W, col 13 = E^T r)
-//                      [96..131] E^T E         6 x 6
-//                      [132..143] compact copy of E^T r and diag(E^T E) for the per-board statistics
+//   rec[2]           per-view Schur pieces written by the Gram kernel, two regions in one allocation:
+//                      W region [V][84]  E^T [F | r]   6 x 14 row-major (cols 0-12 = W, col 13 = E^T r)
+//                      E region [V][48]  E^T E 6 x 6 (36), then E^T r (6) and diag(E^T E) (6)
+//                    views in board-major slot order; the Schur-complement and back-substitution kernels stream
+//                    the W region, the e-block factorisation and the board statistics only the E region.
 //                    double buffered: index ctrl->cur = system at x, cur^1 = candidate.
 //   H_stage          per camera a 16x16 tile [F | r]^T [F | r]  (13x13 Gram, col 13 =
 //                    F^T r, [13][13] = r^T r) + 8 scalars; fixed address so that RCCL can
 //                    all-reduce it without knowing the device-side buffer index.
-//   Y[V][96], L[B][21] (diagonal slots = 1/L_jj), z[B][6], D2[B][6]   e-block factors kept for back-substitution.
-//   T[n_pad^2]       Schur complement sum_b Y_b^T Y_b as dense 16x16 blocks per camera pair.
+//   fac[B][56]       per-board e-block factor (k_schur_factor): forward-substitution multipliers L_ik / L_ii and
+//                    s_i / L_ii, L itself for the back-substitution, 1 / L_ii, z = L^-1 S_b E^T r, the damping D^2.
+//                    Y = L^-1 S_b W is never stored: k_board_gram / k_backsub re-derive it from W (21 FMAs a column).
+//   T[n_bids][256]   Schur complement sum_b Y_b^T Y_b, one 16x16 tile per camera pair that shares a board.
 // The LM control state (trust-region radius, accept/reject, termination, iteration log)
 // lives in `Ctrl` in device memory; every kernel starts with `if (ctrl->done) return`.
 #pragma once
@@ -22,9 +25,18 @@
 
 namespace tscm {
 
-constexpr int kRec = 144;          // doubles per view record
-constexpr int kRecG = 132;         // offset of the compact copy: E^T r (6), diag(E^T E) (6)
-constexpr int kRecEE = 96;         // offset of E^T E inside a record
+constexpr int kRecW = 84;          // doubles per view in the W region: E^T [F | r], 6 x 14 row-major
+constexpr int kRecE = 48;          // doubles per view in the E region: E^T E (36), E^T r (6), diag(E^T E) (6)
+constexpr int kRecEG = 36;         // offset of E^T r / diag inside an E record
+constexpr int kRec = kRecW + kRecE;  // doubles per view over both regions (allocation size, offset limits)
+// per-board factor record (doubles)
+constexpr int kFac = 56;
+constexpr int kFacM = 0;           // [15] L_ik / L_ii, i > k, packed i (i - 1) / 2 + k
+constexpr int kFacC = 15;          // [6]  s_i / L_ii
+constexpr int kFacL = 21;          // [15] L_ik, same packing (back-substitution)
+constexpr int kFacI = 36;          // [6]  1 / L_ii
+constexpr int kFacZ = 42;          // [6]  z = L^-1 S_b E^T r
+constexpr int kFacD = 48;          // [6]  D^2 (damping of the scaled block)
 constexpr int kTcols = 15;         // columns of the single MFMA Gram tile (see k_eval_gram)
 constexpr int kVConst = 27;        // per-view constants: r1, r2, t_b, R_c dR_b/dw_k [:,0:2]
 constexpr int kCConst = 48;        // per-camera constants: R_c, t_c, dR_c/dw_k, fx fy cx cy xi lambda beta 1/(1-alpha)^2
@@ -64,6 +76,10 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// record regions (V = views of this rank)
+__device__ __forceinline__ const double *rec_w(const double *rec, int slot) { return rec + (size_t)kRecW * slot; }
+__device__ __forceinline__ const double *rec_e(const double *rec, int V, int slot) { return rec + (size_t)kRecW * V + (size_t)kRecE * slot; }
 
 struct Options {
     int max_num_iterations;
@@ -113,6 +129,8 @@ struct DevProblem {
     const int *pc_begin, *pc_end, *pc_tile, *bid_mi, *bid_mj;
     const int *bid_part_ptr;                   // per camera-pair block: contiguous range of its partial tiles in pairpart
     const int *sslot;                          // first view slot of each board, boards grouped by camera-set signature
+    const int *sboard;                         // ... and the board itself (its factor record)
+    const int *pair_board;                     // board of each fallback view pair
     const int *bc_begin, *bc_end, *bc_nv, *bc_tile;   // board chunks: range in sslot, views per board, tile ids [chunk*6 + t]
     int n_bchunks, n_tiles;
     const unsigned char *cam_const, *cam_active;
@@ -141,7 +159,7 @@ struct DevState {
     double *campart, *campart2;
     double *H[2], *H_stage;
     double *s_b, *s_c;
-    double *L, *z, *D2, *Y;
+    double *fac;                       // [B][kFac] e-block factors
     double *pairpart, *T;
     double *yhat;
     double *Abig;                      // compact reduced system + rhs row in 16x16 blocks, rigs of more than kMaxCamLds cameras only
@@ -270,6 +288,78 @@ __device__ __forceinline__ int f_tile(int f) { return f < 6 ? f + 3 : (f < 10 ? 
 __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 << ((f - 6) & 1)) : 3; }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue of the Gram kernels (fp64 and fp32-Jacobian variant): one view's two accumulator tiles (u-rows, v-rows)
+// -> its record, entirely in registers (cross-lane shuffles, no LDS phases).
+// D layout: lane (col, kq) holds rows kq + 4*reg of tile column col.  E rows of the record:
+//   e = kq       (w_b rows = tile rows 0..2: reg 0 of the lanes with kq < 3)
+//   e = 3 + l    (t_b rows = sum_j R_c[j][l] * tile row 6+j; rows 6,7 are reg 1 of kq = 2,3, row 8 is
+//                 reg 2 of kq = 0) -- lane (col, kq = l) builds row 3 + l of its column.
+// Thirteen UNCONDITIONAL buffer stores: a lane without an entry for a slot stores to an offset past the end of the
+// record array, which the buffer bounds check drops.  No divergent branch around a memory instruction is left in the
+// view loop, so the compiler knows exactly how many stores follow the prefetch loads and waits for those loads with
+// vmcnt(13) -- not for the stores themselves.
+// cc: the camera's constants (R_c in [0, 9)) through the constant address space; slot: the view's record slot.
+// ---------------------------------------------------------------------------------------------
+typedef const double __attribute__((address_space(4))) *cptr4;
+
+__device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, int lane, const d4 &accU, const d4 &accV, cptr4 cc, unsigned slot, unsigned V)
+{
+    // lane-constant record offsets are rebuilt per view from an opaque copy of the lane id: ~15 integer
+    // instructions instead of registers that stay live (and get spilled) across the whole view loop
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int col = le & 15, kq = le >> 4;
+    // region-relative byte offset of this lane's main entry: E^T E for the w_b columns, E^T [F | r] otherwise
+    // F index: 0-2 w_c, 3-5 t_c, 6 fx, 7 fy, 8 cx, 9 cy, 10 xi, 11 lambda, 12 alpha, 13 r
+    const bool in_e = col <= 2;
+    const unsigned cA = 8u * (unsigned)(in_e ? 6 * kq + col
+                                      : col <= 8 ? kRecW / 6 * kq + col - 3
+                                      : col == 9 ? kRecW / 6 * kq + 6 : col == 10 ? kRecW / 6 * kq + 8
+                                      : kRecW / 6 * kq + col - 1);
+    const unsigned offW = 8u * (unsigned)kRecW * slot;                                       // wave-uniform
+    const unsigned offE = 8u * ((unsigned)kRecW * V + (unsigned)kRecE * slot);
+    const d4 sT = accU + accV;
+    const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
+    const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
+    const int l = kq < 3 ? kq : 0;
+    // R_c[j][l], j = 0..2: three uniform candidates per entry, selected by the lane's l
+    const double r0 = l == 0 ? cc[0] : l == 1 ? cc[1] : cc[2];
+    const double r1 = l == 0 ? cc[3] : l == 1 ? cc[4] : cc[5];
+    const double r2 = l == 0 ? cc[6] : l == 1 ? cc[7] : cc[8];
+    const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;   // rows kq and 3+kq (u+v)
+    const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8; // their u-row parts
+    const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
+    const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
+    constexpr unsigned BAD = 0xffffe000u;
+    auto st = [&](bool ok, unsigned byte_off, unsigned soff, double v) { buf_store_f64(r_rec, ok ? byte_off : BAD, soff, v); };
+    const bool k3 = kq < 3, split = col == 9 || col == 10, c6 = k3 && col == 6, c14 = k3 && col == 14, main = k3 && col != 15;
+    // main entries: rows kq (lo) and 3 + kq (hi) of this lane's column; fx|fy and cx|cy store their u-part here.
+    // (lanes of both regions in one instruction: the region base travels in the lane offset)
+    const unsigned oA = cA + (in_e ? offE : offW);
+    st(main, oA, 0u, split ? mU_lo : mT_lo);
+    st(main, oA + (in_e ? 8u * 18u : 8u * 3u * (kRecW / 6)), 0u, split ? mU_hi : mT_hi);
+    // ... and their v-part (= total - u-part) next to it
+    st(k3 && split, cA + 8u, offW, mT_lo - mU_lo);
+    st(k3 && split, cA + 8u + 8u * 3u * (kRecW / 6), offW, mT_hi - mU_hi);
+    // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]   (lanes of tile column 6)
+    const unsigned oB = 8u * (unsigned)(6 * kq + 3);
+    double vhi_kq = 0.0;
+#pragma unroll
+    for (int lp = 0; lp < 3; ++lp) {
+        const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
+        const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
+        st(c6, oB + 8u * lp, offE, vlo);
+        st(c6, oB + 8u * 18u + 8u * lp, offE, vhi);
+        if (lp == kq) vhi_kq = vhi;
+    }
+    // diag(E^T E): w_b part from the lanes (col == kq), t_b part from the lanes of column 6
+    st((k3 && col == kq) || c6, 8u * (unsigned)(kRecEG + (col == 6 ? 9 : 6)) + 8u * (unsigned)kq, offE, col == 6 ? vhi_kq : mT_lo);
+    // compact E^T r
+    st(c14, 8u * (unsigned)kRecEG + 8u * (unsigned)kq, offE, mT_lo);
+    st(c14, 8u * (unsigned)(kRecEG + 3) + 8u * (unsigned)kq, offE, mT_hi);
+}
+
+// ---------------------------------------------------------------------------------------------
 // THE HOT KERNEL: per-corner TSCM projection + analytic Jacobian + residual, then ALL Gram
 // products of the 2 x 20 Jacobian block [E | F | r] from ONE 16x16 f64 MFMA tile per 4 rows:
 //   * t_b columns are constant combinations of the t_c columns (J_tb = J_tc R_c): dropped from
@@ -315,7 +405,6 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
     // camera constants: read through the constant address space (uniform address, written by an earlier
     // kernel) -> scalar loads straight into SGPR operands, no v_readlane pair per use
-    typedef const double __attribute__((address_space(4))) *cptr4;
     const cptr4 ccs = (cptr4)(S.cconst + kCStride * cam);
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
@@ -491,64 +580,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
         camU += accU; camV += accV;
         if (ablate & 2) continue;
-        // ---- epilogue: tile -> record, entirely in registers (cross-lane shuffles, no LDS phases) ------
-        // D layout: lane (col, kq) holds rows kq + 4*reg of column col.  E rows of the record:
-        //   e = kq       (w_b rows = tile rows 0..2: reg 0 of the lanes with kq < 3)
-        //   e = 3 + l    (t_b rows = sum_j R_c[j][l] * tile row 6+j; rows 6,7 are reg 1 of kq = 2,3, row 8 is
-        //                 reg 2 of kq = 0) -- lane (col, kq = l) builds row 3 + l of its column.
-        {
-            // lane-constant record offsets are rebuilt per view from an opaque copy of the lane id: ~15 integer
-            // instructions instead of registers that stay live (and get spilled) across the whole view loop
-            int le = lane;
-            asm volatile("" : "+v"(le));
-            const int col = le & 15, kq = le >> 4;
-            const unsigned oA = 8u * (unsigned)(col <= 2 ? kRecEE + 6 * kq + col
-                                              : col <= 8 ? 16 * kq + col - 3
-                                              : col == 9 ? 16 * kq + 6 : col == 10 ? 16 * kq + 8
-                                              : col <= 14 ? 16 * kq + col - 1 : 16 * kq + 14);
-            const unsigned oB = 8u * (unsigned)(kRecEE + 6 * kq + 3);
-            const d4 sT = accU + accV;
-            const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
-            const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
-            const int l = kq < 3 ? kq : 0;
-            // R_c[j][l], j = 0..2: three uniform candidates per entry, selected by the lane's l
-            const double r0 = l == 0 ? CC(0) : l == 1 ? CC(1) : CC(2);
-            const double r1 = l == 0 ? CC(3) : l == 1 ? CC(4) : CC(5);
-            const double r2 = l == 0 ? CC(6) : l == 1 ? CC(7) : CC(8);
-            const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;   // rows kq and 3+kq (u+v)
-            const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8; // their u-row parts
-            const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
-            const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
-            const unsigned rec_off = 8u * (unsigned)kRec * (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase);   // wave-uniform
-            // Thirteen UNCONDITIONAL buffer stores: a lane without an entry for a slot stores to an offset past
-            // the end of the record array, which the buffer bounds check drops.  No divergent branch around a
-            // memory instruction is left in the view loop, so the compiler knows exactly how many stores follow
-            // the prefetch loads and waits for those loads with vmcnt(13) -- not for the stores themselves.
-            constexpr unsigned BAD = 0xffffe000u;
-            auto st = [&](bool ok, unsigned byte_off, double v) { buf_store_f64(r_rec, ok ? byte_off : BAD, rec_off, v); };
-            const bool k3 = kq < 3, split = col == 9 || col == 10, zero = col == 15, c6 = k3 && col == 6, c14 = k3 && col == 14;
-            // main entries: rows kq (lo) and 3 + kq (hi) of this lane's column; fx|fy and cx|cy store their u-part here
-            st(k3, oA, split ? mU_lo : (zero ? 0.0 : mT_lo));
-            st(k3, oA + (col <= 2 ? 144u : 384u), split ? mU_hi : (zero ? 0.0 : mT_hi));
-            // ... and their v-part (= total - u-part) next to it; column 15 zeroes the two padding columns
-            st(k3 && (split || zero), oA + 8, zero ? 0.0 : mT_lo - mU_lo);
-            st(k3 && (split || zero), oA + 392, zero ? 0.0 : mT_hi - mU_hi);
-            // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]   (lanes of tile column 6)
-            double vhi_kq = 0.0;
-#pragma unroll
-            for (int lp = 0; lp < 3; ++lp) {
-                const double vlo = CC(lp) * mT_lo + CC(3 + lp) * a7_lo + CC(6 + lp) * a8_lo;
-                const double vhi = CC(lp) * mT_hi + CC(3 + lp) * a7_hi + CC(6 + lp) * a8_hi;
-                st(c6, oB + 8 * lp, vlo);
-                st(c6, oB + 144 + 8 * lp, vhi);
-                if (lp == kq) vhi_kq = vhi;
-            }
-            // diag(E^T E): w_b part from the lanes (col == kq), t_b part from the lanes of column 6
-            st((k3 && col == kq) || c6, 8u * (unsigned)(kRecG + (col == 6 ? 9 : 6)) + 8u * (unsigned)kq, col == 6 ? vhi_kq : mT_lo);
-            // compact E^T r
-            st(c14, 8u * (unsigned)kRecG + 8u * (unsigned)kq, mT_lo);
-            st(c14, 8u * (unsigned)(kRecG + 3) + 8u * (unsigned)kq, mT_hi);
-        }
+        store_view_record(r_rec, lane, accU, accV, ccs, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), (unsigned)P.V);
     }
     }   // block of <= 64 views
     // the four waves of the workgroup (same camera) sum their tiles through LDS in a fixed order
@@ -649,8 +681,8 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
         if (q1 > q0) {
             double g[6] = { 0, 0, 0, 0, 0, 0 }, dg[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
-                const double *rec = S.rec[tgt] + (size_t)kRec * q;
-                for (int i = 0; i < 6; ++i) { g[i] += rec[kRecG + i]; dg[i] += rec[kRecG + 6 + i]; }
+                const double *rec = rec_e(S.rec[tgt], P.V, q);
+                for (int i = 0; i < 6; ++i) { g[i] += rec[kRecEG + i]; dg[i] += rec[kRecEG + 6 + i]; }
             }
             for (int i = 0; i < 6; ++i) {
                 const double x = S.board_rt[tgt][6 * b + i];
@@ -748,10 +780,11 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
 }
 
 // ---------------------------------------------------------------------------------------------
-// e-block elimination (SchurEliminator, one 6x6 block per board): 16 lanes per board.
-//   V = sum_views E^T E, Jacobi-scaled, damped with D^2 = clamp(diag)/radius, Cholesky L L^T;
-//   lane a solves column a of  L Y = S_b W  for every view (a = 13: z = L^{-1} S_b E^T r).
-// grid ceil(B/16) x 256
+// e-block factorisation (SchurEliminator, one 6x6 block per board): ONE LANE per board.
+//   V = sum_views E^T E, Jacobi-scaled, damped with D^2 = clamp(diag)/radius, Cholesky L L^T.
+// Reads only the E region of the records; writes the board's factor record (kFac doubles): everything the
+// Schur-complement and back-substitution kernels need to re-derive Y = L^-1 S_b W column by column.
+// grid ceil(B/256) x 256
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool chol6(const double M[21], double L[21])
 {
@@ -780,24 +813,25 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
     const int cur = S.ctrl->cur;
-    const int b = (blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int a = threadIdx.x & 15;
+    const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= P.B) return;
     const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
     if (q1 == q0) return;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
     double sb[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) sb[i] = S.s_b[6 * b + i];
     double M[21], g[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
     for (int i = 0; i < 21; ++i) M[i] = 0.0;
     for (int q = q0; q < q1; ++q) {
-        const double *rec = S.rec[cur] + (size_t)kRec * q;
+        const double *rec = rec_e(S.rec[cur], P.V, q);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
-            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += rec[kRecEE + i * 6 + j];
-            g[i] += rec[kRecG + i];
+            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += rec[i * 6 + j];
+            g[i] += rec[kRecEG + i];
         }
     }
     double D2[6];
@@ -810,93 +844,137 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
     }
     double L[21];
     if (!chol6(M, L)) S.ctrl->lin_fail = 1;
-    for (int q = q0; q < q1; ++q) {
-        const int v = q;
-        const double *rec = S.rec[cur] + (size_t)kRec * v;
-        double y[6];
+    double *f = S.fac + (size_t)kFac * b;
+    // forward substitution in multiply-only form: y_i = c_i w_i - sum_{k<i} m_ik y_k
+    double z[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double w = (a == kFR ? g[i] : rec[i * 16 + a]) * sb[i];
+    for (int i = 0; i < 6; ++i) {
+        const double il = L[i * (i + 1) / 2 + i];
+        const double c = sb[i] * il;
+        f[kFacC + i] = c;
+        f[kFacI + i] = il;
+        f[kFacD + i] = D2[i];
+        double w = c * g[i];
 #pragma unroll
-            for (int k = 0; k < i; ++k) w -= L[i * (i + 1) / 2 + k] * y[k];
-            y[i] = w * L[i * (i + 1) / 2 + i];
+        for (int k = 0; k < i; ++k) {
+            const double m = L[i * (i + 1) / 2 + k] * il;
+            f[kFacM + i * (i - 1) / 2 + k] = m;
+            f[kFacL + i * (i - 1) / 2 + k] = L[i * (i + 1) / 2 + k];
+            w -= m * z[k];
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) S.Y[(size_t)96 * v + i * 16 + a] = y[i];
-        if (a == kFR && q == q0) for (int i = 0; i < 6; ++i) S.z[6 * b + i] = y[i];
+        z[i] = w;
+        f[kFacZ + i] = w;
     }
-    if (a == 0) {
-        for (int i = 0; i < 21; ++i) S.L[(size_t)21 * b + i] = L[i];
-        for (int i = 0; i < 6; ++i) S.D2[6 * b + i] = D2[i];
-    }
+    f[54] = 0.0; f[55] = 0.0;
 }
 
-// Schur complement contributions  T(m_p, m_q) += Y'_p^T Y'_q  for the views p <= q of one board.
-// Boards are grouped by their camera set ("signature"); one 4-wave workgroup per chunk of boards
-// of ONE signature, so the NV(NV+1)/2 16x16 tiles of a chunk map to fixed camera-pair blocks and
-// stay in registers (4 entries per lane per tile); every Y' record is read once per board.
-// The four waves' tiles are summed in a fixed order through LDS.   grid n_bchunks x 256
+// The multipliers of one board's forward substitution y = L^-1 S_b w (k_schur_factor), wave-uniform: loaded through
+// the constant address space, i.e. by scalar loads into SGPRs that feed the FMAs as scalar operands.
+struct FacFwd { double m[15], c[6], z[6]; };
+__device__ __forceinline__ void load_fac_fwd(const double *fac, int board, FacFwd &F)
+{
+    const cptr4 f = (cptr4)(fac + (size_t)kFac * board);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) F.m[i] = f[kFacM + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { F.c[i] = f[kFacC + i]; F.z[i] = f[kFacZ + i]; }
+}
+
+// One column of Y = L^-1 S_b W from the column of W.  Column kFR (the gradient column) of EVERY view of a board is
+// z = L^-1 S_b (sum over the board's views of E^T r): the reduced right-hand side reads sum_b Y_v^T z from the
+// diagonal camera blocks only.  Returns the column as the two MFMA operands of a 6-row block: K = 6 rows as two
+// k-steps of 4 (rows 0..3, then rows 4, 5 and two zero rows); lane (a, kq) supplies row kq and row 4 + kq.
+__device__ __forceinline__ void y_column_operands(const FacFwd &F, const double (&w)[6], bool grad_col, int kq, double &s0, double &s1)
+{
+    double y0 = F.c[0] * w[0];
+    double y1 = F.c[1] * w[1] - F.m[0] * y0;
+    double y2 = F.c[2] * w[2] - F.m[1] * y0 - F.m[2] * y1;
+    double y3 = F.c[3] * w[3] - F.m[3] * y0 - F.m[4] * y1 - F.m[5] * y2;
+    double y4 = F.c[4] * w[4] - F.m[6] * y0 - F.m[7] * y1 - F.m[8] * y2 - F.m[9] * y3;
+    double y5 = F.c[5] * w[5] - F.m[10] * y0 - F.m[11] * y1 - F.m[12] * y2 - F.m[13] * y3 - F.m[14] * y4;
+    y0 = grad_col ? F.z[0] : y0; y1 = grad_col ? F.z[1] : y1; y2 = grad_col ? F.z[2] : y2;
+    y3 = grad_col ? F.z[3] : y3; y4 = grad_col ? F.z[4] : y4; y5 = grad_col ? F.z[5] : y5;
+    // (register values, not an indexable array: a select chain over array elements is turned into a dynamic index,
+    // and the array then lives in scratch)
+    asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5));
+    const bool lo = (kq & 1) == 0, first = kq < 2;
+    const double a01 = lo ? y0 : y1, a23 = lo ? y2 : y3, a45 = lo ? y4 : y5;
+    s0 = first ? a01 : a23;
+    s1 = first ? a45 : 0.0;
+}
+
+// Schur complement contributions  T(m_p, m_q) += Y_p^T Y_q  for the views p <= q of one board, Y = L^-1 S_b W.
+// Boards are grouped by their camera set ("signature"); one 8-wave workgroup per chunk of boards of ONE signature,
+// so the NV(NV+1)/2 16x16 tiles of a chunk map to fixed camera-pair blocks and stay in registers as MFMA
+// accumulators.  Per board a wave reads the NV W records once: lane (a, kq) loads column a of every view, runs the
+// 21-FMA forward substitution with the board's multipliers as scalar operands (all four kq groups redundantly: the
+// column then sits in the lane that feeds it to the matrix core, no LDS transpose), and two v_mfma_f64_16x16x4 per
+// tile contract the 6 rows.  The next board's columns and multipliers are requested as soon as the current ones are
+// consumed, i.e. before the MFMAs, which cover their latency.
+// The eight waves' tiles are summed in a fixed order through LDS.   grid n_bchunks x 512
 template <int NV>
-__device__ __forceinline__ void board_gram_chunk(const DevProblem &P, const DevState &S, int chunk, double (*red)[256], double *stage)
+__device__ __forceinline__ void board_gram_chunk(const DevProblem &P, const DevState &S, int cur, int chunk, double (*red)[256])
 {
     constexpr int NT = NV * (NV + 1) / 2;
-    constexpr int NR = (NV * 96 + 63) / 64;          // raw doubles per lane for one board's records
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int a = lane & 15, bg = lane >> 4;
-    double *ly = stage + wave * (3 * 96);            // this wave's staging copy of the board's records
-    double acc[NT][4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a = lane & 15, kq = lane >> 4;
+    d4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { acc[t][0] = 0.0; acc[t][1] = 0.0; acc[t][2] = 0.0; acc[t][3] = 0.0; }
+    for (int t = 0; t < NT; ++t) acc[t] = d4{ 0.0, 0.0, 0.0, 0.0 };
     const int b1 = P.bc_end[chunk];
-    // The wave's board list (every 8th board of the chunk) is fetched 64 boards at a time and
-    // broadcast; each board's NV contiguous records are loaded fully coalesced ONE BOARD AHEAD into
-    // registers, passed through LDS, and read back as the (column a | 4 columns of group bg) operands.
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(S.rec[cur], sizeof(double) * (size_t)kRecW * P.V);
+    // lane offsets of column a inside a W record (columns 14, 15 of the tile do not exist: read past the end = 0)
+    constexpr unsigned BAD = 0xffffe000u;
+    const unsigned col_off = a < 14 ? 8u * (unsigned)a : BAD;
+    const bool grad_col = a == kFR;
+    // The wave's board list (every 8th board of the chunk) is fetched 64 boards at a time into lane registers.
     for (int base = P.bc_begin[chunk] + wave; base < b1; base += 8 * 64) {
         const int mine = base + 8 * lane;
-        const int myslot = mine < b1 ? P.sslot[mine] : 0;
+        int myslot = mine < b1 ? P.sslot[mine] : 0, myboard = mine < b1 ? P.sboard[mine] : 0;
+        asm volatile("" : "+v"(myslot), "+v"(myboard));      // the list is here before the board loop starts
         const int nb = min(64, (b1 - base + 7) >> 3);
-        double raw[NR];
+        double w[NV][6];
+        FacFwd F;
         {
-            const double *Y = S.Y + (size_t)96 * __shfl(myslot, 0);
+            const unsigned s0 = 8u * (unsigned)kRecW * (unsigned)__builtin_amdgcn_readlane(myslot, 0);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) raw[r] = (lane + 64 * r < NV * 96) ? Y[lane + 64 * r] : 0.0;
+            for (int p = 0; p < NV; ++p)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) w[p][k] = buf_load_f64(r_w, col_off + 8u * (unsigned)(kRecW * p + 14 * k), s0);
+            load_fac_fwd(S.fac, __builtin_amdgcn_readlane(myboard, 0), F);
         }
         for (int jb = 0; jb < nb; ++jb) {
-            wave_lds_fence();
+            double s0[NV], s1[NV];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) if (lane + 64 * r < NV * 96) ly[lane + 64 * r] = raw[r];
-            if (jb + 1 < nb) {
-                const double *Y = S.Y + (size_t)96 * __shfl(myslot, jb + 1);
+            for (int p = 0; p < NV; ++p) y_column_operands(F, w[p], grad_col, kq, s0[p], s1[p]);
+            {
+                // always issued (the list's last board re-reads itself): no branch around the loads
+                const int jn = min(jb + 1, nb - 1);
+                const unsigned sn = 8u * (unsigned)kRecW * (unsigned)__builtin_amdgcn_readlane(myslot, jn);
 #pragma unroll
-                for (int r = 0; r < NR; ++r) raw[r] = (lane + 64 * r < NV * 96) ? Y[lane + 64 * r] : 0.0;
+                for (int p = 0; p < NV; ++p)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) w[p][k] = buf_load_f64(r_w, col_off + 8u * (unsigned)(kRecW * p + 14 * k), sn);
+                load_fac_fwd(S.fac, __builtin_amdgcn_readlane(myboard, jn), F);
             }
-            wave_lds_fence();
-            double ya[NV][6];
-            d4 yb[NV][6];
-#pragma unroll
-            for (int p = 0; p < NV; ++p) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { ya[p][k] = ly[96 * p + k * 16 + a]; yb[p][k] = *reinterpret_cast<const d4 *>(ly + 96 * p + k * 16 + 4 * bg); }
-            }
+            __builtin_amdgcn_sched_barrier(0);      // the requests stay ABOVE the MFMAs (the scheduler would sink the scalar loads to their first use)
             int t = 0;
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
 #pragma unroll
                 for (int q = p; q < NV; ++q, ++t) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        acc[t][0] += ya[p][k] * yb[q][k][0]; acc[t][1] += ya[p][k] * yb[q][k][1];
-                        acc[t][2] += ya[p][k] * yb[q][k][2]; acc[t][3] += ya[p][k] * yb[q][k][3];
-                    }
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(s0[p], s0[q], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(s1[p], s1[q], acc[t], 0, 0, 0);
                 }
             }
         }
     }
+    // D layout: lane (col = a, kq) holds rows kq + 4 r of column a -> tile entry [row][col]
     const int tid = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave][a * 16 + 4 * bg + e] = acc[t][e];
+        for (int r = 0; r < 4; ++r) red[wave][(kq + 4 * r) * 16 + a] = acc[t][r];
         __syncthreads();
         if (tid < 256)
             S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] =
@@ -909,12 +987,12 @@ __global__ __launch_bounds__(512) void k_board_gram(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
     __shared__ double red[8][256];
-    __shared__ __attribute__((aligned(16))) double stage[8 * 3 * 96];
     const int chunk = blockIdx.x;
+    const int cur = S.ctrl->cur;
     switch (P.bc_nv[chunk]) {
-    case 1: board_gram_chunk<1>(P, S, chunk, red, stage); break;
-    case 2: board_gram_chunk<2>(P, S, chunk, red, stage); break;
-    case 3: board_gram_chunk<3>(P, S, chunk, red, stage); break;
+    case 1: board_gram_chunk<1>(P, S, cur, chunk, red); break;
+    case 2: board_gram_chunk<2>(P, S, cur, chunk, red); break;
+    case 3: board_gram_chunk<3>(P, S, cur, chunk, red); break;
     default: break;      // boards seen by more than three cameras go through k_pair_gram
     }
 }
@@ -926,21 +1004,25 @@ __global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
     if (S.ctrl->done) return;
     __shared__ double red[4][256];
     const int pc = blockIdx.x;
+    const int cur = S.ctrl->cur;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int a = lane & 15, bg = lane >> 4;
-    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    const int a = lane & 15, kq = lane >> 4;
+    d4 acc = { 0.0, 0.0, 0.0, 0.0 };
     for (int p = P.pc_begin[pc] + wave; p < P.pc_end[pc]; p += 4) {
-        const double *Yi = S.Y + (size_t)96 * P.pair_i[p];
-        const double *Yj = S.Y + (size_t)96 * P.pair_j[p];
+        const double *Wi = rec_w(S.rec[cur], P.pair_i[p]), *Wj = rec_w(S.rec[cur], P.pair_j[p]);
+        FacFwd F;
+        load_fac_fwd(S.fac, __builtin_amdgcn_readfirstlane(P.pair_board[p]), F);     // p is wave-uniform
+        double wi[6], wj[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double ya = Yi[k * 16 + a];
-            const d4 yb = *reinterpret_cast<const d4 *>(Yj + k * 16 + 4 * bg);
-            acc[0] += ya * yb[0]; acc[1] += ya * yb[1]; acc[2] += ya * yb[2]; acc[3] += ya * yb[3];
-        }
+        for (int k = 0; k < 6; ++k) { wi[k] = a < 14 ? Wi[14 * k + a] : 0.0; wj[k] = a < 14 ? Wj[14 * k + a] : 0.0; }
+        double i0, i1, j0, j1;
+        y_column_operands(F, wi, a == kFR, kq, i0, i1);
+        y_column_operands(F, wj, a == kFR, kq, j0, j1);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, j0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, j1, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][a * 16 + 4 * bg + e] = acc[e];
+    for (int r = 0; r < 4; ++r) red[wave][(kq + 4 * r) * 16 + a] = acc[r];
     __syncthreads();
     const int t = threadIdx.x;
     S.pairpart[(size_t)256 * P.pc_tile[pc] + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
@@ -1623,7 +1705,8 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 }
 
 // back-substitution of the board steps (SchurEliminator::BackSubstitute), 16 lanes per board:
-//   y_b = L^{-T} (z - sum_v Y_v yhat[m_v]);  delta_b = -s_b y_b;  candidate = x + delta.
+//   y_b = L^{-T} (z - L^{-1} S_b sum_v W_v yhat[m_v]);  delta_b = -s_b y_b;  candidate = x + delta.
+// (sum_v Y_v yhat = L^{-1} S_b sum_v W_v yhat: one forward substitution per board instead of one per view column)
 // grid ceil(B/16) x 256
 __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
 {
@@ -1638,42 +1721,48 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
     if (b < P.B) {
         const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
         // everything that depends on the board only is requested up front, in the same memory round trip as the view
-        // range: the factor, z, the damping, the current pose and its scaling (they are consumed after the view loop)
-        double L[21], zb[6], d2[6], xb[6], sb[6];
+        // range: the factor record, the current pose and its scaling (they are consumed after the view loop)
+        double f[kFacD + 6], xb[6], sb[6];
+        const double *fr = S.fac + (size_t)kFac * b;
 #pragma unroll
-        for (int i = 0; i < 21; ++i) L[i] = S.L[(size_t)21 * b + i];
+        for (int i = 0; i < kFacD + 6; ++i) f[i] = fr[i];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { zb[k] = S.z[6 * b + k]; d2[k] = S.D2[6 * b + k]; xb[k] = S.board_rt[cur][6 * b + k]; sb[k] = S.s_b[6 * b + k]; }
+        for (int k = 0; k < 6; ++k) { xb[k] = S.board_rt[cur][6 * b + k]; sb[k] = S.s_b[6 * b + k]; }
         if (q1 == q0 || fail) {
             if (a < 6) S.board_rt[cur ^ 1][6 * b + a] = S.board_rt[cur][6 * b + a];
         } else {
             double p[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
-                const int v = q;
-                const double yh = (a < kFA) ? S.yhat[P.slot_cam[v] * 16 + a] : 0.0;
-                const double *Yv = S.Y + (size_t)96 * v;
+                const double yh = (a < kFA) ? S.yhat[P.slot_cam[q] * 16 + a] : 0.0;
+                const double *Wv = rec_w(S.rec[cur], q);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) p[k] += Yv[k * 16 + a] * yh;
+                for (int k = 0; k < 6; ++k) p[k] += (a < kFA ? Wv[14 * k + a] : 0.0) * yh;
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 p[k] += __shfl_xor(p[k], 1, 16); p[k] += __shfl_xor(p[k], 2, 16);
                 p[k] += __shfl_xor(p[k], 4, 16); p[k] += __shfl_xor(p[k], 8, 16);
             }
-            double t[6], y[6];
+            double t[6], y[6], pz[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) t[k] = zb[k] - p[k];
+            for (int i = 0; i < 6; ++i) {
+                double v = f[kFacC + i] * p[i];
+#pragma unroll
+                for (int k = 0; k < i; ++k) v -= f[kFacM + i * (i - 1) / 2 + k] * pz[k];
+                pz[i] = v;
+                t[i] = f[kFacZ + i] - v;
+            }
 #pragma unroll
             for (int i = 5; i >= 0; --i) {
                 double w = t[i];
 #pragma unroll
-                for (int k = i + 1; k < 6; ++k) w -= L[k * (k + 1) / 2 + i] * y[k];
-                y[i] = w * L[i * (i + 1) / 2 + i];      // diagonal slots hold 1 / L_ii
+                for (int k = i + 1; k < 6; ++k) w -= f[kFacL + k * (k - 1) / 2 + i] * y[k];
+                y[i] = w * f[kFacI + i];
             }
             double m = 0.0, s = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                m += 0.5 * t[k] * t[k] + 0.5 * d2[k] * y[k] * y[k];
+                m += 0.5 * t[k] * t[k] + 0.5 * f[kFacD + k] * y[k] * y[k];
                 const double x = xb[k];
                 const double xn = x + (-(sb[k] * y[k]));
                 const double d = x - xn;

@@ -360,10 +360,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     // (two passes: count, then assign) so that k_T_reduce streams them without indirection.
     struct ChunkT { int begin, end, nv, bid[6]; };
     std::vector<ChunkT> bchunks;
-    std::vector<int> sslot, pair_i, pair_j;
+    std::vector<int> sslot, sboard, pair_i, pair_j, pair_board;
     struct PChunk { int begin, end, bid; };
     std::vector<PChunk> pchunks;
-    std::vector<std::vector<std::pair<int, int>>> fb_pairs;      // fallback pairs per bid (boards with > 3 views)
+    struct FbPair { int q1, q2, board; };
+    std::vector<std::vector<FbPair>> fb_pairs;      // fallback pairs per bid (boards with > 3 views)
     {
         size_t fast_boards = 0;
         for (int b : order_b) if (bv_ptr[b + 1] - bv_ptr[b] <= 3) ++fast_boards;
@@ -380,7 +381,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
                     const size_t c1 = std::min(e, c0 + per_bchunk);
                     ChunkT ch{};
                     ch.begin = (int)sslot.size();
-                    for (size_t k = c0; k < c1; ++k) sslot.push_back(bv_ptr[order_b[k]]);
+                    for (size_t k = c0; k < c1; ++k) { sslot.push_back(bv_ptr[order_b[k]]); sboard.push_back(order_b[k]); }
                     ch.end = (int)sslot.size();
                     ch.nv = nv;
                     int t = 0;
@@ -395,7 +396,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
                         for (int q2 = q1; q2 < bv_ptr[b + 1]; ++q2) {
                             const int bid = get_bid(slot_cam[q1], slot_cam[q2]);
                             if ((int)fb_pairs.size() <= bid) fb_pairs.resize(bid + 1);
-                            fb_pairs[bid].emplace_back(q1, q2);
+                            fb_pairs[bid].push_back({ q1, q2, b });
                         }
                 }
             }
@@ -406,7 +407,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         const int per_pchunk = std::max<int>(1, (int)((n_fb + 511) / 512));
         for (size_t bid = 0; bid < fb_pairs.size(); ++bid) {
             const int base = (int)pair_i.size();
-            for (auto &pr : fb_pairs[bid]) { pair_i.push_back(pr.first); pair_j.push_back(pr.second); }
+            for (auto &pr : fb_pairs[bid]) { pair_i.push_back(pr.q1); pair_j.push_back(pr.q2); pair_board.push_back(pr.board); }
             const int end = (int)pair_i.size();
             for (int b0 = base; b0 < end; b0 += per_pchunk) pchunks.push_back({ b0, std::min(end, b0 + per_pchunk), (int)bid });
         }
@@ -460,6 +461,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.pc_tile, pc_tile))) return rc;
     if ((rc = dev_upload(s, &P.bid_part_ptr, bid_part_ptr))) return rc;
     if ((rc = dev_upload(s, &P.sslot, sslot))) return rc;
+    if ((rc = dev_upload(s, &P.sboard, sboard))) return rc;
+    if ((rc = dev_upload(s, &P.pair_board, pair_board))) return rc;
     if ((rc = dev_upload(s, &P.bc_begin, bc_begin))) return rc;
     if ((rc = dev_upload(s, &P.bc_end, bc_end))) return rc;
     if ((rc = dev_upload(s, &P.bc_nv, bc_nv))) return rc;
@@ -523,10 +526,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal + world))) return rc;
     if ((rc = dev_alloc(s, &S.s_b, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.s_c, (size_t)s->n_pad))) return rc;
-    if ((rc = dev_alloc(s, &S.L, 21 * (size_t)B))) return rc;
-    if ((rc = dev_alloc(s, &S.z, 6 * (size_t)B))) return rc;
-    if ((rc = dev_alloc(s, &S.D2, 6 * (size_t)B))) return rc;
-    if ((rc = dev_alloc(s, &S.Y, 96 * (size_t)V))) return rc;
+    if ((rc = dev_alloc(s, &S.fac, (size_t)kFac * B))) return rc;
     if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
     if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
@@ -704,7 +704,7 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        if (S.n_bs_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+        if (S.n_st_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_st_blocks), dim3(256), 0, s->stream, P, S);     // one lane per board
         if (P.n_bchunks) hipLaunchKernelGGL(k_board_gram, dim3(P.n_bchunks), dim3(512), 0, s->stream, P, S);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
@@ -1053,13 +1053,14 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     if (board_grad) std::memset(board_grad, 0, sizeof(double) * 6 * (size_t)s->B);
     if (view_cross) std::memset(view_cross, 0, sizeof(double) * 90 * (size_t)p->n_views);
     for (int dv = 0; dv < s->V; ++dv) {
-        const double *r = rec.data() + (size_t)kRec * s->h_view_slot[dv];
+        const double *rw = rec.data() + (size_t)kRecW * s->h_view_slot[dv];                           // E^T [F | r], 6 x 14
+        const double *re = rec.data() + (size_t)kRecW * s->V + (size_t)kRecE * s->h_view_slot[dv];  // E^T E, 6 x 6
         const int b = s->h_view_board[dv], ov = s->dev2orig[dv];
         for (int i = 0; i < 6; ++i) {
-            if (board_gram) for (int j = 0; j < 6; ++j) board_gram[36 * (size_t)b + 6 * i + j] += r[kRecEE + 6 * i + j];
-            if (board_grad) board_grad[6 * (size_t)b + i] += r[16 * i + kFR];
+            if (board_gram) for (int j = 0; j < 6; ++j) board_gram[36 * (size_t)b + 6 * i + j] += re[6 * i + j];
+            if (board_grad) board_grad[6 * (size_t)b + i] += rw[14 * i + kFR];
             if (view_cross) {
-                for (int j = 0; j < 13; ++j) view_cross[90 * (size_t)ov + 15 * i + j] = r[16 * i + j];
+                for (int j = 0; j < 13; ++j) view_cross[90 * (size_t)ov + 15 * i + j] = rw[14 * i + j];
             }
         }
     }
