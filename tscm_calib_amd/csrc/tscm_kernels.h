@@ -125,6 +125,9 @@ struct DevProblem {
     const int *chunk_vb, *chunk_ve, *chunk_cam, *cam_chunk_ptr;
     const int *bv_ptr;                 // board -> range of view SLOTS (records are stored board-major)
     const int *view_slot, *slot_cam;   // device view -> slot ; slot -> camera
+    const int *slot_view, *slot_board; // slot -> device view ; slot -> board
+    const int *slow_boards;            // boards seen by more than three cameras (factored by k_schur_factor, Gram by k_pair_gram)
+    int n_slow;
     const int *pair_i, *pair_j;
     const int *pc_begin, *pc_end, *pc_tile, *bid_mi, *bid_mj;
     const int *bid_part_ptr;                   // per camera-pair block: contiguous range of its partial tiles in pairpart
@@ -132,6 +135,8 @@ struct DevProblem {
     const int *sboard;                         // ... and the board itself (its factor record)
     const int *pair_board;                     // board of each fallback view pair
     const int *bc_begin, *bc_end, *bc_nv, *bc_tile;   // board chunks: range in sslot, views per board, tile ids [chunk*6 + t]
+    const int4 *bc_desc;                       // the same per chunk in one 16-byte record: first board, end board, first slot, views per board
+                                               // (device boards are numbered in signature order: a chunk's boards AND slots are contiguous)
     int n_bchunks, n_tiles;
     const unsigned char *cam_const, *cam_active;
     const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
@@ -716,13 +721,30 @@ __global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, 
 // grid (C + 1) x 256.  H_stage = C camera tiles, then kScal scalars: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b
 // [4] e-block factorisation failures on this rank, then one slot per rank with that rank's board gradient max-norm
 // (zero in the other ranks' slots): ONE sum all-reduce carries sums, the failure flag and the maximum.
-__device__ void control_step(const DevProblem &P, const DevState &S, int init, double *sm);
+// What the control step reads from memory that does NOT depend on the evaluation being finalised: the LM state and the
+// target point's camera-side parameters.  Loaded at the head of the kernel (by every workgroup: whichever arrives last
+// runs the step), so that the step itself only waits for the staged tiles.
+struct ControlPre { CtrlHead c; double x[2]; };
+__device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre)
+{
+    pre.c = *S.ctrl;
+    const int tgt = init ? pre.c.cur : (pre.c.cur ^ 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = threadIdx.x + 256 * j;
+        const int m = p >> 4, a = p & 15;
+        pre.x[j] = (p < 16 * P.C && a < 15) ? (a < 6 ? S.cam_rt[tgt][6 * m + a] : S.intr[tgt][9 * m + (a - 6)]) : 0.0;
+    }
+}
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm);
 
 // fused_control: -1 = none (multi-GPU: the all-reduce sits between this kernel and k_control);
 // 0 / 1 = the last block to arrive also runs the LM control step with init = fused_control
 // (release/acquire hand-off at agent scope, arrival counter reset for the next launch).
 __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S, int have_backsub, int fused_control)
 {
+    ControlPre pre;
+    if (fused_control >= 0) control_prefetch(P, S, fused_control, pre);
     if (S.ctrl->done) return;
     __shared__ double sm[256];
     __shared__ double G[512];
@@ -776,7 +798,7 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
         __hip_atomic_store(&S.ctrl->fin_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    control_step(P, S, fused_control, sm);
+    control_step(P, S, fused_control, pre, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -809,31 +831,11 @@ __device__ __forceinline__ bool chol6(const double M[21], double L[21])
     return ok;
 }
 
-__global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
+// Factor the damped, Jacobi-scaled 6x6 block of a board from M = sum_views E^T E (packed lower) and g = sum_views E^T r,
+// and write the board's factor record (kFac doubles) to f (HBM or LDS).  Returns false if the block is not positive
+// definite.
+__device__ __forceinline__ bool factor_core(double (&M)[21], const double (&g)[6], const double (&sb)[6], double radius, double dmin, double dmax, double *f)
 {
-    if (S.ctrl->done) return;
-    const int cur = S.ctrl->cur;
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= P.B) return;
-    const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
-    if (q1 == q0) return;
-    const double radius = S.ctrl->radius;
-    const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
-    double sb[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sb[i] = S.s_b[6 * b + i];
-    double M[21], g[6] = { 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-    for (int i = 0; i < 21; ++i) M[i] = 0.0;
-    for (int q = q0; q < q1; ++q) {
-        const double *rec = rec_e(S.rec[cur], P.V, q);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += rec[i * 6 + j];
-            g[i] += rec[kRecEG + i];
-        }
-    }
     double D2[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -843,8 +845,7 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
         M[i * (i + 1) / 2 + i] += D2[i];
     }
     double L[21];
-    if (!chol6(M, L)) S.ctrl->lin_fail = 1;
-    double *f = S.fac + (size_t)kFac * b;
+    const bool ok = chol6(M, L);
     // forward substitution in multiply-only form: y_i = c_i w_i - sum_{k<i} m_ik y_k
     double z[6];
 #pragma unroll
@@ -866,10 +867,69 @@ __global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
         f[kFacZ + i] = w;
     }
     f[54] = 0.0; f[55] = 0.0;
+    return ok;
 }
 
-// The multipliers of one board's forward substitution y = L^-1 S_b w (k_schur_factor), wave-uniform: loaded through
-// the constant address space, i.e. by scalar loads into SGPRs that feed the FMAs as scalar operands.
+// ... of board b with its views at slots [q0, q1), record to HBM
+__device__ __forceinline__ void factor_board(const DevProblem &P, const DevState &S, int cur, double radius, double dmin, double dmax,
+                                             int b, int q0, int q1)
+{
+    double sb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sb[i] = S.s_b[6 * b + i];
+    double M[21], g[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 21; ++i) M[i] = 0.0;
+    for (int q = q0; q < q1; ++q) {
+        const double *rec = rec_e(S.rec[cur], P.V, q);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += rec[i * 6 + j];
+            g[i] += rec[kRecEG + i];
+        }
+    }
+    if (!factor_core(M, g, sb, radius, dmin, dmax, S.fac + (size_t)kFac * b)) S.ctrl->lin_fail = 1;
+}
+
+// stand-alone factorisation of the boards seen by more than three cameras (their Gram products go through
+// k_pair_gram); the others are factored inside k_schur_gram.   grid ceil(n_slow/256) x 256
+__global__ __launch_bounds__(256) void k_schur_factor(DevProblem P, DevState S)
+{
+    if (S.ctrl->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n_slow) return;
+    const int b = P.slow_boards[i];
+    factor_board(P, S, S.ctrl->cur, S.ctrl->radius, S.ctrl->opt.min_lm_diagonal, S.ctrl->opt.max_lm_diagonal, b, P.bv_ptr[b], P.bv_ptr[b + 1]);
+}
+
+// e-block factorisation + Schur complement contributions  T(m_p, m_q) += Y_p^T Y_q  (views p <= q of one board,
+// Y = L^-1 S_b W) in ONE launch.  Boards are grouped by their camera set ("signature"); one 4-wave workgroup per
+// chunk of <= 64 boards of ONE signature, so the NV(NV+1)/2 16x16 tiles of a chunk map to fixed camera-pair blocks
+// and stay in registers as MFMA accumulators.
+//   phase 0a  16 lanes per board sum the E records of its views (contiguous: coalesced) into LDS
+//   phase 0b  one lane per board: damped Cholesky -> the board's factor record, in LDS
+//   (then the records leave for HBM -- the back-substitution needs them -- as one coalesced stream per board)
+//   phase 1   a wave takes FOUR boards at a time: lane (a, kq) loads column a of the W records of board kq of the
+//             group and runs the 21-FMA forward substitution with that board's multipliers (LDS).  The matrix core
+//             contracts over k, and T is a sum over boards -- so the k index of v_mfma_f64_16x16x4 IS the board:
+//             for each of the 6 rows r, one MFMA per tile adds sum_{4 boards} Y_p[r][i] Y_q[r][j].  No lane computes
+//             anything twice and no operand has to be moved: 6 NT MFMAs and 27 NV FMAs per lane per four boards.
+//             The next group's columns are requested before the MFMAs, which cover their latency.
+// The four waves' tiles are summed in a fixed order through LDS.
+// grid (chunks of this NV) x 256
+constexpr int kChunkBoards = 64;
+
+// phase stamps of the fused kernels (make PHASES=1: -DTSCM_PHASE_PROFILE; s_memrealtime, 10 ns ticks; one line per
+// launch from workgroups 0 and 200 -- profiling builds only)
+#ifdef TSCM_PHASE_PROFILE
+#define PHASE_STAMP(var) const long long var = wall_clock64()
+#else
+#define PHASE_STAMP(var)
+#endif
+
+// the forward-substitution values of a board factored by k_schur_factor, wave-uniform through the constant address
+// space (scalar loads): k_pair_gram
 struct FacFwd { double m[15], c[6], z[6]; };
 __device__ __forceinline__ void load_fac_fwd(const double *fac, int board, FacFwd &F)
 {
@@ -882,18 +942,26 @@ __device__ __forceinline__ void load_fac_fwd(const double *fac, int board, FacFw
 
 // One column of Y = L^-1 S_b W from the column of W.  Column kFR (the gradient column) of EVERY view of a board is
 // z = L^-1 S_b (sum over the board's views of E^T r): the reduced right-hand side reads sum_b Y_v^T z from the
-// diagonal camera blocks only.  Returns the column as the two MFMA operands of a 6-row block: K = 6 rows as two
-// k-steps of 4 (rows 0..3, then rows 4, 5 and two zero rows); lane (a, kq) supplies row kq and row 4 + kq.
+// diagonal camera blocks only.
+__device__ __forceinline__ void y_column(const FacFwd &F, const double (&w)[6], bool grad_col, double (&y)[6])
+{
+    y[0] = F.c[0] * w[0];
+    y[1] = F.c[1] * w[1] - F.m[0] * y[0];
+    y[2] = F.c[2] * w[2] - F.m[1] * y[0] - F.m[2] * y[1];
+    y[3] = F.c[3] * w[3] - F.m[3] * y[0] - F.m[4] * y[1] - F.m[5] * y[2];
+    y[4] = F.c[4] * w[4] - F.m[6] * y[0] - F.m[7] * y[1] - F.m[8] * y[2] - F.m[9] * y[3];
+    y[5] = F.c[5] * w[5] - F.m[10] * y[0] - F.m[11] * y[1] - F.m[12] * y[2] - F.m[13] * y[3] - F.m[14] * y[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = grad_col ? F.z[i] : y[i];
+}
+
+// ... as the two MFMA operands of a 6-row block of ONE board (k_pair_gram): K = 6 rows as two k-steps of 4 (rows 0..3,
+// then rows 4, 5 and two zero rows); lane (a, kq) supplies row kq and row 4 + kq.
 __device__ __forceinline__ void y_column_operands(const FacFwd &F, const double (&w)[6], bool grad_col, int kq, double &s0, double &s1)
 {
-    double y0 = F.c[0] * w[0];
-    double y1 = F.c[1] * w[1] - F.m[0] * y0;
-    double y2 = F.c[2] * w[2] - F.m[1] * y0 - F.m[2] * y1;
-    double y3 = F.c[3] * w[3] - F.m[3] * y0 - F.m[4] * y1 - F.m[5] * y2;
-    double y4 = F.c[4] * w[4] - F.m[6] * y0 - F.m[7] * y1 - F.m[8] * y2 - F.m[9] * y3;
-    double y5 = F.c[5] * w[5] - F.m[10] * y0 - F.m[11] * y1 - F.m[12] * y2 - F.m[13] * y3 - F.m[14] * y4;
-    y0 = grad_col ? F.z[0] : y0; y1 = grad_col ? F.z[1] : y1; y2 = grad_col ? F.z[2] : y2;
-    y3 = grad_col ? F.z[3] : y3; y4 = grad_col ? F.z[4] : y4; y5 = grad_col ? F.z[5] : y5;
+    double y[6];
+    y_column(F, w, grad_col, y);
+    double y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3], y4 = y[4], y5 = y[5];
     // (register values, not an indexable array: a select chain over array elements is turned into a dynamic index,
     // and the array then lives in scratch)
     asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5));
@@ -903,98 +971,126 @@ __device__ __forceinline__ void y_column_operands(const FacFwd &F, const double 
     s1 = first ? a45 : 0.0;
 }
 
-// Schur complement contributions  T(m_p, m_q) += Y_p^T Y_q  for the views p <= q of one board, Y = L^-1 S_b W.
-// Boards are grouped by their camera set ("signature"); one 8-wave workgroup per chunk of boards of ONE signature,
-// so the NV(NV+1)/2 16x16 tiles of a chunk map to fixed camera-pair blocks and stay in registers as MFMA
-// accumulators.  Per board a wave reads the NV W records once: lane (a, kq) loads column a of every view, runs the
-// 21-FMA forward substitution with the board's multipliers as scalar operands (all four kq groups redundantly: the
-// column then sits in the lane that feeds it to the matrix core, no LDS transpose), and two v_mfma_f64_16x16x4 per
-// tile contract the 6 rows.  The next board's columns and multipliers are requested as soon as the current ones are
-// consumed, i.e. before the MFMAs, which cover their latency.
-// The eight waves' tiles are summed in a fixed order through LDS.   grid n_bchunks x 512
 template <int NV>
-__device__ __forceinline__ void board_gram_chunk(const DevProblem &P, const DevState &S, int cur, int chunk, double (*red)[256])
+__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0)
 {
+    // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
+    // other address follows from them arithmetically -- the second round trip already brings the data
+    const int4 desc = P.bc_desc[chunk0 + blockIdx.x];
+    const int ctrl_done = S.ctrl->done, cur = S.ctrl->cur;
+    const double radius = S.ctrl->radius, dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
+    if (ctrl_done) return;
+    PHASE_STAMP(ts0);
     constexpr int NT = NV * (NV + 1) / 2;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ double sumE[kChunkBoards][kRecE];
+    __shared__ __attribute__((aligned(16))) double facl[kChunkBoards][kFac];
+    __shared__ double tiles[4][NT][256];
+    const int chunk = chunk0 + blockIdx.x;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int a = lane & 15, kq = lane >> 4;
+    const int c0 = desc.x, nbd = desc.y - desc.x, slot0 = desc.z;       // boards c0 .. c0 + nbd - 1 (<= kChunkBoards), views at slots slot0 + NV * i
+    const double *rec = S.rec[cur];
+    // ---- requests: the E records of the boards this lane sums (phase 0a), the W columns of the four groups of four
+    //      boards its wave contracts (phase 1), the Jacobi scaling of the board it factors (phase 0b)
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(rec, sizeof(double) * (size_t)kRecW * P.V);
+    constexpr unsigned BAD = 0xffffe000u;
+    double ev[4][3];
+    {
+        const int e = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bf = 16 * i + (tid >> 4);
+            const double *E = rec_e(rec, P.V, slot0 + NV * min(bf, nbd - 1));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int p = 0; p < NV; ++p) acc += E[kRecE * p + e + 16 * j];
+                ev[i][j] = acc;
+            }
+        }
+    }
+    double w[4][NV][6];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int bg = 16 * wave + 4 * g + kq;
+        const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + (unsigned)a) : BAD;
+#pragma unroll
+        for (int p = 0; p < NV; ++p)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w[g][p][k] = buf_load_f64(r_w, base, 8u * (unsigned)(kRecW * p + 14 * k));
+    }
+    double sb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sb[i] = tid < nbd ? S.s_b[6 * (c0 + tid) + i] : 1.0;
+    // ---- phase 0a: 16 lanes per board, 16 boards per pass; the NV E records of a board are adjacent ----------------
+    {
+        const int e = tid & 15, grp = tid >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sumE[16 * i + grp][e + 16 * j] = ev[i][j];
+    }
+    __syncthreads();
+    PHASE_STAMP(ts1);
+    // ---- phase 0b: one lane per board --------------------------------------------------------------------------------
+    if (tid < nbd) {
+        double M[21], g[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = sumE[tid][6 * i + j];
+            g[i] = sumE[tid][kRecEG + i];
+        }
+        if (!factor_core(M, g, sb, radius, dmin, dmax, facl[tid])) S.ctrl->lin_fail = 1;
+    }
+    __syncthreads();
+    PHASE_STAMP(ts2);
+    // the factor records leave for HBM (the back-substitution reads them): one contiguous stream for the chunk
+    for (int i = tid; i < nbd * kFac; i += 256) S.fac[(size_t)kFac * c0 + i] = (&facl[0][0])[i];
+    // ---- phase 1 ---------------------------------------------------------------------------------------------------------
     d4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = d4{ 0.0, 0.0, 0.0, 0.0 };
-    const int b1 = P.bc_end[chunk];
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(S.rec[cur], sizeof(double) * (size_t)kRecW * P.V);
-    // lane offsets of column a inside a W record (columns 14, 15 of the tile do not exist: read past the end = 0)
-    constexpr unsigned BAD = 0xffffe000u;
-    const unsigned col_off = a < 14 ? 8u * (unsigned)a : BAD;
     const bool grad_col = a == kFR;
-    // The wave's board list (every 8th board of the chunk) is fetched 64 boards at a time into lane registers.
-    for (int base = P.bc_begin[chunk] + wave; base < b1; base += 8 * 64) {
-        const int mine = base + 8 * lane;
-        int myslot = mine < b1 ? P.sslot[mine] : 0, myboard = mine < b1 ? P.sboard[mine] : 0;
-        asm volatile("" : "+v"(myslot), "+v"(myboard));      // the list is here before the board loop starts
-        const int nb = min(64, (b1 - base + 7) >> 3);
-        double w[NV][6];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (16 * wave + 4 * g >= nbd) break;                              // wave-uniform
+        const int bg = 16 * wave + 4 * g + kq;
+        const bool valid = bg < nbd;
+        const int bl = min(bg, nbd - 1);
         FacFwd F;
-        {
-            const unsigned s0 = 8u * (unsigned)kRecW * (unsigned)__builtin_amdgcn_readlane(myslot, 0);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) F.m[i] = facl[bl][kFacM + i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { F.c[i] = facl[bl][kFacC + i]; F.z[i] = valid ? facl[bl][kFacZ + i] : 0.0; }
+        double y[NV][6];
+#pragma unroll
+        for (int p = 0; p < NV; ++p) y_column(F, w[g][p], grad_col, y[p]);      // lanes without a board: w = 0, z = 0 -> y = 0
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            int t = 0;
 #pragma unroll
             for (int p = 0; p < NV; ++p)
 #pragma unroll
-                for (int k = 0; k < 6; ++k) w[p][k] = buf_load_f64(r_w, col_off + 8u * (unsigned)(kRecW * p + 14 * k), s0);
-            load_fac_fwd(S.fac, __builtin_amdgcn_readlane(myboard, 0), F);
-        }
-        for (int jb = 0; jb < nb; ++jb) {
-            double s0[NV], s1[NV];
-#pragma unroll
-            for (int p = 0; p < NV; ++p) y_column_operands(F, w[p], grad_col, kq, s0[p], s1[p]);
-            {
-                // always issued (the list's last board re-reads itself): no branch around the loads
-                const int jn = min(jb + 1, nb - 1);
-                const unsigned sn = 8u * (unsigned)kRecW * (unsigned)__builtin_amdgcn_readlane(myslot, jn);
-#pragma unroll
-                for (int p = 0; p < NV; ++p)
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) w[p][k] = buf_load_f64(r_w, col_off + 8u * (unsigned)(kRecW * p + 14 * k), sn);
-                load_fac_fwd(S.fac, __builtin_amdgcn_readlane(myboard, jn), F);
-            }
-            __builtin_amdgcn_sched_barrier(0);      // the requests stay ABOVE the MFMAs (the scheduler would sink the scalar loads to their first use)
-            int t = 0;
-#pragma unroll
-            for (int p = 0; p < NV; ++p) {
-#pragma unroll
-                for (int q = p; q < NV; ++q, ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(s0[p], s0[q], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(s1[p], s1[q], acc[t], 0, 0, 0);
-                }
-            }
+                for (int q = p; q < NV; ++q, ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[p][r], y[q][r], acc[t], 0, 0, 0);
         }
     }
+    PHASE_STAMP(ts3);
     // D layout: lane (col = a, kq) holds rows kq + 4 r of column a -> tile entry [row][col]
-    const int tid = threadIdx.x;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][(kq + 4 * r) * 16 + a] = acc[t][r];
-        __syncthreads();
-        if (tid < 256)
-            S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] =
-                ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(512) void k_board_gram(DevProblem P, DevState S)
-{
-    if (S.ctrl->done) return;
-    __shared__ double red[8][256];
-    const int chunk = blockIdx.x;
-    const int cur = S.ctrl->cur;
-    switch (P.bc_nv[chunk]) {
-    case 1: board_gram_chunk<1>(P, S, cur, chunk, red); break;
-    case 2: board_gram_chunk<2>(P, S, cur, chunk, red); break;
-    case 3: board_gram_chunk<3>(P, S, cur, chunk, red); break;
-    default: break;      // boards seen by more than three cameras go through k_pair_gram
-    }
+        for (int r = 0; r < 4; ++r) tiles[wave][t][(kq + 4 * r) * 16 + a] = acc[t][r];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] = (tiles[0][t][tid] + tiles[1][t][tid]) + (tiles[2][t][tid] + tiles[3][t][tid]);
+#ifdef TSCM_PHASE_PROFILE
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200))
+        printf("schur_gram wg %d: boards %d  E sums %lld  factor %lld  gram %lld  tiles %lld [10 ns]\n", (int)blockIdx.x, nbd, ts1 - ts0, ts2 - ts1, ts3 - ts2, wall_clock64() - ts3);
+#endif
 }
 
 // Fallback for boards seen by more than three cameras: explicit list of view pairs, pre-sorted by
@@ -1704,81 +1800,236 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 #endif
 }
 
-// back-substitution of the board steps (SchurEliminator::BackSubstitute), 16 lanes per board:
-//   y_b = L^{-T} (z - L^{-1} S_b sum_v W_v yhat[m_v]);  delta_b = -s_b y_b;  candidate = x + delta.
-// (sum_v Y_v yhat = L^{-1} S_b sum_v W_v yhat: one forward substitution per board instead of one per view column)
-// grid ceil(B/16) x 256
-__global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
+// Back-substitution of the board steps (SchurEliminator::BackSubstitute) AND the per-view constants of the candidate
+// point (what k_view_prep computes for the initial point) in one launch.  A 128-thread workgroup owns kBsBoards
+// consecutive boards, whose views are consecutive record slots.  Small workgroups on purpose: the kernel streams the W
+// region, a CU sustains ~20 GB/s of it, so the time is set by the CU with the most bytes -- thousands of small
+// workgroups spread evenly, a few hundred large ones leave CUs with one or with two of them (measured: 2.3 TB/s).
+//   phase A  q_b = sum_v W_v yhat[m_v]: the W records of a round of 32 slots are ONE contiguous piece of memory, read
+//            flat (every wave instruction 512 consecutive bytes) into LDS; 16 lanes per slot take their columns from there
+//   phase B  one lane per board: y_b = L^{-T} (z - L^{-1} S_b q_b);  delta_b = -s_b y_b;  candidate = x + delta
+//            (sum_v Y_v yhat = L^{-1} S_b sum_v W_v yhat: one forward substitution per board);  the candidate rotations
+//            R_c of the cameras are prepared by otherwise idle lanes
+//   phase C  one lane per view of these boards: board rotation columns, t_b and R_c dR_b/dw of the candidate, staged in
+//            LDS and written as 256-byte records (vconst, see k_view_prep); workgroup 0 also writes the per-camera records
+// grid ceil(B / kBsBoards) x 128, dynamic LDS kBsLds doubles
+constexpr int kBsBoards = 16;
+constexpr int kBsThreads = 128;
+constexpr int kBsRound = 32;       // slots per round of phase A: 32 * 84 doubles = exactly 21 per thread
+constexpr int kBsTile = 64;        // views per round of phase C
+constexpr int kBsLdsA = kBsRound * kRecW + kBsRound * 6;
+constexpr int kBsLds = kBsTile * (kVFloatOff + 1) > kBsLdsA ? kBsTile * (kVFloatOff + 1) : kBsLdsA;
+static_assert(kBsRound * kRecW == 21 * kBsThreads, "a round of W records is 21 doubles per thread");
+static_assert(kBsBoards * kFac == 7 * kBsThreads, "the factor records are 7 doubles per thread");
+static_assert(kBsBoards * kFac <= kBsRound * kRecW, "the factor records re-use the W area");
+
+__device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m)
 {
-    if (S.ctrl->done) return;
-    __shared__ double sm_m[16], sm_s[16];
-    const int cur = S.ctrl->cur;
-    const int fail = S.ctrl->lin_fail;
-    const int grp = threadIdx.x >> 4;
-    const int b = blockIdx.x * 16 + grp;
-    const int a = threadIdx.x & 15;
+    double crt[3], Rc[9], dRc[27];
+    for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
+    rotation_and_derivatives(crt, Rc, dRc);
+    double *o = S.cconst + kCStride * m;
+    for (int k = 0; k < 9; ++k) o[k] = Rc[k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
+    for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
+    const double *I = S.intr[tgt] + 9 * m;
+    for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
+    const double oma = 1.0 - I[6];
+    o[45] = I[6] / oma;
+    o[46] = 1.0 / (oma * oma);
+    o[47] = 0.0;
+    float *of = reinterpret_cast<float *>(o + kCConst);
+    for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
+}
+
+__global__ __launch_bounds__(kBsThreads) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
+{
+    // head: control block and slot range in one round trip
+    const int b0 = blockIdx.x * kBsBoards;
+    const int nbl = min(kBsBoards, P.B - b0);
+    const int s0 = P.bv_ptr[b0], s1 = P.bv_ptr[b0 + nbl];                // the views of these boards: slots [s0, s1)
+    const int ctrl_done = S.ctrl->done, cur = S.ctrl->cur, fail = S.ctrl->lin_fail;
+    if (ctrl_done) return;
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    double *s_w = dyn;                                     // [kBsRound][kRecW]   phase A
+    double (*s_qv)[6] = reinterpret_cast<double (*)[6]>(dyn + kBsRound * kRecW);     // [kBsRound][6] W yhat per slot of the round
+    double *s_fac = dyn;                                   // [kBsBoards][kFac]   phase B
+    double *st_all = dyn;                                  // [kBsTile][kVFloatOff + 1]  phase C
+    __shared__ double s_q[kBsBoards][6], s_new[kBsBoards][6];
+    __shared__ double s_rc[kMaxCam][9];
+    __shared__ double s_yh[16 * kMaxCam];
+    __shared__ double sm[16];
+    __shared__ int s_view[kBsTile];
+    const int t = threadIdx.x;
+    PHASE_STAMP(ts0);
+    // ---- everything whose address is known is requested now ---------------------------------------------------------
+    const int my_q0 = t < nbl ? P.bv_ptr[b0 + t] : 0, my_q1 = t < nbl ? P.bv_ptr[b0 + t + 1] : 0;
+    // (phase C's view / board / camera of the first tile: used at the end)
+    const int c_slot = min(s0 + t, max(s1 - 1, 0));
+    const int c_view = s1 > s0 ? P.slot_view[c_slot] : 0, c_board = s1 > s0 ? P.slot_board[c_slot] : 0, c_cam = s1 > s0 ? P.slot_cam[c_slot] : 0;
+    // (phase B's current pose and Jacobi scaling of this lane's board)
+    double xb[6], sbv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { xb[k] = t < nbl ? S.board_rt[cur][6 * (b0 + t) + k] : 0.0; sbv[k] = t < nbl ? S.s_b[6 * (b0 + t) + k] : 1.0; }
+    // (phase B's factor records: the boards' records are contiguous, 7 doubles per thread)
+    double facv[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) facv[j] = S.fac[(size_t)kFac * b0 + min(t + kBsThreads * j, nbl * kFac - 1)];
+    for (int i = t; i < P.n_pad; i += kBsThreads) s_yh[i] = S.yhat[i];
+    if (t < kBsBoards * 6) (&s_q[0][0])[t] = 0.0;
+    // ---- phase A -----------------------------------------------------------------------------------------------------
+    {
+        const int grp = t >> 4, a = t & 15;
+        const double *wsrc = S.rec[cur];
+        const size_t w_end = (size_t)kRecW * max(s1, 1);               // first double behind this workgroup's records
+        double v[21];
+        int camv = 0;
+        {
+            const size_t base = (size_t)kRecW * s0;
+#pragma unroll
+            for (int j = 0; j < 21; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
+            camv = P.slot_cam[min(s0 + (t & 31), max(s1 - 1, 0))];
+        }
+        for (int rbase = s0; rbase < s1; rbase += kBsRound) {
+            const int rend = min(s1, rbase + kBsRound);
+            __syncthreads();                                            // the previous round is done with s_w / s_qv (and s_yh is there)
+#pragma unroll
+            for (int j = 0; j < 21; ++j) s_w[t + kBsThreads * j] = v[j];
+            const int cam_l = camv;
+            if (rbase + kBsRound < s1) {
+                // the next round's records are requested before this round computes
+                const size_t base = (size_t)kRecW * (rbase + kBsRound);
+#pragma unroll
+                for (int j = 0; j < 21; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
+                camv = P.slot_cam[min(rbase + kBsRound + (t & 31), s1 - 1)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < kBsRound / 8; ++pass) {
+                const int sl = 8 * pass + grp;                          // slot of the round; its camera sits in lane sl of every wave
+                const int cam = __shfl(cam_l, sl);
+                const double yh = a < kFA ? s_yh[16 * cam + a] : 0.0;
+                double p[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    p[k] = (a < kFA ? s_w[kRecW * sl + 14 * k + a] : 0.0) * yh;
+                    p[k] += __shfl_xor(p[k], 1, 16); p[k] += __shfl_xor(p[k], 2, 16);
+                    p[k] += __shfl_xor(p[k], 4, 16); p[k] += __shfl_xor(p[k], 8, 16);
+                }
+                if (a == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s_qv[sl][k] = p[k];
+                }
+            }
+            __syncthreads();
+            // per board, its views in slot order (deterministic)
+            if (t < nbl) {
+                for (int q = max(my_q0, rbase); q < min(my_q1, rend); ++q)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s_q[t][k] += s_qv[q - rbase][k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 7; ++j) s_fac[t + kBsThreads * j] = facv[j];
+        __syncthreads();
+    }
+    PHASE_STAMP(ts1);
+    // ---- phase B: lanes 0 .. nbl-1 one board each; lanes 32 .. 32+C-1 the candidate camera rotations ----------------
     double mb = 0.0, ss = 0.0;
-    if (b < P.B) {
-        const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
-        // everything that depends on the board only is requested up front, in the same memory round trip as the view
-        // range: the factor record, the current pose and its scaling (they are consumed after the view loop)
-        double f[kFacD + 6], xb[6], sb[6];
-        const double *fr = S.fac + (size_t)kFac * b;
+    if (t < nbl) {
+        const int b = b0 + t;
+        if (my_q1 == my_q0 || fail) {
 #pragma unroll
-        for (int i = 0; i < kFacD + 6; ++i) f[i] = fr[i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { xb[k] = S.board_rt[cur][6 * b + k]; sb[k] = S.s_b[6 * b + k]; }
-        if (q1 == q0 || fail) {
-            if (a < 6) S.board_rt[cur ^ 1][6 * b + a] = S.board_rt[cur][6 * b + a];
+            for (int k = 0; k < 6; ++k) { S.board_rt[cur ^ 1][6 * b + k] = xb[k]; s_new[t][k] = xb[k]; }
         } else {
-            double p[6] = { 0, 0, 0, 0, 0, 0 };
-            for (int q = q0; q < q1; ++q) {
-                const double yh = (a < kFA) ? S.yhat[P.slot_cam[q] * 16 + a] : 0.0;
-                const double *Wv = rec_w(S.rec[cur], q);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) p[k] += (a < kFA ? Wv[14 * k + a] : 0.0) * yh;
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                p[k] += __shfl_xor(p[k], 1, 16); p[k] += __shfl_xor(p[k], 2, 16);
-                p[k] += __shfl_xor(p[k], 4, 16); p[k] += __shfl_xor(p[k], 8, 16);
-            }
-            double t[6], y[6], pz[6];
+            const double *f = s_fac + kFac * t;
+            double tt[6], y[6], pz[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                double v = f[kFacC + i] * p[i];
+                double v = f[kFacC + i] * s_q[t][i];
 #pragma unroll
                 for (int k = 0; k < i; ++k) v -= f[kFacM + i * (i - 1) / 2 + k] * pz[k];
                 pz[i] = v;
-                t[i] = f[kFacZ + i] - v;
+                tt[i] = f[kFacZ + i] - v;
             }
 #pragma unroll
             for (int i = 5; i >= 0; --i) {
-                double w = t[i];
+                double w = tt[i];
 #pragma unroll
                 for (int k = i + 1; k < 6; ++k) w -= f[kFacL + k * (k - 1) / 2 + i] * y[k];
                 y[i] = w * f[kFacI + i];
             }
-            double m = 0.0, s = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                m += 0.5 * t[k] * t[k] + 0.5 * f[kFacD + k] * y[k] * y[k];
+                mb += 0.5 * tt[k] * tt[k] + 0.5 * f[kFacD + k] * y[k] * y[k];
                 const double x = xb[k];
-                const double xn = x + (-(sb[k] * y[k]));
+                const double xn = x + (-(sbv[k] * y[k]));
                 const double d = x - xn;
-                s += d * d;
-                if (a == k) S.board_rt[cur ^ 1][6 * b + k] = xn;
+                ss += d * d;
+                S.board_rt[cur ^ 1][6 * b + k] = xn;
+                s_new[t][k] = xn;
             }
-            mb = m; ss = s;
         }
+    } else if (t >= 32 && t < 32 + P.C) {
+        const int m = t - 32;
+        double crt[3], Rc[9], dRc[27];
+        for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[cur ^ 1][6 * m + k];
+        rotation_and_derivatives(crt, Rc, dRc);
+        for (int k = 0; k < 9; ++k) s_rc[m][k] = Rc[k];
+        if (blockIdx.x == 0) write_camera_record(S, cur ^ 1, m);
     }
-    if (a == 0) { sm_m[grp] = mb; sm_s[grp] = ss; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = 0.0, s = 0.0;
-        for (int i = 0; i < 16; ++i) { m += sm_m[i]; s += sm_s[i]; }
-        S.bs_part[2 * blockIdx.x] = m; S.bs_part[2 * blockIdx.x + 1] = s;
+    {
+        double red[2] = { mb, ss }, mdummy = 0.0;
+        block_reduce256<2>(red, mdummy, sm);       // (contains the barriers that publish s_new / s_rc and retire s_fac)
+        if (t == 0) { S.bs_part[2 * blockIdx.x] = red[0]; S.bs_part[2 * blockIdx.x + 1] = red[1]; }
     }
+    PHASE_STAMP(ts2);
+    // ---- phase C: one lane per view of these boards, tiles of kBsTile views ------------------------------------------
+    for (int base = s0; base < s1; base += kBsTile) {
+        const int slot = base + t;
+        int view = -1;
+        if (t < kBsTile && slot < s1) {
+            const bool first = base == s0;
+            view = first ? c_view : P.slot_view[slot];
+            const int bl = (first ? c_board : P.slot_board[slot]) - b0, m = first ? c_cam : P.slot_cam[slot];
+            double rt[6], bc[kBoardConst];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rt[k] = s_new[bl][k];
+            board_constants(rt, bc);
+            double *o = st_all + (size_t)t * (kVFloatOff + 1);
+            for (int k = 0; k < 6; ++k) o[k] = bc[k];
+            for (int k = 0; k < 3; ++k) o[6 + k] = rt[3 + k];
+            for (int k = 0; k < 6; ++k) {           // six 3-vectors d -> R_c d
+                const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
+                for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = s_rc[m][3 * r] * d0 + s_rc[m][3 * r + 1] * d1 + s_rc[m][3 * r + 2] * d2;
+            }
+            for (int k = kVConst; k < kVFloatOff; ++k) o[k] = 0.0;
+        }
+        // the records are indexed by device view (camera-major); a workgroup's slots map to scattered views, so the
+        // staging tile is drained one record per 32 consecutive lanes: 256-byte contiguous pieces
+        if (t < kBsTile) s_view[t] = view;
+        __syncthreads();
+        const int nrec = min(kBsTile, s1 - base);
+        for (int e = t; e < nrec * kVFloatOff; e += kBsThreads) {
+            const int v = e / kVFloatOff, k = e % kVFloatOff;
+            S.vconst[(size_t)kVStride * s_view[v] + k] = st_all[(size_t)v * (kVFloatOff + 1) + k];
+        }
+        if (with_floats) {
+            constexpr int kF = kVStride - kVFloatOff;
+            for (int e = t; e < nrec * kF; e += kBsThreads) {
+                const int v = e / kF, k = e % kF, j = 2 * k;
+                const double *sv = st_all + (size_t)v * (kVFloatOff + 1);
+                const float f0 = j < kVConst ? (float)sv[j] : 0.f, f1 = j + 1 < kVConst ? (float)sv[j + 1] : 0.f;
+                S.vconst[(size_t)kVStride * s_view[v] + kVFloatOff + k] = __hiloint2double(__float_as_int(f1), __float_as_int(f0));
+            }
+        }
+        __syncthreads();
+    }
+#ifdef TSCM_PHASE_PROFILE
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200))
+        printf("backsub_prep wg %d: W.yhat %lld  board solve %lld  view constants %lld [10 ns]\n", (int)blockIdx.x, ts1 - ts0, ts2 - ts1, wall_clock64() - ts2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1786,13 +2037,13 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, DevState S)
 // one thread.  `init` = IterationZero; otherwise the tail of one loop iteration followed by
 // FinalizeIterationAndCheckIfMinimizerCanContinue.
 // ---------------------------------------------------------------------------------------------
-__device__ void control_step(const DevProblem &P, const DevState &S, int init, double *sm)
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm)
 {
-    // The LM state is read ONCE (wide loads, one memory round trip), advanced in registers and written back
-    // once: as individual fields in global memory the ~40 dependent loads and stores of this function cost
-    // about half a microsecond each on the single thread that executes it.
+    // The LM state is read ONCE (wide loads, one memory round trip -- by control_prefetch, at the head of the kernel),
+    // advanced in registers and written back once: as individual fields in global memory the ~40 dependent loads and
+    // stores of this function cost about half a microsecond each on the single thread that executes it.
     Ctrl &g = *S.ctrl;
-    CtrlHead c = g;
+    CtrlHead c = pre.c;
     if (c.done) return;
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
@@ -1803,10 +2054,13 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
     const double *sc = S.H_stage + 256 * P.C;
     // camera-side norms |x - Plus(x, -g)|_inf, its 2-norm, |x|^2 and the cost, one thread per parameter
     double gmax_c = 0.0, gsq_c = 0.0, xsq_c = 0.0, cost = 0.0;
-    for (int p = t; p < 16 * P.C; p += 256) {          // (one pass up to 16 cameras)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                       // (one pass up to 16 cameras, two up to kMaxCam)
+        const int p = t + 256 * j;
+        if (p >= 16 * P.C) break;
         const int m = p >> 4, a = p & 15;
         if (a < 15 && P.cam_active[m] && !(a < 6 && P.cam_const[m])) {
-            const double x = a < 6 ? S.cam_rt[tgt][6 * m + a] : S.intr[tgt][9 * m + (a - 6)];
+            const double x = pre.x[j];
             const double g = a < kFA ? H[256 * m + a * 16 + kFR] : 0.0;   // b, c: zero gradient
             const double d = x - (x + (-g));
             gmax_c = fmax(gmax_c, fabs(d)); gsq_c += d * d; xsq_c += x * x;
@@ -1909,7 +2163,9 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, d
 __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int init)
 {
     __shared__ double sm[256];
-    control_step(P, S, init, sm);
+    ControlPre pre;
+    control_prefetch(P, S, init, pre);
+    control_step(P, S, init, pre, sm);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -75,14 +75,16 @@ struct tscm_solver {
     hipStream_t own_stream = nullptr;   // `stream` is replaced by the group's while a local group solve runs
     bool mono = false;
     std::vector<int> dev2orig;          // device view -> problem view
-    std::vector<int> h_view_obs, h_view_count, h_view_cam, h_view_board, h_view_slot;
+    std::vector<int> h_view_obs, h_view_count, h_view_cam, h_view_board, h_view_slot;   // h_view_board: DEVICE board index
+    std::vector<int> board_perm;        // device board index -> board of the caller (relative to b0): see create
     // caller-owned parameter arrays (host)
     double *h_cam_rt = nullptr, *h_intr = nullptr, *h_board_rt = nullptr;
     // resident initial parameters for the benchmark
     double *d_init_cam = nullptr, *d_init_intr = nullptr, *d_init_board = nullptr;
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
-    size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0;
+    size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0, lds_gram = 0, lds_bs = 0;
+    int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     // dominant-kernel timing
@@ -272,12 +274,40 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         if (p->view_camera[order[i]] == p->view_camera[order[i - 1]] && p->view_board[order[i]] == p->view_board[order[i - 1]])
             return fail(TSCM_E_INVALID, "two views with the same (camera, board)");
     const int V = (int)order.size();
+    // ---- device board order: boards grouped by camera-set signature (number of views, then the cameras), unseen boards
+    // last.  The Schur kernels work on chunks of boards of ONE signature; with this numbering a chunk is a contiguous
+    // range of boards AND of record slots, so its kernels derive every address from one small descriptor instead of
+    // chasing per-board index tables (each dependent global load costs about a microsecond at the head of a kernel).
+    std::vector<int> dev_board(B, -1);          // caller's board (relative to b0) -> device board
+    {
+        std::vector<int> ptr(B + 1, 0), cams(V);
+        for (int i = 0; i < V; ++i) ptr[p->view_board[order[i]] - b0 + 1]++;
+        for (int b = 0; b < B; ++b) ptr[b + 1] += ptr[b];
+        std::vector<int> fill(B, 0);
+        for (int i = 0; i < V; ++i) { const int b = p->view_board[order[i]] - b0; cams[ptr[b] + fill[b]++] = p->view_camera[order[i]]; }   // `order` is camera-major: sorted
+        std::vector<int> perm(B);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+            const int nx = ptr[x + 1] - ptr[x], ny = ptr[y + 1] - ptr[y];
+            if ((nx == 0) != (ny == 0)) return ny == 0;           // boards without views go last
+            if (nx != ny) return nx < ny;
+            for (int k = 0; k < nx; ++k) if (cams[ptr[x] + k] != cams[ptr[y] + k]) return cams[ptr[x] + k] < cams[ptr[y] + k];
+            return false;
+        });
+        s->board_perm = perm;
+        for (int i = 0; i < B; ++i) dev_board[perm[i]] = i;
+    }
+    // views of one camera sorted by device board
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (p->view_camera[a] != p->view_camera[b]) return p->view_camera[a] < p->view_camera[b];
+        return dev_board[p->view_board[a] - b0] < dev_board[p->view_board[b] - b0];
+    });
     s->V = V; s->dev2orig = order;
     std::vector<int> view_cam(V), view_board(V), view_obs(V), view_count(V);
     long N = 0;
     for (int i = 0; i < V; ++i) {
         const int v = order[i];
-        view_cam[i] = p->view_camera[v]; view_board[i] = p->view_board[v] - b0; view_count[i] = p->view_count[v];   // board index local to the rank
+        view_cam[i] = p->view_camera[v]; view_board[i] = dev_board[p->view_board[v] - b0]; view_count[i] = p->view_count[v];   // device board index
         view_obs[i] = (int)N; N += p->view_count[v];
     }
     if (N > 0x7fffffffL) return fail(TSCM_E_UNSUPPORTED, "more than 2^31 corners");
@@ -333,8 +363,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         for (int i = 0; i < V; ++i) { const int b = view_board[i]; bv_idx[bv_ptr[b] + fill[b]++] = i; }
     }
     // records are stored board-major: slot q of bv order <-> device view bv_idx[q]
-    std::vector<int> view_slot(V), slot_cam(V);
-    for (int q = 0; q < V; ++q) { view_slot[bv_idx[q]] = q; slot_cam[q] = view_cam[bv_idx[q]]; }
+    std::vector<int> view_slot(V), slot_cam(V), slot_view(V), slot_board(V);
+    for (int q = 0; q < V; ++q) { view_slot[bv_idx[q]] = q; slot_cam[q] = view_cam[bv_idx[q]]; slot_view[q] = bv_idx[q]; slot_board[q] = view_board[bv_idx[q]]; }
     s->h_view_slot = view_slot;
     // ---- Schur-complement work lists ------------------------------------------------------------
     // camera-pair blocks ("bids") of T: every pair that shares a board on ANY rank, in lexicographic order
@@ -368,8 +398,12 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     {
         size_t fast_boards = 0;
         for (int b : order_b) if (bv_ptr[b + 1] - bv_ptr[b] <= 3) ++fast_boards;
-        const int target_bchunks = 256;
-        const int per_bchunk = std::max<int>(1, (int)((fast_boards + target_bchunks - 1) / target_bchunks));
+        // chunks of 16 .. kChunkBoards boards (k_schur_gram: 4 waves x groups of 4 boards), about 512 of them on big problems
+        // The Schur kernels stream the records and a CU sustains only its share of the memory system, so the CUs must
+        // get equal numbers of workgroups: two per CU on big problems (a multiple of the CU count), never more than
+        // kChunkBoards boards each, at least 16 (four waves of one group of four).
+        const int target_bchunks = 2 * std::max(1, prop.multiProcessorCount);
+        const int per_bchunk = std::min<int>(kChunkBoards, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
         size_t i = 0;
         while (i < order_b.size()) {
             size_t e = i + 1;
@@ -454,6 +488,25 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.bv_ptr, bv_ptr))) return rc;
     if ((rc = dev_upload(s, &P.view_slot, view_slot))) return rc;
     if ((rc = dev_upload(s, &P.slot_cam, slot_cam))) return rc;
+    if ((rc = dev_upload(s, &P.slot_view, slot_view))) return rc;
+    if ((rc = dev_upload(s, &P.slot_board, slot_board))) return rc;
+    {
+        std::vector<int> slow;
+        for (int b : order_b) if (bv_ptr[b + 1] - bv_ptr[b] > 3) slow.push_back(b);
+        P.n_slow = (int)slow.size();
+        if ((rc = dev_upload(s, &P.slow_boards, slow))) return rc;
+        // chunks are in signature order, i.e. sorted by views per board: one launch of k_schur_gram<NV> per NV present
+        int max_boards = 1;
+        for (size_t c = 0; c < bchunks.size(); ++c) {
+            const int nv = bchunks[c].nv;
+            if (s->nv_chunks[nv]++ == 0) s->nv_chunk0[nv] = (int)c;
+            max_boards = std::max(max_boards, bchunks[c].end - bchunks[c].begin);
+        }
+        if (max_boards > kChunkBoards) return fail(TSCM_E_UNSUPPORTED, "internal error: board chunk larger than kChunkBoards");
+        s->lds_gram = 0;
+        s->lds_bs = sizeof(double) * (size_t)kBsLds;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
+    }
     if ((rc = dev_upload(s, &P.pair_i, pair_i))) return rc;
     if ((rc = dev_upload(s, &P.pair_j, pair_j))) return rc;
     if ((rc = dev_upload(s, &P.pc_begin, pc_begin))) return rc;
@@ -467,6 +520,13 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.bc_end, bc_end))) return rc;
     if ((rc = dev_upload(s, &P.bc_nv, bc_nv))) return rc;
     if ((rc = dev_upload(s, &P.bc_tile, bc_tile))) return rc;
+    {
+        // device boards are numbered in signature order, so entry k of the sorted board list IS board k
+        for (size_t k = 0; k < sboard.size(); ++k) if (sboard[k] != (int)k) return fail(TSCM_E_UNSUPPORTED, "internal error: device board order is not the signature order");
+        std::vector<int4> desc(bchunks.size());
+        for (size_t c = 0; c < bchunks.size(); ++c) desc[c] = make_int4(bchunks[c].begin, bchunks[c].end, bv_ptr[bchunks[c].begin], bchunks[c].nv);
+        if ((rc = dev_upload(s, &P.bc_desc, desc))) return rc;
+    }
     if ((rc = dev_upload(s, &P.bid_mi, bid_mi))) return rc;
     if ((rc = dev_upload(s, &P.bid_mj, bid_mj))) return rc;
     {
@@ -530,7 +590,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
     if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
-    S.n_bs_blocks = (B + 15) / 16;
+    S.n_bs_blocks = (B + kBsBoards - 1) / kBsBoards;
     S.n_st_blocks = (B + 255) / 256;
     if ((rc = dev_alloc(s, &S.bs_part, 2 * (size_t)S.n_bs_blocks))) return rc;
     if ((rc = dev_alloc(s, &S.st_part, 3 * (size_t)S.n_st_blocks))) return rc;
@@ -593,8 +653,10 @@ extern "C" int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, c
     const double *c = (s->mono || !cam_rt) ? zero.data() : cam_rt;
     HIP_TRY(hipMemcpyAsync(s->d_init_cam, c, sizeof(double) * 6 * s->C, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_init_intr, intr, sizeof(double) * 9 * s->C, hipMemcpyHostToDevice, s->stream));
-    // board_rt is the caller's full-length array; this rank keeps the poses of the boards it owns
-    if (s->B) HIP_TRY(hipMemcpyAsync(s->d_init_board, board_rt + 6 * (size_t)s->b0, sizeof(double) * 6 * s->B, hipMemcpyHostToDevice, s->stream));
+    // board_rt is the caller's full-length array; this rank keeps the poses of the boards it owns, in device board order
+    std::vector<double> brd(6 * (size_t)s->B);
+    for (int i = 0; i < s->B; ++i) std::memcpy(brd.data() + 6 * (size_t)i, board_rt + 6 * ((size_t)s->b0 + s->board_perm[i]), 6 * sizeof(double));
+    if (s->B) HIP_TRY(hipMemcpyAsync(s->d_init_board, brd.data(), sizeof(double) * 6 * s->B, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->have_init = true;
     return 0;
@@ -688,7 +750,8 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
+        // the constants of a candidate point were written by k_backsub_prep; the initial point needs them here
+        if (!have_backsub) hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
         if (int rc = launch_eval(s, cand)) return rc;
         hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1 + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
         hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub, sep ? -1 : init);
@@ -704,8 +767,10 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        if (S.n_st_blocks) hipLaunchKernelGGL(k_schur_factor, dim3(S.n_st_blocks), dim3(256), 0, s->stream, P, S);     // one lane per board
-        if (P.n_bchunks) hipLaunchKernelGGL(k_board_gram, dim3(P.n_bchunks), dim3(512), 0, s->stream, P, S);
+        if (P.n_slow) hipLaunchKernelGGL(k_schur_factor, dim3((P.n_slow + 255) / 256), dim3(256), 0, s->stream, P, S);
+        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1]);
+        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2]);
+        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3]);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
     }
@@ -717,7 +782,7 @@ static int enqueue_iteration(LmRun &run)
         else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
         else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
         else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
-        if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub, dim3(S.n_bs_blocks), dim3(256), 0, s->stream, P, S);
+        if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub_prep, dim3(S.n_bs_blocks), dim3(kBsThreads), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
     }
     return enqueue_eval(run, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
@@ -903,7 +968,11 @@ extern "C" int tscm_solver_download_params(tscm_solver *s, double *cam_rt, doubl
     if (cam_rt && !s->mono) HIP_TRY(hipMemcpy(cam_rt, s->S.cam_rt[0], sizeof(double) * 6 * s->C, hipMemcpyDeviceToHost));
     if (intr) HIP_TRY(hipMemcpy(intr, s->S.intr[0], sizeof(double) * 9 * s->C, hipMemcpyDeviceToHost));
     // only the owned boards: the other entries of the caller's array are left untouched (see tscm_solver_gather_boards)
-    if (board_rt && s->B) HIP_TRY(hipMemcpy(board_rt + 6 * (size_t)s->b0, s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToHost));
+    if (board_rt && s->B) {
+        std::vector<double> brd(6 * (size_t)s->B);
+        HIP_TRY(hipMemcpy(brd.data(), s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToHost));
+        for (int i = 0; i < s->B; ++i) std::memcpy(board_rt + 6 * ((size_t)s->b0 + s->board_perm[i]), brd.data() + 6 * (size_t)i, 6 * sizeof(double));
+    }
     return 0;
 }
 
@@ -920,8 +989,11 @@ extern "C" int tscm_solver_gather_boards(tscm_solver *s, double *board_rt)
     const size_t n = 6 * (size_t)s->B_total;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&full), n * sizeof(double)));
     std::unique_ptr<double, void (*)(double *)> guard(full, [](double *q) { (void)hipFree(q); });
-    HIP_TRY(hipMemsetAsync(full, 0, n * sizeof(double), s->stream));
-    if (s->B) HIP_TRY(hipMemcpyAsync(full + 6 * (size_t)s->b0, s->S.board_rt[0], sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice, s->stream));
+    {
+        std::vector<double> mine(n, 0.0);
+        if (int rc = tscm_solver_download_params(s, nullptr, nullptr, mine.data())) return rc;     // owned boards at their own positions
+        HIP_TRY(hipMemcpy(full, mine.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    }
     NCCL_TRY(ncclAllReduce(full, full, n, ncclDouble, ncclSum, s->comm->comm, s->stream));
     HIP_TRY(hipMemcpyAsync(board_rt, full, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1055,7 +1127,7 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     for (int dv = 0; dv < s->V; ++dv) {
         const double *rw = rec.data() + (size_t)kRecW * s->h_view_slot[dv];                           // E^T [F | r], 6 x 14
         const double *re = rec.data() + (size_t)kRecW * s->V + (size_t)kRecE * s->h_view_slot[dv];  // E^T E, 6 x 6
-        const int b = s->h_view_board[dv], ov = s->dev2orig[dv];
+        const int b = s->b0 + s->board_perm[s->h_view_board[dv]], ov = s->dev2orig[dv];
         for (int i = 0; i < 6; ++i) {
             if (board_gram) for (int j = 0; j < 6; ++j) board_gram[36 * (size_t)b + 6 * i + j] += re[6 * i + j];
             if (board_grad) board_grad[6 * (size_t)b + i] += rw[14 * i + kFR];
