@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
 CPU_BASELINE_ITERS = 8
+EVENT_STRIDE = 4
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -201,6 +202,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config index (4 = headline)")
+    ap.add_argument("--poses-fixed", action="store_true",
+                    help="hold every board / view pose block constant (the intrinsics-only form of config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jacobian-fp32", action="store_true",
                     help="north_star's 1e-3 tier: fp32 derivatives + fp32 MFMA contraction (default: all fp64, the headline)")
@@ -235,7 +238,7 @@ def main():
         Solver = _StubSolver
     else:
         from tscm_calib_amd import api, lib
-        full = synth.make_config(args.config)
+        full = synth.make_config(args.config, poses_fixed=args.poses_fixed)
         Solver = api.Solver
         if lib.lib().tscm_device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: HIP device {local_rank} does not exist ({lib.lib().tscm_device_count()} visible): "
@@ -265,7 +268,8 @@ def main():
     natural = solver.solve_resident(reset=True, **extra)
     if args.warmup > 0:
         run_iterations(solver, args.warmup, **extra)
-    solver.kernel_time(enable=os.environ.get("TSCM_BENCH_NO_EVENTS") is None)
+    # HIP events around every EVENT_STRIDE-th launch of the dominant kernel (each pair holds the stream for ~6 us)
+    solver.kernel_time(enable=0 if os.environ.get("TSCM_BENCH_NO_EVENTS") else EVENT_STRIDE)
     barrier()
     t0 = time.perf_counter()
     run_iterations(solver, args.steps, **extra)
@@ -286,7 +290,7 @@ def main():
         roof = {
             "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else "k_eval_gram", "bound": "mfma",
             "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-            "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
+            "traffic": None, "launches": launches, "launches_timed_every": EVENT_STRIDE, "avg_launch_ms": avg_ms,
             "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
             "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
         }
@@ -325,7 +329,8 @@ def main():
             "rccl_ranks": rccl_ranks,
             "config": {"workload": f"BASELINE config {args.config}: {full.n_cameras} cams x "
                                    f"{full.meta.get('views_per_cam')} views/cam, {full.n_boards} frames, "
-                                   f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta.get('seed')})",
+                                   f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta.get('seed')})"
+                                   + (", all board poses constant" if args.poses_fixed else ""),
                        "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)"},
             "natural_solve": {"termination": natural["message"], "iterations": natural["num_iterations"] - 1,
                               "rmse_px": natural["rmse"], "seconds": natural["seconds_solve"],

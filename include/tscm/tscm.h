@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSCM_ABI_VERSION 1
+#define TSCM_ABI_VERSION 2   /* 2: tscm_problem.board_pose_constant (appended; zero-initialised structs keep their meaning) */
 
 enum {
     TSCM_OK = 0,
@@ -72,6 +72,12 @@ typedef struct tscm_problem {
     const unsigned char *cam_pose_constant; /* [C] SetParameterBlockConstant           */
                                    /*   (multi_calib.cpp:186: camera 0); NULL = none   */
     int mono;                      /* 1: TS.h functor -- no camera pose block at all   */
+    const unsigned char *board_pose_constant; /* [B] 1 = the board's pose block is held    */
+                                   /*   constant (problem.SetParameterBlockConstant on */
+                                   /*   chessboards_[i].rt_ / rt_[i]); NULL = none.    */
+                                   /*   The reference never does this; it is the       */
+                                   /*   "intrinsics-only" form of BASELINE config 2    */
+                                   /*   (all views fixed: 7 free intrinsics remain).   */
 } tscm_problem;
 
 /* ceres::Solver::Options fields the path depends on, Ceres defaults
@@ -168,8 +174,10 @@ int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, const double
 int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *opt, tscm_summary *summary, int reset);
 int tscm_solver_download_params(tscm_solver *s, double *cam_rt, double *intr, double *board_rt);
 void tscm_solver_destroy(tscm_solver *s);
-/* timing of the dominant kernel (tscm_eval_gram) accumulated by HIP events on the
- * solver's own stream since the last call; returns launches and total milliseconds. */
+/* timing of the dominant kernel (k_eval_gram) by HIP events on the solver's own stream, accumulated since the last
+ * call: returns the number of timed launches and their total milliseconds, and (re)arms the timers --
+ * enable = 0: off; n >= 1: bracket every n-th launch (an event pair delays the stream by a few microseconds, so a
+ * benchmark samples instead of timing every launch). */
 int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches, double *total_ms);
 
 /* One-shot drop-ins ------------------------------------------------------------

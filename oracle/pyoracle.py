@@ -31,7 +31,7 @@ class OrcProblem(C.Structure):
         ("board_xy", C.c_void_p), ("view_camera", C.c_void_p), ("view_board", C.c_void_p),
         ("view_offset", C.c_void_p), ("view_count", C.c_void_p), ("obs_u", C.c_void_p), ("obs_v", C.c_void_p),
         ("cam_rt", C.c_void_p), ("intr", C.c_void_p), ("board_rt", C.c_void_p),
-        ("cam_pose_constant", C.c_void_p), ("mono", C.c_int),
+        ("cam_pose_constant", C.c_void_p), ("mono", C.c_int), ("board_pose_constant", C.c_void_p),
     ]
 
 
@@ -146,6 +146,10 @@ def c_problem(p) -> OrcProblem:
         assert arr.flags["C_CONTIGUOUS"]
         setattr(q, name, arr.ctypes.data)
     q.mono = 1 if p.mono else 0
+    bpc = getattr(p, "board_pose_constant", None)
+    if bpc is not None:
+        assert bpc.dtype == np.uint8 and bpc.flags["C_CONTIGUOUS"]
+        q.board_pose_constant = bpc.ctypes.data
     return q
 
 

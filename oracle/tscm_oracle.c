@@ -440,7 +440,8 @@ typedef struct {
     /* program structure */
     int *cam_pose_col;   /* [C] column offset of the camera pose in the f-part, -1 if constant/inactive */
     int *intr_col;       /* [C] column offset of the intrinsics in the f-part, -1 if inactive */
-    int *board_active;   /* [B] */
+    int *board_active;   /* [B] the board's pose is a free e-block: it has views and is not constant */
+    int *board_seen;     /* [B] the board has views (its residual blocks exist even when its pose is constant) */
     int nf;              /* reduced-system size */
     int *bv_ptr, *bv_idx;/* board -> views adjacency (CSR) */
     long *view_row;      /* [n_views] first corner row (program order) of each view */
@@ -582,7 +583,35 @@ static int schur_eliminate_board(lm_state *S, int b, double radius, double *lhs,
 {
     const orc_problem *p = S->p;
     const int nf = S->nf;
-    if (!S->board_active[b]) return 0;
+    if (!S->board_seen[b]) return 0;
+    if (!S->board_active[b]) {
+        /* constant pose block (removed from the program): its residual blocks only have f-columns */
+        for (int q = S->bv_ptr[b]; q < S->bv_ptr[b + 1]; ++q) {
+            const int v = S->bv_idx[q];
+            const int m = p->view_camera[v];
+            const int cc = S->cam_pose_col[m], ic = S->intr_col[m];
+            for (int j = 0; j < p->view_count[v]; ++j) {
+                const long k = S->view_row[v] + j;
+                for (int r = 0; r < 2; ++r) {
+                    const double *Fc = S->Jc + 12 * k + 6 * r;
+                    const double *Fi = S->Ji + 18 * k + 9 * r;
+                    const double rr = S->res[2 * k + r];
+                    if (cc >= 0) {
+                        for (int i = 0; i < 6; ++i) {
+                            for (int l = 0; l < 6; ++l) lhs[(cc + i) * nf + cc + l] += Fc[i] * Fc[l];
+                            for (int l = 0; l < 9; ++l) { const double t = Fc[i] * Fi[l]; lhs[(cc + i) * nf + ic + l] += t; lhs[(ic + l) * nf + cc + i] += t; }
+                            rhs[cc + i] += Fc[i] * rr;
+                        }
+                    }
+                    for (int i = 0; i < 9; ++i) {
+                        for (int l = 0; l < 9; ++l) lhs[(ic + i) * nf + ic + l] += Fi[i] * Fi[l];
+                        rhs[ic + i] += Fi[i] * rr;
+                    }
+                }
+            }
+        }
+        return 0;
+    }
     double ete[36], g[6];
     memset(ete, 0, sizeof(ete)); memset(g, 0, sizeof(g));
     for (int i = 0; i < 6; ++i) { const double D = sqrt(S->d_b[6 * b + i] / radius); ete[i * 6 + i] = D * D; }
@@ -816,11 +845,13 @@ int orc_solve(const orc_problem *p, const orc_options *opt, orc_summary *sum)
     S.cam_pose_col = (int *)xcalloc((size_t)C, sizeof(int));
     S.intr_col = (int *)xcalloc((size_t)C, sizeof(int));
     S.board_active = (int *)xcalloc((size_t)B, sizeof(int));
+    S.board_seen = (int *)xcalloc((size_t)B, sizeof(int));
     int *cam_active = (int *)xcalloc((size_t)C, sizeof(int));
     S.view_row = (long *)xcalloc((size_t)p->n_views, sizeof(long));
     S.bv_ptr = (int *)xcalloc((size_t)B + 1, sizeof(int));
     S.bv_idx = (int *)xcalloc((size_t)p->n_views, sizeof(int));
-    { long k = 0; for (int v = 0; v < p->n_views; ++v) { S.view_row[v] = k; k += p->view_count[v]; if (p->view_count[v] > 0) { cam_active[p->view_camera[v]] = 1; S.board_active[p->view_board[v]] = 1; S.bv_ptr[p->view_board[v] + 1]++; } } }
+    { long k = 0; for (int v = 0; v < p->n_views; ++v) { S.view_row[v] = k; k += p->view_count[v]; if (p->view_count[v] > 0) { cam_active[p->view_camera[v]] = 1; S.board_seen[p->view_board[v]] = 1; S.bv_ptr[p->view_board[v] + 1]++; } } }
+    for (int b = 0; b < B; ++b) S.board_active[b] = S.board_seen[b] && !(p->board_pose_constant && p->board_pose_constant[b]);
     for (int b = 0; b < B; ++b) S.bv_ptr[b + 1] += S.bv_ptr[b];
     { int *fill = (int *)xcalloc((size_t)B, sizeof(int)); for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0) { const int b = p->view_board[v]; S.bv_idx[S.bv_ptr[b] + fill[b]++] = v; } free(fill); }
     int col = 0;
@@ -1034,7 +1065,7 @@ int orc_solve(const orc_problem *p, const orc_options *opt, orc_summary *sum)
     for (int m = 0; m < C; ++m) if (S.intr_col[m] >= 0) memcpy(p->intr + 9 * m, S.x_intr + 9 * m, 9 * sizeof(double));
     for (int b = 0; b < B; ++b) if (S.board_active[b]) memcpy(p->board_rt + 6 * b, S.x_board + 6 * b, 6 * sizeof(double));
 
-    free(S.cam_pose_col); free(S.intr_col); free(S.board_active); free(cam_active); free(S.view_row); free(S.bv_ptr); free(S.bv_idx);
+    free(S.cam_pose_col); free(S.intr_col); free(S.board_active); free(S.board_seen); free(cam_active); free(S.view_row); free(S.bv_ptr); free(S.bv_idx);
     free(zero_cam); free(S.x_cam); free(S.c_cam); free(S.x_intr); free(S.c_intr); free(S.x_board); free(S.c_board);
     free(S.res); free(S.Jc); free(S.Jb); free(S.Ji); free(S.g_f); free(S.g_b); free(S.s_f); free(S.s_b); free(S.d_f); free(S.d_b);
     free(S.step_f); free(S.step_b); free(S.lhs); free(S.rhs); free(S.inv_ete);

@@ -58,6 +58,10 @@ typedef struct {
     const unsigned char *cam_pose_constant; /* [C] 1 = SetParameterBlockConstant
                                                (multi_calib.cpp:186); may be NULL */
     int mono;                  /* 1: TS.h functor (no camera pose), C must be 1 */
+    const unsigned char *board_pose_constant; /* [B] 1 = SetParameterBlockConstant on the board's pose block; may be NULL.
+                                  Not used by the reference (BASELINE config 2's "intrinsics-only" form).  Ceres removes
+                                  constant blocks from the reduced program; if NO board block is left it would switch
+                                  DENSE_SCHUR to DENSE_QR -- here the same normal equations go through the Cholesky path. */
 } orc_problem;
 
 typedef struct {

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = lib.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.tscm_abi_version() == 1
+    assert L.tscm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
     assert (o.max_num_consecutive_invalid_steps, o.jacobi_scaling, o.check_every) == (5, 1, 4)
     assert lib.default_options(True).max_num_iterations == 100       # TS.cpp:274
-    assert C.sizeof(lib.CIteration) == 72 and C.sizeof(lib.CProblem) == 112
+    assert C.sizeof(lib.CIteration) == 72 and C.sizeof(lib.CProblem) == 120        # ABI 2: + board_pose_constant
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -26,7 +26,7 @@ def _cmp_trace(gs, os_, rtol=1e-6):
 
 def test_native_library_is_loaded(hip_device):
     from tscm_calib_amd import lib
-    assert lib.lib().tscm_abi_version() == 1
+    assert lib.lib().tscm_abi_version() == 2
     assert lib.lib().tscm_device_count() >= 1
 
 
@@ -178,6 +178,41 @@ def test_lm_mono_config2(hip_device):
     assert e["intr"] < 1e-6 and e["board_rt"] < 1e-6, e
     assert abs(gs["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
     assert gs["termination"] == "CONVERGENCE"
+
+
+def test_constant_board_poses(hip_device):
+    """board_pose_constant (SetParameterBlockConstant on pose blocks; the reference never does it -- SURVEY 8d's
+    poses-fixed switch): all views fixed (mono: 7 free intrinsics, the Schur complement vanishes), and a rig with every
+    second board fixed, against the oracle."""
+    p = synth.make_config(1, poses_fixed=True)
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    assert H.param_rel_err(pg, po)["intr"] < 1e-6
+    assert np.array_equal(pg.board_rt, p.board_rt)                  # constant blocks come back bit for bit
+    q = H.small_rig(4, 16, seed=9)
+    c = np.zeros(q.n_boards, dtype=np.uint8)
+    c[::2] = 1
+    q.board_pose_constant = c
+    qg, qo, gs, os_ = _solve_both(q)
+    _cmp_trace(gs, os_)
+    assert max(H.param_rel_err(qg, qo).values()) < 1e-6
+    assert np.array_equal(qg.board_rt[::2], q.board_rt[::2])
+    # sharded: the flags follow the boards to their ranks
+    qs = q.copy().normalised()
+    with api.Group(qs, 3) as g:
+        sums = g.solve()
+    assert sums[0]["num_iterations"] == os_["num_iterations"]
+    assert max(H.param_rel_err(qs, qo).values()) < 1e-6 and np.array_equal(qs.board_rt[::2], q.board_rt[::2])
+
+
+def test_lm_mono_config2_poses_fixed(hip_device):
+    """BASELINE config 2 in its "intrinsics-only" form: 2000 views x 54 corners, every view pose held constant."""
+    p = synth.make_config(2, poses_fixed=True)
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    assert H.param_rel_err(pg, po)["intr"] < 1e-6
+    assert abs(gs["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
+    assert np.array_equal(pg.board_rt, p.board_rt)
 
 
 def test_lm_multi_config4_vs_oracle(hip_device):

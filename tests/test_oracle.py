@@ -218,3 +218,34 @@ def test_openmp_passes_agree_with_the_sequential_checker():
             assert abs(x["cost"] - y["cost"]) <= 1e-11 * abs(y["cost"])
         assert np.max(np.abs(a.intr - b.intr) / np.maximum(np.abs(a.intr), 1e-3)) < 1e-9
         assert np.max(np.abs(a.board_rt - b.board_rt)) < 1e-7
+
+
+def test_constant_board_poses_in_the_oracle():
+    """tscm_problem.board_pose_constant (the poses-fixed form of BASELINE config 2): constant blocks leave the program --
+    they are returned untouched, their residuals still count, and with exact data and exact poses the intrinsics are
+    recovered."""
+    p = synth.make_problem(1, 30, 5, noise_px=0.0)
+    p.board_rt = p.meta["gt_board_rt"].copy()
+    p.board_pose_constant = np.ones(p.n_boards, dtype=np.uint8)
+    q = p.copy().normalised()
+    s = orc.solve(q)
+    assert s["termination_type"] == 0 and s["final_cost"] < 1e-12
+    assert np.array_equal(q.board_rt, p.board_rt)
+    assert np.max(np.abs(q.intr[0, :7] - p.meta["gt_intr"][0, :7]) / np.abs(p.meta["gt_intr"][0, :7])) < 1e-5
+    # a rig with every second board constant: those stay, the others move, and the cost is the plain sum over ALL corners
+    p = synth.make_problem(4, 12, 6)
+    c = np.zeros(p.n_boards, dtype=np.uint8)
+    c[::2] = 1
+    p.board_pose_constant = c
+    q = p.copy().normalised()
+    s = orc.solve(q)
+    assert s["termination_type"] == 0
+    assert np.array_equal(q.board_rt[::2], p.board_rt[::2]) and np.abs(q.board_rt[1::2] - p.board_rt[1::2]).max() > 0
+    cost, _ = orc.evaluate(q, jets=False)
+    assert abs(cost - s["final_cost"]) <= 1e-12 * cost
+    # an all-zero flag array is the unconstrained problem
+    a, b = p.copy().normalised(), p.copy().normalised()
+    a.board_pose_constant = None
+    b.board_pose_constant = np.zeros(p.n_boards, dtype=np.uint8)
+    sa, sb = orc.solve(a), orc.solve(b)
+    assert sa["iterations"] == sb["iterations"] and np.array_equal(a.intr, b.intr)

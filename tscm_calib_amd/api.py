@@ -87,10 +87,11 @@ class Solver:
         _l.check(_l.lib().tscm_solver_gather_boards(self._h, _l.dptr(board)))
         return board
 
-    def kernel_time(self, enable: bool = True):
-        """(launches, total_ms) of the dominant kernel since the last call; (re)arms the HIP-event timers."""
+    def kernel_time(self, enable=True):
+        """(timed launches, total_ms) of the dominant kernel since the last call; (re)arms the HIP-event timers:
+        enable = False / 0 off, True / 1 every launch, n every n-th launch."""
         n, ms = C.c_int(0), C.c_double(0.0)
-        _l.check(_l.lib().tscm_solver_kernel_time(self._h, 1 if enable else 0, C.byref(n), C.byref(ms)))
+        _l.check(_l.lib().tscm_solver_kernel_time(self._h, int(enable), C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
 
@@ -184,7 +185,8 @@ def _is_normalised(p: Problem) -> bool:
     ok = lambda a, dt: isinstance(a, np.ndarray) and a.dtype == dt and a.flags["C_CONTIGUOUS"]
     return (all(ok(getattr(p, n), np.float64) for n in ("board_xy", "obs_u", "obs_v", "cam_rt", "intr", "board_rt"))
             and all(ok(getattr(p, n), np.int32) for n in ("view_camera", "view_board", "view_offset", "view_count"))
-            and ok(p.cam_pose_constant, np.uint8))
+            and ok(p.cam_pose_constant, np.uint8)
+            and (p.board_pose_constant is None or ok(p.board_pose_constant, np.uint8)))
 
 
 def calibrate(problem: Problem, device: int = 0, **options) -> dict:

@@ -101,11 +101,14 @@ def find_chessboard(gray, cols: int, rows: int, sigma: int = 4, device: int = 0)
     return d["sub"][boards[0].ravel()]
 
 
-def find_chessboards(images, cols: int, rows: int, sigma: int = 4, device: int = 0) -> list:
+def find_chessboards(images, cols: int, rows: int, sigma: int = 4, device: int = 0, first_board_only: bool = False) -> list:
     """find_chessboard for a list of images of one size: ONE pass of the detection kernels for all of them
-    (tscm_detect_corners_batch), then the structure recovery per image.  Entries are (rows * cols, 2) arrays or None."""
+    (tscm_detect_corners_batch), then the structure recovery per image.  Entries are (rows * cols, 2) arrays or None.
+    Acceptance: exactly one board of rows x cols corners (main.cpp:40-46, the input images); first_board_only: at least
+    one board and board 0 has the right shape (main.cpp:67, the remapped chessboards of the refinement pass)."""
     out = []
     for d in detect_corners_batch(images, sigma=sigma, device=device):
         boards = chessboards_from_corners(d["x"], d["y"], d["v1"], d["v2"])
-        out.append(d["sub"][boards[0].ravel()] if len(boards) == 1 and boards[0].shape == (rows, cols) else None)
+        ok = (len(boards) >= 1 if first_board_only else len(boards) == 1) and boards[0].shape == (rows, cols)
+        out.append(d["sub"][boards[0].ravel()] if ok else None)
     return out

@@ -758,7 +758,9 @@ extern "C" int tscm_detect_corners_batch(const unsigned char *const *images, int
                        d_count = { cur.take<int>(B) };
     struct { DescribeTables *p; } d_tab = { cur.take<DescribeTables>(1) };
     if (!d_tab.p || !d_count.p || !d_sub.p) return tscm_set_error(TSCM_E_HIP, "internal error: arena too small");
-    for (size_t q = 0; q < B; ++q) CRN_TRY(hipMemcpy(d_gray.p + q * gbytes, images[q], gbytes, hipMemcpyHostToDevice));
+    // a strided view (cv::Mat ROI, numpy column slice) only guarantees (height - 1) * stride + width bytes behind its pointer
+    const size_t host_bytes = (size_t)(height - 1) * (size_t)stride + (size_t)width;
+    for (size_t q = 0; q < B; ++q) CRN_TRY(hipMemcpy(d_gray.p + q * gbytes, images[q], std::min(gbytes, host_bytes), hipMemcpyHostToDevice));
     CRN_TRY(hipMemcpy(d_taps.p, taps.data(), sizeof(double) * ntap, hipMemcpyHostToDevice));
     CRN_TRY(hipMemcpy(d_tab.p, tab.data(), sizeof(DescribeTables), hipMemcpyHostToDevice));
     {

@@ -139,6 +139,7 @@ struct DevProblem {
                                                // (device boards are numbered in signature order: a chunk's boards AND slots are contiguous)
     int n_bchunks, n_tiles;
     const unsigned char *cam_const, *cam_active;
+    const unsigned char *board_const;  // [B] device board: pose block held constant (tscm_problem.board_pose_constant)
     const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
     const int *act_map;                // [n_pad] compact index -> padded column (first n_act entries)
     int n_act;
@@ -683,7 +684,7 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
     double gmax = 0.0, gsq = 0.0, xsq = 0.0;
     if (b < P.B) {
         const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
-        if (q1 > q0) {
+        if (q1 > q0 && !P.board_const[b]) {         // constant pose blocks are not part of the reduced program
             double g[6] = { 0, 0, 0, 0, 0, 0 }, dg[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
                 const double *rec = rec_e(S.rec[tgt], P.V, q);
@@ -834,8 +835,16 @@ __device__ __forceinline__ bool chol6(const double M[21], double L[21])
 // Factor the damped, Jacobi-scaled 6x6 block of a board from M = sum_views E^T E (packed lower) and g = sum_views E^T r,
 // and write the board's factor record (kFac doubles) to f (HBM or LDS).  Returns false if the block is not positive
 // definite.
-__device__ __forceinline__ bool factor_core(double (&M)[21], const double (&g)[6], const double (&sb)[6], double radius, double dmin, double dmax, double *f)
+// A board whose pose block is constant (SetParameterBlockConstant) has no e-block: its record is all zeros, which makes
+// Y = 0 (no Schur-complement contribution), z = 0 and the back-substituted step exactly 0.
+__device__ __forceinline__ bool factor_core(double (&M)[21], const double (&g)[6], const double (&sb)[6], double radius, double dmin, double dmax, double *f,
+                                            bool constant_block = false)
 {
+    if (constant_block) {
+#pragma unroll
+        for (int i = 0; i < kFac; ++i) f[i] = 0.0;
+        return true;
+    }
     double D2[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -889,7 +898,7 @@ __device__ __forceinline__ void factor_board(const DevProblem &P, const DevState
             g[i] += rec[kRecEG + i];
         }
     }
-    if (!factor_core(M, g, sb, radius, dmin, dmax, S.fac + (size_t)kFac * b)) S.ctrl->lin_fail = 1;
+    if (!factor_core(M, g, sb, radius, dmin, dmax, S.fac + (size_t)kFac * b, P.board_const[b] != 0)) S.ctrl->lin_fail = 1;
 }
 
 // stand-alone factorisation of the boards seen by more than three cameras (their Gram products go through
@@ -1024,6 +1033,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     double sb[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) sb[i] = tid < nbd ? S.s_b[6 * (c0 + tid) + i] : 1.0;
+    const bool board_is_const = tid < nbd && P.board_const[c0 + tid] != 0;
     // ---- phase 0a: 16 lanes per board, 16 boards per pass; the NV E records of a board are adjacent ----------------
     {
         const int e = tid & 15, grp = tid >> 4;
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
             for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = sumE[tid][6 * i + j];
             g[i] = sumE[tid][kRecEG + i];
         }
-        if (!factor_core(M, g, sb, radius, dmin, dmax, facl[tid])) S.ctrl->lin_fail = 1;
+        if (!factor_core(M, g, sb, radius, dmin, dmax, facl[tid], board_is_const)) S.ctrl->lin_fail = 1;
     }
     __syncthreads();
     PHASE_STAMP(ts2);

@@ -88,7 +88,8 @@ struct tscm_solver {
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     // dominant-kernel timing
-    bool timing = false;
+    int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel with HIP events
+    unsigned eval_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t ev_used = 0;
     int t_launches = 0;
@@ -536,6 +537,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.cam_const, cam_const))) return rc;
     if ((rc = dev_upload(s, &P.cam_active, cam_active))) return rc;
     {
+        std::vector<unsigned char> board_const((size_t)B, 0);
+        if (p->board_pose_constant) for (int i = 0; i < B; ++i) board_const[i] = p->board_pose_constant[b0 + s->board_perm[i]] ? 1 : 0;
+        if ((rc = dev_upload(s, &P.board_const, board_const))) return rc;
+    }
+    {
         std::vector<unsigned char> col_active((size_t)s->n_pad, 0);
         for (int i = 0; i < s->n_pad; ++i) { const int m = i >> 4, a = i & 15; col_active[i] = (a < kFA && cam_active[m] && !(a < 6 && cam_const[m])) ? 1 : 0; }
         if ((rc = dev_upload(s, &P.col_active, col_active))) return rc;
@@ -668,7 +674,9 @@ static int launch_eval(tscm_solver *s, int cand)
     const DevProblem &P = s->P;
     if (P.n_chunks == 0) return 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->timing) {
+    // (an event pair costs about 3 us of stream time per side: sampling keeps the measurement out of the result)
+    const bool timed = s->timing > 0 && (s->eval_launches++ % (unsigned)s->timing) == 0;
+    if (timed) {
         if (s->ev_used == s->ev.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -681,7 +689,7 @@ static int launch_eval(tscm_solver *s, int cand)
     if (s->f32_jacobian) hipLaunchKernelGGL(k_eval_gram_f32, dim3(P.n_chunks / 4), dim3(256), s->lds_eval32, s->stream, P, s->S, cand);
     else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
     else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
-    if (s->timing) HIP_TRY(hipEventRecord(e1, s->stream));
+    if (timed) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
 }
 
@@ -702,7 +710,8 @@ extern "C" int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches
     if (launches) *launches = s->t_launches;
     if (total_ms) *total_ms = s->t_ms;
     s->t_launches = 0; s->t_ms = 0.0;
-    s->timing = enable != 0;
+    s->timing = enable < 0 ? 0 : enable;
+    s->eval_launches = 0;
     return 0;
 }
 
@@ -1094,11 +1103,7 @@ extern "C" int tscm_eval_functor(const tscm_problem *p, int device, double *resi
         if (J_board) std::memcpy(J_board + 12 * dst, h_Jb.data() + 12 * src, sizeof(double) * 12 * cnt);
         if (J_intr) std::memcpy(J_intr + 18 * dst, h_Ji.data() + 18 * src, sizeof(double) * 18 * cnt);
     }
-    // cost in problem order (same summation order as a sequential evaluator)
-    { long k = 0; for (int v = 0; v < p->n_views; ++v) for (int j = 0; j < p->view_count[v]; ++j, ++k) {
-        // locate the device row of this corner
-        (void)j; } }
-    for (size_t k = 0; k < N; ++k) c += 0.5 * (h_res[2 * k] * h_res[2 * k] + h_res[2 * k + 1] * h_res[2 * k + 1]);
+    for (size_t k = 0; k < N; ++k) c += 0.5 * (h_res[2 * k] * h_res[2 * k] + h_res[2 * k + 1] * h_res[2 * k + 1]);     // device corner order
     if (cost) *cost = c;
     return 0;
 }
@@ -1147,6 +1152,13 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     return 0;
 }
 
+// device buffer freed on every exit path of the small entry points below
+struct DevBuf {
+    double *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(n, 1) * sizeof(double)); }
+};
+
 extern "C" int tscm_project_points(const double *intr9, const double *points, int n, int device, double *pixels)
 {
     if (!intr9 || (n > 0 && (!points || !pixels)) || n < 0) return fail(TSCM_E_INVALID, "NULL argument");
@@ -1154,15 +1166,14 @@ extern "C" int tscm_project_points(const double *intr9, const double *points, in
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
     HIP_TRY(hipSetDevice(device));
     if (n == 0) return 0;
-    double *d_i = nullptr, *d_p = nullptr, *d_o = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_i), 9 * sizeof(double)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_p), 3 * (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_o), 2 * (size_t)n * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_i, intr9, 9 * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_p, points, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_project, dim3((n + 255) / 256), dim3(256), 0, 0, d_i, d_p, n, d_o);
-    HIP_TRY(hipMemcpy(pixels, d_o, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_i); (void)hipFree(d_p); (void)hipFree(d_o);
+    DevBuf d_i, d_p, d_o;
+    HIP_TRY(d_i.alloc(9));
+    HIP_TRY(d_p.alloc(3 * (size_t)n));
+    HIP_TRY(d_o.alloc(2 * (size_t)n));
+    HIP_TRY(hipMemcpy(d_i.p, intr9, 9 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p.p, points, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_project, dim3((n + 255) / 256), dim3(256), 0, 0, d_i.p, d_p.p, n, d_o.p);
+    HIP_TRY(hipMemcpy(pixels, d_o.p, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1173,15 +1184,14 @@ extern "C" int tscm_unproject_pixels(const double *intr9, const double *pixels, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
     HIP_TRY(hipSetDevice(device));
     if (n == 0) return 0;
-    double *d_i = nullptr, *d_p = nullptr, *d_o = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_i), 9 * sizeof(double)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_p), 2 * (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_o), 3 * (size_t)n * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_i, intr9, 9 * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_p, pixels, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_unproject, dim3((n + 255) / 256), dim3(256), 0, 0, d_i, d_p, n, d_o);
-    HIP_TRY(hipMemcpy(rays, d_o, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_i); (void)hipFree(d_p); (void)hipFree(d_o);
+    DevBuf d_i, d_p, d_o;
+    HIP_TRY(d_i.alloc(9));
+    HIP_TRY(d_p.alloc(2 * (size_t)n));
+    HIP_TRY(d_o.alloc(3 * (size_t)n));
+    HIP_TRY(hipMemcpy(d_i.p, intr9, 9 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_p.p, pixels, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_unproject, dim3((n + 255) / 256), dim3(256), 0, 0, d_i.p, d_p.p, n, d_o.p);
+    HIP_TRY(hipMemcpy(rays, d_o.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

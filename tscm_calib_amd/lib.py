@@ -35,7 +35,7 @@ class CProblem(C.Structure):
         ("board_xy", C.c_void_p), ("view_camera", C.c_void_p), ("view_board", C.c_void_p),
         ("view_offset", C.c_void_p), ("view_count", C.c_void_p), ("obs_u", C.c_void_p), ("obs_v", C.c_void_p),
         ("cam_rt", C.c_void_p), ("intr", C.c_void_p), ("board_rt", C.c_void_p),
-        ("cam_pose_constant", C.c_void_p), ("mono", C.c_int),
+        ("cam_pose_constant", C.c_void_p), ("mono", C.c_int), ("board_pose_constant", C.c_void_p),
     ]
 
 
@@ -211,6 +211,11 @@ def c_problem(p) -> CProblem:
             raise ValueError(f"{name} must be C-contiguous (use Problem.normalised())")
         setattr(q, name, arr.ctypes.data)
     q.mono = 1 if p.mono else 0
+    bpc = getattr(p, "board_pose_constant", None)
+    if bpc is not None:
+        if bpc.dtype != np.uint8 or not bpc.flags["C_CONTIGUOUS"]:
+            raise ValueError("board_pose_constant must be C-contiguous uint8 (use Problem.normalised())")
+        q.board_pose_constant = bpc.ctypes.data
     return q
 
 

@@ -16,14 +16,20 @@ def board_points(cols: int, rows: int, pitch: float) -> np.ndarray:
     return np.stack([v.ravel() * pitch, u.ravel() * pitch, np.zeros(cols * rows)], axis=1).astype(np.float64)
 
 
-def calibrate_camera(pu, pv, has, cols, rows, pitch, img_size, device=0):
-    """TripleSphereCamera::calibrate (TS.cpp:30-105): principal point at the image centre, xi = lambda = 0,
-    alpha = 0.5, estimate_focal, estimate_extrinsic, refinement.  Returns (intr[9], Rt[V,3,3] = [r1 r2 t], summary)."""
+def calibrate_camera(pu, pv, has, cols, rows, pitch, img_size, device=0, init_intr=None):
+    """TripleSphereCamera::calibrate (TS.cpp:30-105).  Without an initial guess (has_init_guess_ false, :41-51):
+    principal point at the image centre, xi = lambda = 0, alpha = 0.5, estimate_focal.  With init_intr (the member
+    intrinsic_ after a converged earlier refinement set has_init_guess_, :78) those steps are skipped and only the
+    extrinsics are re-estimated (:52).  Then estimate_extrinsic, refinement.
+    Returns (intr[9], Rt[V,3,3] = [r1 r2 t], summary)."""
     n = cols * rows
     W = board_points(cols, rows, pitch)
     count = (np.asarray(has, dtype=np.int32) * n).astype(np.int32)
-    intr = np.array([0.0, 0.0, img_size[0] / 2 - 0.5, img_size[1] / 2 - 0.5, 0.0, 0.0, 0.5, 0.0, 0.0])
-    intr[0] = intr[1] = rig.estimate_focal(pu, pv, count, cols, rows, intr[2], intr[3], device)[0]
+    if init_intr is None:
+        intr = np.array([0.0, 0.0, img_size[0] / 2 - 0.5, img_size[1] / 2 - 0.5, 0.0, 0.0, 0.5, 0.0, 0.0])
+        intr[0] = intr[1] = rig.estimate_focal(pu, pv, count, cols, rows, intr[2], intr[3], device)[0]
+    else:
+        intr = np.array(init_intr, dtype=np.float64).reshape(9).copy()
     Rt0, _ = rig.estimate_extrinsic(intr, pu, pv, count, W, cols, device)
     sel = np.flatnonzero(count > 0)
     V = sel.shape[0]
@@ -63,14 +69,18 @@ def monocular_calib(images, cols: int, rows: int, pitch: float, sigma: int = 4, 
         mx, my, _ = maps.build_maps([desc], desc.width * desc.height, device)
         board_imgs.append(maps.remap(images[i], mx.reshape(desc.height, desc.width), my.reshape(desc.height, desc.width), to_gray=images[i].ndim == 3,
                                      device=device))
-    for i, board_img, pts in zip(seen, board_imgs, corners.find_chessboards(board_imgs, cols, rows, sigma=sigma, device=device)):
+    # (main.cpp:67: the remapped board is rejected only if NO board came out or board 0 has the wrong shape)
+    for i, board_img, pts in zip(seen, board_imgs, corners.find_chessboards(board_imgs, cols, rows, sigma=sigma, device=device, first_board_only=True)):
         if pts is not None:                                                   # :92-105 back through [r1 r2 t] and project()
             P = (Rt[i] @ np.concatenate([pts - pitch, np.ones((n, 1))], axis=1).T).T
             uv = api.project(intr, P, device)
             pu[i], pv[i] = uv[:, 0], uv[:, 1]
         if _top_left_is_bright(board_img, pitch):                             # :72-89 / :107-121 flip rule
             pu[i], pv[i] = pu[i][::-1].copy(), pv[i][::-1].copy()
-    intr, Rt, second = calibrate_camera(pu, pv, has, cols, rows, pitch, img_size, device)         # :127
+    # :127 -- the second calibrate() of the same object: a converged first refinement left has_init_guess_ set (TS.cpp:78),
+    # so it starts from the first-pass intrinsics and only re-estimates the extrinsics
+    warm = intr if first["termination_type"] == 0 else None
+    intr, Rt, second = calibrate_camera(pu, pv, has, cols, rows, pitch, img_size, device, init_intr=warm)
     return dict(intr=intr, Rt=Rt, has=has, pix_u=pu, pix_v=pv, first=first, second=second)
 
 

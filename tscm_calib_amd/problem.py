@@ -35,6 +35,7 @@ class Problem:
     cam_pose_constant: np.ndarray # [C] uint8
     mono: bool = False
     meta: dict = field(default_factory=dict)
+    board_pose_constant: "np.ndarray | None" = None   # [B] uint8, 1 = pose block held constant (None: all free, as in the reference)
 
     @property
     def n_points(self) -> int:
@@ -53,7 +54,8 @@ class Problem:
             self.n_cameras, self.n_boards, self.board_xy.copy(), self.view_camera.copy(),
             self.view_board.copy(), self.view_offset.copy(), self.view_count.copy(),
             self.obs_u.copy(), self.obs_v.copy(), self.cam_rt.copy(), self.intr.copy(),
-            self.board_rt.copy(), self.cam_pose_constant.copy(), self.mono, dict(self.meta))
+            self.board_rt.copy(), self.cam_pose_constant.copy(), self.mono, dict(self.meta),
+            None if self.board_pose_constant is None else self.board_pose_constant.copy())
 
     def normalised(self) -> "Problem":
         """Contiguous, correctly typed arrays (what the C ABI expects)."""
@@ -63,7 +65,8 @@ class Problem:
             int(self.n_cameras), int(self.n_boards), f(self.board_xy).reshape(-1, 2), i(self.view_camera),
             i(self.view_board), i(self.view_offset), i(self.view_count), f(self.obs_u), f(self.obs_v),
             f(self.cam_rt).reshape(-1, 6), f(self.intr).reshape(-1, 9), f(self.board_rt).reshape(-1, 6),
-            np.ascontiguousarray(self.cam_pose_constant, dtype=np.uint8), bool(self.mono), dict(self.meta))
+            np.ascontiguousarray(self.cam_pose_constant, dtype=np.uint8), bool(self.mono), dict(self.meta),
+            None if self.board_pose_constant is None else np.ascontiguousarray(self.board_pose_constant, dtype=np.uint8))
 
     def validate(self) -> None:
         C, B, V = self.n_cameras, self.n_boards, self.n_views
@@ -71,6 +74,8 @@ class Problem:
             raise ValueError("parameter array shapes do not match n_cameras/n_boards")
         if self.mono and C != 1:
             raise ValueError("mono problem needs exactly one camera")
+        if self.board_pose_constant is not None and self.board_pose_constant.shape != (B,):
+            raise ValueError("board_pose_constant must have n_boards entries")
         for a in (self.view_board, self.view_offset, self.view_count):
             if a.shape != (V,):
                 raise ValueError("view arrays must all have n_views entries")

@@ -303,10 +303,17 @@ def make_problem(n_cameras: int, views_per_cam: int, seed: int, *, noise_px: flo
 CONFIGS = {1: (1, 20), 2: (1, 2000), 3: (4, 500), 4: (4, 10000), 5: (8, 20000)}
 
 
-def make_config(index: int, **kw) -> Problem:
+def make_config(index: int, *, poses_fixed: bool = False, **kw) -> Problem:
+    """BASELINE.json config `index`.  poses_fixed: the "intrinsics-only" form SURVEY 8d asks for next to config 2 --
+    every board / view pose block is held constant (tscm_problem.board_pose_constant) at its ground-truth value, as if
+    the poses were known from an earlier calibration, and only the intrinsics (and the free camera poses) are solved."""
     C, V = CONFIGS[index]
     p = make_problem(C, V, 20240 + index, **kw)
     p.meta["config"] = index
+    if poses_fixed:
+        p.board_rt = p.meta["gt_board_rt"].copy()
+        p.board_pose_constant = np.ones(p.n_boards, dtype=np.uint8)
+        p.meta["poses_fixed"] = True
     return p
 
 
