@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turns the two PMC passes of tools/pmc.sh (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs of `bench.py --steps 10
+--warmup 0 --no-cpu-baseline`) into profiles/pmc_eval_gram.json / pmc_side_kernels.json entries.
+
+    python tools/record_pmc.py gpurun_out/pmc_<fetch tag> gpurun_out/pmc_<write tag> [config]
+
+Units and corrections as MI355X_MICROARCH.md prescribes and tools/calib_fetch.hip confirmed on these boxes: both counters
+report KB; FETCH_SIZE counts half of the bytes of this library's 8 B/lane and 16 B/lane loads (x2), WRITE_SIZE is exact.
+The entry is stamped with the hash of the kernel sources it was measured on (bench.py only reports `roofline.traffic`
+while that hash matches the sources it runs)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def per_kernel(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    tot, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tscm::", "")
+        tot[k] += float(r["Counter_Value"])
+        n[k] += 1
+    return {k: tot[k] / n[k] for k in tot}, dict(n)
+
+
+def main():
+    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    config = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
+    write, _ = per_kernel(write_dir, "WRITE_SIZE")
+    sha = bench._kernel_src_sha()
+    kernels = {}
+    for k in sorted(fetch):
+        rd, wr = 2.0 * fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
+        kernels[k] = {"dispatches": nf[k], "FETCH_SIZE_KB_per_launch": fetch[k], "WRITE_SIZE_KB_per_launch": write.get(k, 0.0),
+                      "read_bytes_corrected": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    path = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
+    doc = json.load(open(path))
+    ev = next(v for k, v in kernels.items() if k.startswith("k_eval_gram"))
+    n_corners = {4: 2160000}.get(config)
+    doc[f"config{config}"] = {
+        "kernel_src_sha": sha, "round": 2,
+        "FETCH_SIZE_KB_per_launch": ev["FETCH_SIZE_KB_per_launch"], "WRITE_SIZE_KB_per_launch": ev["WRITE_SIZE_KB_per_launch"],
+        "read_bytes_corrected": ev["read_bytes_corrected"], "hbm_bytes_per_launch": ev["hbm_bytes_per_launch"],
+        "algorithmic_bytes_per_launch": n_corners * bench.BYTES_PER_CORNER if n_corners else None,
+        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/pmc.sh), averaged over the k_eval_gram dispatches; "
+                "hbm = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes). Writes are the kernel's OUTPUT: 132 doubles per view of Schur records + per-workgroup camera tiles.",
+    }
+    doc[f"config{config}_all_kernels_round2"] = {"kernel_src_sha": sha, "per_launch": kernels}
+    json.dump(doc, open(path, "w"), indent=1)
+    for k, v in kernels.items():
+        print(f"{k:34s} read {v['read_bytes_corrected'] / 1e6:7.2f} MB  write {v['write_bytes'] / 1e6:7.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
