@@ -1529,297 +1529,6 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
 }
 
 // ---------------------------------------------------------------------------------------------
-// Reduced camera system on ONE WAVE (rigs of up to 4 cameras: n_pad <= 64, n_act + 1 <= 16 NB columns).
-// The compact system and, as one more row, its right-hand side live row-major in LDS; the factorisation is a
-// left-looking blocked Cholesky with 4-column panels in a ROLLED loop (the code of a single wave is fetched from a
-// cold instruction cache: a fully unrolled register version ran at ~54 cycles per 64-byte line):
-//   * panel update  A_p -= L[:, 0:k0] L[k0:k0+4, 0:k0]^T  on the matrix core.  v_mfma_f64_16x16x4 computes
-//     D[m][n] = sum_k a(m, k) b(k, n) with lane (x, k) supplying a(x, k) and b(k, x) and rows m = kq + 4 reg of column
-//     n in lane (n, kq).  Feeding a = the panel's own four rows of L (m < 4) and b = sixteen rows of L makes reg 0 of
-//     lane (row, col) the update of element (row, k0 + col): operands and result are all in the "lane = (row, column
-//     within the panel)" layout that is also how the wave reads and writes the LDS matrix -- no transposes.
-//   * the 4x4 diagonal block is read by broadcast and factored AND inverted redundantly in every lane (uniform
-//     values: ~60 dependent flops); each lane then forms its entry of  X = A_p L_kk^{-T}  from its row's four raw
-//     values and writes it back.  The right-hand side row rides along: after the last panel it holds w = L^{-1} b.
-// Back-substitution and tail as in k_solve_reduced, on wave shuffles.
-// LDS: N (N + 1) + N + 128 doubles, N = 16 NB.
-// ---------------------------------------------------------------------------------------------
-template <int NB>
-__host__ __device__ constexpr int solve_wave_lds_doubles() { return 16 * NB * (16 * NB + 1) + 16 * NB + 128; }
-
-// The reduced system's LDS image: A [N][N + 1] row-major (lower triangle + the rhs as row n_act), idg [N],
-// yv [64], s_yh [64].
-// solve_gather: ALL NT threads of the workgroup assemble A -- the element loop is unrolled (its loads must be in flight
-// together), so the more threads share it the less code a wave fetches from the cold instruction cache.  The caller
-// puts a workgroup barrier between the gather and solve_factor_wave (one wave).
-template <int NB, int NT>
-__device__ __forceinline__ void solve_gather(const DevProblem &P, const DevState &S, double *lds)
-{
-    constexpr int N = 16 * NB, LD = N + 1;
-    constexpr int NE = (N * (N + 1) / 2 + NT - 1) / NT;   // elements of the lower triangle (incl. the rhs row) per thread
-    double *A = lds;
-    double *yv = A + N * LD + N;
-    int *s_map = reinterpret_cast<int *>(yv + 64);        // [64] compact -> padded (the s_yh area, free until the tail)
-    const int tid = threadIdx.x;
-    const int na = P.n_act, n = P.n_pad;
-    // every address below comes from kernel arguments, so the control block, the scalings, BOTH candidate H buffers
-    // (the current one is picked once the control block is here) and T travel in ONE memory round trip
-    const int ne_total = (na + 1) * (na + 2) / 2;
-    if (tid < 64) {
-        int base = 0, c0 = P.cam_col0[0];
-#pragma unroll
-        for (int q = 1; q < kMaxCamLds; ++q) { const bool ge = tid >= P.cam_pre[q]; base = ge ? P.cam_pre[q] : base; c0 = ge ? P.cam_col0[q] : c0; }
-        s_map[tid] = tid < na ? c0 + (tid - base) : -1;
-    }
-    const double my_sc = tid < n ? S.s_c[tid] : 1.0;
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t r_h0 = make_rsrc(S.H[0], sizeof(double) * 256 * (size_t)P.C), r_h1 = make_rsrc(S.H[1], sizeof(double) * 256 * (size_t)P.C);
-    const __amdgpu_buffer_rsrc_t r_t = make_rsrc(S.T, sizeof(double) * 256 * (size_t)P.n_bids);
-    const unsigned mask = (unsigned)P.pair_mask;          // up to 4 cameras: the pair bits lo * 8 + hi fit 32 bits
-    constexpr unsigned BAD = 0xffffe000u;
-    int e_pi[NE], e_pj[NE], e_idx[NE];                    // padded row (-2: the rhs row, -1: no element), padded column, LDS index
-    double h0[NE], h1[NE], tt[NE];
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-        const int e = tid + NT * u;
-        int i = (int)((__builtin_amdgcn_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        i += (i + 1) * (i + 2) / 2 <= e ? 1 : 0;
-        i -= i * (i + 1) / 2 > e ? 1 : 0;
-        const int j = e - i * (i + 1) / 2;
-        const bool valid = e < ne_total;
-        const int pj = (valid && j < na) ? s_map[j] : -1;      // -1: the corner element (rhs row, rhs column)
-        const int pi = !valid ? -1 : i < na ? s_map[i] : -2;
-        e_pi[u] = pi; e_pj[u] = pj; e_idx[u] = i * LD + j;
-        // matrix element: H[pi][pj] (same camera) and T[pi][pj];  rhs row: column kFR of H / T at row pj
-        const bool has = pj >= 0 && pi != -1;
-        const int mj = pj >> 4;
-        const int hi = pi >= 0 ? pi : pj, hb = pi >= 0 ? (pj & 15) : kFR;
-        const unsigned oh = (has && (hi >> 4) == mj) ? 8u * (unsigned)(256 * mj + (hi & 15) * 16 + hb) : BAD;
-        // T(hi, col) with col = pj or the gradient column of pj's camera; hi >= col camera-wise: the upper tile (mj, mi) transposed
-        int lo = mj, hic = hi >> 4, ta = pi >= 0 ? (pj & 15) : (hi & 15), tb = pi >= 0 ? (hi & 15) : kFR;
-        if (pi < 0) { hic = mj; }
-        const int bit = lo * 8 + hic;
-        const unsigned ot = (has && ((mask >> bit) & 1u)) ? 8u * (unsigned)(256 * __builtin_popcount(mask & ((1u << bit) - 1u)) + ta * 16 + tb) : BAD;
-        h0[u] = buf_load_f64(r_h0, oh, 0u);
-        h1[u] = buf_load_f64(r_h1, oh, 0u);
-        tt[u] = buf_load_f64(r_t, ot, 0u);
-    }
-    const int cur = S.ctrl->cur;
-    const double radius = S.ctrl->radius;
-    const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
-    // padded-column scalings through LDS (yv is free until the back-substitution)
-    if (tid < 64) yv[tid] = my_sc;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-        const int pi = e_pi[u], pj = e_pj[u];
-        if (pi == -1) continue;
-        const double h = cur ? h1[u] : h0[u];
-        double v = 1.0;                                   // the corner element
-        if (pj >= 0) {
-            const double sj = yv[pj], si = pi >= 0 ? yv[pi] : 1.0;
-            v = si * sj * (h - tt[u]);
-            if (pi == pj) v += fmin(fmax(si * si * h, dmin), dmax) / radius;
-        }
-        A[e_idx[u]] = v;
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void solve_factor_wave(const DevProblem &P, const DevState &S, double *lds)
-{
-    constexpr int N = 16 * NB, LD = N + 1;
-    double *A = lds;                  // [N][LD]
-    double *idg = A + N * LD;         // [N]   1 / L_kk
-    double *yv = idg + N;             // [64]  solution by padded column (the gather left the scalings here)
-    double *s_yh = yv + 64;           // [64]  (the gather left the compact -> padded map here)
-    const int lane = threadIdx.x & 63, c = lane & 15, kq = lane >> 4;
-    const int na = P.n_act, n = P.n_pad;          // na + 1 <= N, n <= 64
-    const int ib = na;                            // row of the right-hand side
-    const int cur = S.ctrl->cur;
-    int fail = S.ctrl->lin_fail;
-    const double my_sc = yv[lane];
-    const int my_pad = reinterpret_cast<const int *>(s_yh)[lane];        // padded column of compact column `lane`
-    const unsigned char my_act = lane < n ? P.col_active[lane] : 0;
-    // tail operands (this lane's padded column): in flight during the factorisation
-    double t_x = 0.0, t_hg = 0.0, t_hrow[kFA];
-    {
-        const double *H = S.H[cur];
-        const int m = lane >> 4, ai = lane & 15;
-#pragma unroll
-        for (int b = 0; b < kFA; ++b) t_hrow[b] = 0.0;
-        if (lane < n) {
-            if (ai < 6) t_x = S.cam_rt[cur][6 * m + ai];
-            else if (ai < 15) t_x = S.intr[cur][9 * m + (ai - 6)];
-            if (ai < kFA) {
-#pragma unroll
-                for (int b = 0; b < kFA; ++b) t_hrow[b] = H[256 * m + ai * 16 + b];
-                t_hg = H[256 * m + ai * 16 + kFR];
-            }
-        }
-    }
-    wave_lds_fence();
-    PHASE_STAMP(tf0);
-    // ---- factorisation ------------------------------------------------------------------------------------------------
-    const int NP = (na + 3) >> 2;                       // panels that hold free columns
-    const int NBe = (ib >> 4) + 1;                      // block-rows that hold rows <= ib
-    for (int p = 0; p < NP; ++p) {
-        const int k0 = 4 * p, R = p >> 2;
-        d4 acc[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = d4{ 0.0, 0.0, 0.0, 0.0 };
-        for (int q = 0; q < p; ++q) {
-            const double a_op = c < 4 ? A[(k0 + c) * LD + 4 * q + kq] : 0.0;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (b < R || b >= NBe) continue;        // wave-uniform
-                const double b_op = A[(16 * b + c) * LD + 4 * q + kq];
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc[b], 0, 0, 0);
-            }
-        }
-        // updated raw panel entries back to LDS: lane (c, kq) owns element (16 b + c, k0 + kq)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b < R || b >= NBe) continue;
-            const int i = 16 * b + c;
-            if (i >= k0 && i <= ib && p > 0) A[i * LD + k0 + kq] -= acc[b][0];
-        }
-        wave_lds_fence();
-        // the 4x4 diagonal block, uniform in every lane; columns past the last free one are identity
-        double a00 = A[(k0 + 0) * LD + k0 + 0];
-        double a10 = A[(k0 + 1) * LD + k0 + 0], a11 = A[(k0 + 1) * LD + k0 + 1];
-        double a20 = A[(k0 + 2) * LD + k0 + 0], a21 = A[(k0 + 2) * LD + k0 + 1], a22 = A[(k0 + 2) * LD + k0 + 2];
-        double a30 = A[(k0 + 3) * LD + k0 + 0], a31 = A[(k0 + 3) * LD + k0 + 1], a32 = A[(k0 + 3) * LD + k0 + 2], a33 = A[(k0 + 3) * LD + k0 + 3];
-        const int nv = na - k0;                          // free columns in this panel (>= 1)
-        if (nv < 2) { a10 = 0.0; a11 = 1.0; }
-        if (nv < 3) { a20 = 0.0; a21 = 0.0; a22 = 1.0; }
-        if (nv < 4) { a30 = 0.0; a31 = 0.0; a32 = 0.0; a33 = 1.0; }
-        if (!(a00 > 0.0)) { fail = 1; a00 = 1.0; }
-        const double i0 = fast_rsqrt(a00);
-        const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-        double d1 = a11 - l10 * l10;
-        if (!(d1 > 0.0)) { fail = 1; d1 = 1.0; }
-        const double i1 = fast_rsqrt(d1);
-        const double l21 = (a21 - l20 * l10) * i1, l31 = (a31 - l30 * l10) * i1;
-        double d2 = a22 - l20 * l20 - l21 * l21;
-        if (!(d2 > 0.0)) { fail = 1; d2 = 1.0; }
-        const double i2 = fast_rsqrt(d2);
-        const double l32 = (a32 - l30 * l20 - l31 * l21) * i2;
-        double d3 = a33 - l30 * l30 - l31 * l31 - l32 * l32;
-        if (!(d3 > 0.0)) { fail = 1; d3 = 1.0; }
-        const double i3 = fast_rsqrt(d3);
-        // inverse of the lower factor
-        const double v10 = -l10 * i0 * i1;
-        const double v20 = -(l20 * i0 + l21 * v10) * i2, v21 = -l21 * i1 * i2;
-        const double v30 = -(l30 * i0 + l31 * v10 + l32 * v20) * i3, v31 = -(l31 * i1 + l32 * v21) * i3, v32 = -l32 * i2 * i3;
-        // row kq of the inverse for this lane
-        const double w0 = kq == 0 ? i0 : kq == 1 ? v10 : kq == 2 ? v20 : v30;
-        const double w1 = kq == 0 ? 0.0 : kq == 1 ? i1 : kq == 2 ? v21 : v31;
-        const double w2 = kq < 2 ? 0.0 : kq == 2 ? i2 : v32;
-        const double w3 = kq < 3 ? 0.0 : i3;
-        if (lane < 4) idg[k0 + lane] = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : i3;
-        // X = A_p L_kk^{-T}: lane (c, kq) forms entry (16 b + c, k0 + kq) from its row's raw values
-        double xv[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            xv[b] = 0.0;
-            if (b < R || b >= NBe) continue;
-            const int i = 16 * b + c;
-            if (i >= k0 && i <= ib) {
-                const double r0 = A[i * LD + k0], r1 = nv > 1 ? A[i * LD + k0 + 1] : 0.0, r2 = nv > 2 ? A[i * LD + k0 + 2] : 0.0, r3 = nv > 3 ? A[i * LD + k0 + 3] : 0.0;
-                xv[b] = r0 * w0 + r1 * w1 + r2 * w2 + r3 * w3;
-            }
-        }
-        wave_lds_fence();                                 // every lane has read its raw row
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b < R || b >= NBe) continue;
-            const int i = 16 * b + c;
-            if (i >= k0 && i <= ib) A[i * LD + k0 + kq] = xv[b];
-        }
-        wave_lds_fence();
-    }
-    PHASE_STAMP(tf1);
-    // ---- back-substitution L^T y = w (row ib of the factor), 4 unknowns per step -----------------------------------------
-    double w = lane < na ? A[ib * LD + lane] : 0.0;
-    for (int tk = NP - 1; tk >= 0; --tk) {
-        const int k0 = 4 * tk;
-        double y[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = __shfl(w, k0 + q);
-#pragma unroll
-        for (int q = 3; q >= 0; --q) {
-            double v = y[q];
-#pragma unroll
-            for (int r = q + 1; r < 4; ++r) v -= (k0 + r < na ? A[(k0 + r) * LD + k0 + q] : 0.0) * y[r];
-            y[q] = k0 + q < na ? v * idg[k0 + q] : 0.0;
-        }
-        if (lane < k0) {
-            double v = w;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v -= (k0 + q < na ? A[(k0 + q) * LD + lane] : 0.0) * y[q];
-            w = v;
-        } else if (lane < k0 + 4) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (lane == k0 + q) w = y[q];
-        }
-    }
-    wave_lds_fence();
-    yv[lane] = 0.0;                                       // (the scalings have been consumed)
-    wave_lds_fence();
-    if (lane < na && my_pad >= 0) yv[my_pad] = w;         // back to padded columns
-    wave_lds_fence();
-    PHASE_STAMP(tf2);
-    // ---- tail: yhat = S_c y, candidate camera parameters, camera part of the model cost change / step norm -------------
-    {
-        const int m = lane >> 4, ai = lane & 15;
-        double model = 0.0, stepsq = 0.0, yh = 0.0;
-        if (lane < n) {
-            const bool act = my_act && !fail;
-            yh = act ? my_sc * yv[lane] : 0.0;
-            S.yhat[lane] = yh;
-            if (ai < kFA) {
-                const double xn = t_x + (-yh);
-                if (ai < 6) S.cam_rt[cur ^ 1][6 * m + ai] = xn; else S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
-                const double d = t_x - xn; stepsq = d * d;
-            } else if (ai < 15) {
-                S.intr[cur ^ 1][9 * m + (ai - 6)] = t_x;   // b, c are inert
-            }
-        }
-        s_yh[lane] = yh;
-        wave_lds_fence();
-        // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
-        if (lane < n && ai < kFA && yh != 0.0) {
-            double hy = 0.0;
-#pragma unroll
-            for (int b = 0; b < kFA; ++b) hy += t_hrow[b] * s_yh[m * 16 + b];
-            model = yh * (t_hg - 0.5 * hy);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { model += __shfl_xor(model, off); stepsq += __shfl_xor(stepsq, off); }
-        if (lane == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
-    }
-#ifdef TSCM_PHASE_PROFILE
-    if (lane == 0) printf("solve wave: factor %lld  backsub %lld  tail %lld [10 ns]\n", tf1 - tf0, tf2 - tf1, wall_clock64() - tf2);
-#endif
-}
-
-template <int NB>
-__global__ __launch_bounds__(256) void k_solve_wave(DevProblem P, DevState S)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds_sw[];
-    if (S.ctrl->done) return;
-    PHASE_STAMP(tg0);
-    solve_gather<NB, 256>(P, S, lds_sw);
-    __syncthreads();
-    PHASE_STAMP(tg1);
-    if (threadIdx.x < 64) solve_factor_wave<NB>(P, S, lds_sw);
-#ifdef TSCM_PHASE_PROFILE
-    if (threadIdx.x == 0) printf("solve kernel: gather %lld  rest %lld [10 ns]\n", tg1 - tg0, wall_clock64() - tg1);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
 // Reduced camera system of rigs with more than kMaxCamLds cameras (up to kMaxCam: 410 free columns): the
 // compact system no longer fits registers + LDS, so ONE 1024-thread workgroup runs a blocked right-looking
 // Cholesky (16-column panels) on the matrix in global memory (S.Abig, L2-resident: <= 1.4 MB).  The right-hand

@@ -85,8 +85,7 @@ struct tscm_solver {
     Ctrl *h_ctrl = nullptr;             // pinned
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0, lds_gram = 0, lds_bs = 0;
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
-    int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras),
-                                        // 4 / 5: k_solve_wave<3> / <4> (up to 4 cameras: one wave, MFMA panels)
+    int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     // dominant-kernel timing
     int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel with HIP events
@@ -615,10 +614,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     {
         auto lds_doubles = [](size_t NN, size_t TT, size_t NPD) { return NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 2 * NN + 3 * NPD; };
         s->solve_variant = s->n_pad <= 64 ? 0 : s->n_pad > 16 * kMaxCamLds ? 3 : (P.n_act <= 100 ? 1 : 2);
-        if (s->n_pad <= 64 && !std::getenv("TSCM_SOLVE_BLOCKED")) s->solve_variant = P.n_act + 1 <= 48 ? 4 : 5;
         s->lds_solve = sizeof(double) * (s->solve_variant == 0 ? lds_doubles(64, 4, 64) : s->solve_variant == 1 ? lds_doubles(100, 4, 128) : lds_doubles(128, 4, 128));
-        if (s->solve_variant == 4) s->lds_solve = sizeof(double) * solve_wave_lds_doubles<3>();
-        if (s->solve_variant == 5) s->lds_solve = sizeof(double) * solve_wave_lds_doubles<4>();
         if (s->solve_variant == 3) {
             // rigs of 9..32 cameras: the compact system (+ rhs row) lives in global memory
             const int NN = (P.n_act + 15) & ~15;
@@ -791,9 +787,7 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        if (s->solve_variant == 4) hipLaunchKernelGGL(k_solve_wave<3>, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
-        else if (s->solve_variant == 5) hipLaunchKernelGGL(k_solve_wave<4>, dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
-        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+        if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
         else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
         else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
         else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
