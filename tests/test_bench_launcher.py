@@ -66,6 +66,20 @@ def test_bench_under_a_torchrun_style_environment():
         busy.close()
 
 
+def test_bench_under_the_real_torchrun():
+    """Exactly the driver's command line for N > 1: python -m torch.distributed.run ... bench.py --gpus N (torch only in the
+    launcher process; the ranks themselves never import it)."""
+    port = _free_port()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "10", "--warmup", "0"],
+                         env=_clean_env(TSCM_BENCH_STUB="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and 1.9 <= d["ms_per_step"] < 4.0
+
+
 def test_single_process_default_is_untouched():
     """No --gpus, no launcher environment: one process, no side channel."""
     out = subprocess.run([sys.executable, BENCH, "--steps", "5", "--warmup", "0"], env=_clean_env(TSCM_BENCH_STUB="1"),
