@@ -239,7 +239,8 @@ def test_lm_multi_config5_vs_oracle(hip_device):
     p = synth.make_config(5)
     assert p.n_cameras == 8 and p.n_corners == 8640000
     L = orc.lib()
-    L.orc_set_num_threads(min(int(L.orc_max_threads()), os.cpu_count() or 1, 64))
+    import bench
+    L.orc_set_num_threads(min(int(L.orc_max_threads()), bench._usable_cores(), 64))
     try:
         pg, po, gs, os_ = _solve_both(p)
     finally:
