@@ -10,11 +10,11 @@
 //                    the W region, the e-block factorisation and the board statistics only the E region.
 //                    double buffered: index ctrl->cur = system at x, cur^1 = candidate.
 //   H_stage          per camera a 16x16 tile [F | r]^T [F | r]  (13x13 Gram, col 13 =
-//                    F^T r, [13][13] = r^T r) + 8 scalars; fixed address so that RCCL can
-//                    all-reduce it without knowing the device-side buffer index.
-//   fac[B][56]       per-board e-block factor (k_schur_factor): forward-substitution multipliers L_ik / L_ii and
+//                    F^T r, [13][13] = r^T r) + 8 scalars + one gradient-max slot per rank; fixed address so that the
+//                    exchange back-end can all-reduce it without knowing the device-side buffer index.
+//   fac[B][56]       per-board e-block factor (k_schur_gram; k_schur_factor for boards seen by > 3 cameras): multipliers L_ik / L_ii and
 //                    s_i / L_ii, L itself for the back-substitution, 1 / L_ii, z = L^-1 S_b E^T r, the damping D^2.
-//                    Y = L^-1 S_b W is never stored: k_board_gram / k_backsub re-derive it from W (21 FMAs a column).
+//                    Y = L^-1 S_b W is never stored: k_schur_gram / k_backsub_prep re-derive it from W (21 FMAs a column).
 //   T[n_bids][256]   Schur complement sum_b Y_b^T Y_b, one 16x16 tile per camera pair that shares a board.
 // The LM control state (trust-region radius, accept/reject, termination, iteration log)
 // lives in `Ctrl` in device memory; every kernel starts with `if (ctrl->done) return`.
