@@ -119,11 +119,14 @@ class _StubSolver:
 
 
 def _kernel_src_sha() -> str:
-    """Identity of the hot kernel's sources: profiles/pmc_eval_gram.json records it with the traffic measurement."""
+    """Identity of the hot kernel's sources (comments and white space do not count): profiles/pmc_eval_gram.json
+    records it with the traffic measurement."""
+    import re
     h = hashlib.sha256()
     for f in ("tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h", "tscm_eval_f32.h"):
-        with open(os.path.join(ROOT, "tscm_calib_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "tscm_calib_amd", "csrc", f), "r") as fh:
+            code = re.sub(r"//[^\n]*", "", fh.read())
+            h.update(re.sub(r"\s+", "", code).encode())
     return h.hexdigest()[:16]
 
 

@@ -47,6 +47,7 @@ def main():
     doc = json.load(open(path))
     ev = next(v for k, v in kernels.items() if k.startswith("k_eval_gram"))
     n_corners = {4: 2160000}.get(config)
+    keep = {k: v for k, v in doc.get(f"config{config}", {}).items() if k.startswith("sq")}       # SQ counter blocks are recorded separately
     doc[f"config{config}"] = {
         "kernel_src_sha": sha, "round": 2,
         "FETCH_SIZE_KB_per_launch": ev["FETCH_SIZE_KB_per_launch"], "WRITE_SIZE_KB_per_launch": ev["WRITE_SIZE_KB_per_launch"],
@@ -55,6 +56,7 @@ def main():
         "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/pmc.sh), averaged over the k_eval_gram dispatches; "
                 "hbm = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes). Writes are the kernel's OUTPUT: 132 doubles per view of Schur records + per-workgroup camera tiles.",
     }
+    doc[f"config{config}"].update(keep)
     doc[f"config{config}_all_kernels_round2"] = {"kernel_src_sha": sha, "per_launch": kernels}
     json.dump(doc, open(path, "w"), indent=1)
     for k, v in kernels.items():
