@@ -777,10 +777,38 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
         }
         S.H_stage[256 * cam + t] = v;
     } else {
+        // the per-workgroup partials of the back-substitution (thousands of them): eight independent 16-byte loads in
+        // flight per thread -- as a plain loop every trip was a memory round trip (5 trips at config 4, 20 at config 5)
         double mb = 0.0, ss = 0.0;
-        if (have_backsub) for (int i = t; i < S.n_bs_blocks; i += 256) { mb += S.bs_part[2 * i]; ss += S.bs_part[2 * i + 1]; }
+        if (have_backsub) {
+            const d2 *bp = reinterpret_cast<const d2 *>(S.bs_part);
+            const int n = S.n_bs_blocks;
+            d2 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = d2{ 0.0, 0.0 };
+            int i = t;
+            for (; i + 7 * 256 < n; i += 8 * 256) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += bp[i + 256 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i + 256 * u < n) a[u] += bp[i + 256 * u];
+            const d2 r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            mb = r[0]; ss = r[1];
+        }
         double gm = 0.0, gs = 0.0, xs = 0.0;
-        for (int i = t; i < S.n_st_blocks; i += 256) { gm = fmax(gm, S.st_part[3 * i]); gs += S.st_part[3 * i + 1]; xs += S.st_part[3 * i + 2]; }
+        {
+            const int n = S.n_st_blocks;
+            double g4[4] = { 0, 0, 0, 0 }, s4[4] = { 0, 0, 0, 0 }, x4[4] = { 0, 0, 0, 0 };
+            int i = t;
+            for (; i + 3 * 256 < n; i += 4 * 256) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const double *q = S.st_part + 3 * (size_t)(i + 256 * u); g4[u] = fmax(g4[u], q[0]); s4[u] += q[1]; x4[u] += q[2]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + 256 * u < n) { const double *q = S.st_part + 3 * (size_t)(i + 256 * u); g4[u] = fmax(g4[u], q[0]); s4[u] += q[1]; x4[u] += q[2]; }
+            gm = fmax(fmax(g4[0], g4[1]), fmax(g4[2], g4[3])); gs = (s4[0] + s4[1]) + (s4[2] + s4[3]); xs = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+        }
         double red[4] = { mb, ss, gs, xs };
         block_reduce256<4>(red, gm, sm);
         mb = red[0]; ss = red[1]; gs = red[2]; xs = red[3];
@@ -2060,6 +2088,7 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
     const int tgt = init ? c.cur : (c.cur ^ 1);
     const int t = threadIdx.x;
     // publish the staged (all-reduced) camera tiles as the target system's H
+#pragma unroll 8
     for (int i = t; i < 256 * P.C; i += 256) S.H[tgt][i] = S.H_stage[i];
     const double *H = S.H_stage;
     const double *sc = S.H_stage + 256 * P.C;
