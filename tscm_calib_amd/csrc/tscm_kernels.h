@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 }
 
 // Back-substitution of the board steps (SchurEliminator::BackSubstitute) AND the per-view constants of the candidate
-// point (what k_view_prep computes for the initial point) in one launch.  A 128-thread workgroup owns kBsBoards
+// point (what k_view_prep computes for the initial point) in one launch.  A workgroup of NTH threads owns NTH / 8
 // consecutive boards, whose views are consecutive record slots.  Small workgroups on purpose: the kernel streams the W
 // region, a CU sustains ~20 GB/s of it, so the time is set by the CU with the most bytes -- thousands of small
 // workgroups spread evenly, a few hundred large ones leave CUs with one or with two of them (measured: 2.3 TB/s).
@@ -1851,16 +1851,23 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 //            R_c of the cameras are prepared by otherwise idle lanes
 //   phase C  one lane per view of these boards: board rotation columns, t_b and R_c dR_b/dw of the candidate, staged in
 //            LDS and written as 256-byte records (vconst, see k_view_prep); workgroup 0 also writes the per-camera records
-// grid ceil(B / kBsBoards) x 128, dynamic LDS kBsLds doubles
-constexpr int kBsBoards = 16;
-constexpr int kBsThreads = 128;
-constexpr int kBsRound = 32;       // slots per round of phase A: 32 * 84 doubles = exactly 21 per thread
+// grid ceil(B / (NTH / 8)) x NTH, dynamic LDS BsGeom<NTH>::kLds doubles
+// NTH threads own NTH / 8 boards; a round of phase A is 32 slots = 2688 doubles of W (21 per thread at 128 threads, 10.5
+// at 256: the last load of a thread is masked), the factor records are 7 doubles per thread.  Two geometries: 128
+// threads / 16 boards (thousands of small workgroups: balanced on mid-size problems) and 256 threads / 32 boards for
+// problems with more groups of 16 than fit the chip at once -- the serial phases B and C cost a workgroup the same ~5 us
+// whatever its size, so larger workgroups halve their share per board.
+constexpr int kBsRound = 32;       // slots per round of phase A
 constexpr int kBsTile = 64;        // views per round of phase C
-constexpr int kBsLdsA = kBsRound * kRecW + kBsRound * 6;
-constexpr int kBsLds = kBsTile * (kVFloatOff + 1) > kBsLdsA ? kBsTile * (kVFloatOff + 1) : kBsLdsA;
-static_assert(kBsRound * kRecW == 21 * kBsThreads, "a round of W records is 21 doubles per thread");
-static_assert(kBsBoards * kFac == 7 * kBsThreads, "the factor records are 7 doubles per thread");
-static_assert(kBsBoards * kFac <= kBsRound * kRecW, "the factor records re-use the W area");
+template <int NTH> struct BsGeom {
+    static constexpr int kBoards = NTH / 8;
+    static constexpr int kLoads = (kBsRound * kRecW + NTH - 1) / NTH;                 // W doubles per thread and round
+    static constexpr int kLdsA = kBsRound * kRecW + kBsRound * 6;
+    static constexpr int kLds = kBsTile * (kVFloatOff + 1) > kLdsA ? kBsTile * (kVFloatOff + 1) : kLdsA;     // dynamic LDS, doubles
+    static_assert(kBoards * kFac == 7 * NTH, "the factor records are 7 doubles per thread");
+    static_assert(kBoards * kFac <= kBsRound * kRecW, "the factor records re-use the W area");
+    static_assert(kBoards + kMaxCam <= NTH, "lane roles of phase B");
+};
 
 __device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m)
 {
@@ -1881,8 +1888,10 @@ __device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, 
     for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
 }
 
-__global__ __launch_bounds__(kBsThreads) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
 {
+    constexpr int kBsBoards = BsGeom<NTH>::kBoards, kBsThreads = NTH, kLoads = BsGeom<NTH>::kLoads;
     // head: control block and slot range in one round trip
     const int b0 = blockIdx.x * kBsBoards;
     const int nbl = min(kBsBoards, P.B - b0);
@@ -1921,31 +1930,31 @@ __global__ __launch_bounds__(kBsThreads) void k_backsub_prep(DevProblem P, DevSt
         const int grp = t >> 4, a = t & 15;
         const double *wsrc = S.rec[cur];
         const size_t w_end = (size_t)kRecW * max(s1, 1);               // first double behind this workgroup's records
-        double v[21];
+        double v[kLoads];
         int camv = 0;
         {
             const size_t base = (size_t)kRecW * s0;
 #pragma unroll
-            for (int j = 0; j < 21; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
+            for (int j = 0; j < kLoads; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
             camv = P.slot_cam[min(s0 + (t & 31), max(s1 - 1, 0))];
         }
         for (int rbase = s0; rbase < s1; rbase += kBsRound) {
             const int rend = min(s1, rbase + kBsRound);
             __syncthreads();                                            // the previous round is done with s_w / s_qv (and s_yh is there)
 #pragma unroll
-            for (int j = 0; j < 21; ++j) s_w[t + kBsThreads * j] = v[j];
+            for (int j = 0; j < kLoads; ++j) if (t + kBsThreads * j < kBsRound * kRecW) s_w[t + kBsThreads * j] = v[j];
             const int cam_l = camv;
             if (rbase + kBsRound < s1) {
                 // the next round's records are requested before this round computes
                 const size_t base = (size_t)kRecW * (rbase + kBsRound);
 #pragma unroll
-                for (int j = 0; j < 21; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
+                for (int j = 0; j < kLoads; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
                 camv = P.slot_cam[min(rbase + kBsRound + (t & 31), s1 - 1)];
             }
             __syncthreads();
 #pragma unroll
-            for (int pass = 0; pass < kBsRound / 8; ++pass) {
-                const int sl = 8 * pass + grp;                          // slot of the round; its camera sits in lane sl of every wave
+            for (int pass = 0; pass < kBsRound / (NTH / 16); ++pass) {
+                const int sl = (NTH / 16) * pass + grp;                          // slot of the round; its camera sits in lane sl of every wave
                 const int cam = __shfl(cam_l, sl);
                 const double yh = a < kFA ? s_yh[16 * cam + a] : 0.0;
                 double p[6];
@@ -2010,8 +2019,8 @@ __global__ __launch_bounds__(kBsThreads) void k_backsub_prep(DevProblem P, DevSt
                 s_new[t][k] = xn;
             }
         }
-    } else if (t >= 32 && t < 32 + P.C) {
-        const int m = t - 32;
+    } else if (t >= kBsBoards && t < kBsBoards + P.C) {
+        const int m = t - kBsBoards;
         double crt[3], Rc[9], dRc[27];
         for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[cur ^ 1][6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);

@@ -84,6 +84,7 @@ struct tscm_solver {
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0, lds_gram = 0, lds_bs = 0;
+    int bs_threads = 128;               // geometry of k_backsub_prep: 128 threads / 16 boards or 256 / 32
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
@@ -505,8 +506,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         }
         if (max_boards > kChunkBoards) return fail(TSCM_E_UNSUPPORTED, "internal error: board chunk larger than kChunkBoards");
         s->lds_gram = 0;
-        s->lds_bs = sizeof(double) * (size_t)kBsLds;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
+        // groups of 16 boards while they all fit the chip at once (5 workgroups per CU), groups of 32 beyond that
+        s->bs_threads = (B + 15) / 16 > 5 * std::max(1, prop.multiProcessorCount) * 3 / 2 ? 256 : 128;
+        s->lds_bs = sizeof(double) * (size_t)(s->bs_threads == 256 ? BsGeom<256>::kLds : BsGeom<128>::kLds);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
     }
     if ((rc = dev_upload(s, &P.pair_i, pair_i))) return rc;
     if ((rc = dev_upload(s, &P.pair_j, pair_j))) return rc;
@@ -596,9 +600,10 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
     if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
-    S.n_bs_blocks = (B + kBsBoards - 1) / kBsBoards;
+    S.n_bs_blocks = (B + 15) / 16;                  // (upper bound for the allocation; set to the geometry's group count below)
     S.n_st_blocks = (B + 255) / 256;
     if ((rc = dev_alloc(s, &S.bs_part, 2 * (size_t)S.n_bs_blocks))) return rc;
+    S.n_bs_blocks = (B + s->bs_threads / 8 - 1) / (s->bs_threads / 8);        // groups of k_backsub_prep's geometry
     if ((rc = dev_alloc(s, &S.st_part, 3 * (size_t)S.n_st_blocks))) return rc;
     if ((rc = dev_alloc(s, &S.ctrl, 1))) return rc;
     HIP_TRY(hipMemset(S.T, 0, sizeof(double) * 256 * (size_t)n_bids));
@@ -791,7 +796,8 @@ static int enqueue_iteration(LmRun &run)
         else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
         else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
         else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
-        if (S.n_bs_blocks) hipLaunchKernelGGL(k_backsub_prep, dim3(S.n_bs_blocks), dim3(kBsThreads), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
+        if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
+        if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
     }
     return enqueue_eval(run, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
