@@ -277,6 +277,10 @@ def main():
         comm = api.Comm(uid, rank, world, local_rank)
         solver.set_comm(comm)
         rccl_ranks = comm.backend_ranks()
+        # RCCL writes its version banner to the C stdout buffer at communicator creation; push it out now so that the
+        # JSON line stays the LAST line of this program's output
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     solver.upload_params()
 
     def barrier():
