@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
 CPU_BASELINE_ITERS = 8
-EVENT_STRIDE = 4
+EVENT_STRIDE = 8
 
 
 # ------------------------------------------------------------------------------------------------ launcher
