@@ -339,6 +339,10 @@ public:
         }
     }
 
+    // Several GPUs, one process per GPU (no counterpart in the reference): rank / world of this process and the
+    // communicator made from rank 0's tscm_comm_unique_id (tscm_comm_create).  calibrate() then shards the frames.
+    void set_sharding(int rank, int world, tscm_comm *comm) { rank_ = rank; world_ = world; comm_ = comm; }
+
     // multi_calib.cpp:155-283: joint LM, write-back (update_param), reprojection-error report
     void calibrate(const tscm_options *options = nullptr)
     {
@@ -363,7 +367,18 @@ public:
         P.cam_pose_constant = cc.data(); P.mono = 0;
         tscm_options o;
         if (options) o = *options; else tscm_default_options(&o, 0);
-        check(tscm_solve_multi(&P, &o, &summary));
+        if (world_ > 1) {
+            // frame-sharded over the ranks of set_sharding(): every rank builds this same problem, keeps the boards it owns
+            // and ends with ALL parameters updated (tscm.h, "multi-GPU")
+            tscm_solver *s = nullptr;
+            check(tscm_solver_create_sharded(&P, device_, rank_, world_, &s));
+            int rc = tscm_solver_set_comm(s, comm_);
+            if (rc == 0) rc = tscm_solver_solve(s, &o, &summary);
+            tscm_solver_destroy(s);
+            check(rc);
+        } else {
+            check(tscm_solve_multi(&P, &o, &summary));
+        }
         for (int m = 0; m < C; ++m) {                                    // :221-226
             cameras_[m].rt_.assign(&crt[6 * (size_t)m], &crt[6 * (size_t)m] + 6);
             cameras_[m].intrinsic_.assign(&I[9 * (size_t)m], &I[9 * (size_t)m] + 9);
@@ -395,6 +410,8 @@ public:
     std::vector<MultiCalib_camera> cameras_;
     std::vector<MultiCalib_chessboard> chessboards_;
     std::vector<Point3d> worlds_;
+    int rank_ = 0, world_ = 1;                // set_sharding()
+    tscm_comm *comm_ = nullptr;
     tscm_summary summary;                     // BriefReport data of the solve (:218)
     std::vector<double> camera_error;         // per-camera mean pixel error (:281)
     double mean_error;                        // "average reproject error" (:283)
