@@ -163,6 +163,7 @@ struct DevProblem {
     // presence mask (bit mi * 8 + mj) by a population count: kernel arguments only, no dependent table load.
     unsigned long long pair_mask;
     const short *bid_lut;              // [C*C] tile of block (mi, mj), mi <= mj; -1 = no board is seen by both
+    const int4 *solve_map;             // [kSolveMapSlots / 4][threads of k_solve_reduced] operand offsets of every thread (k_solve_map)
 };
 
 struct DevState {
@@ -1273,6 +1274,80 @@ __device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const
     if (i == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
 }
 
+// compact index of the reduced system -> padded column (-1 past the last free column), from kernel arguments only
+__device__ __forceinline__ int compact_to_padded(const DevProblem &P, int ci)
+{
+    int base = 0, c0 = P.cam_col0[0];
+#pragma unroll
+    for (int q = 1; q < kMaxCamLds; ++q) { const bool ge = ci >= P.cam_pre[q]; base = ge ? P.cam_pre[q] : base; c0 = ge ? P.cam_col0[q] : c0; }
+    return ci < P.n_act ? c0 + (ci - base) : -1;
+}
+// Tile of thread tid in k_solve_reduced's G x G grid (NP panels of free columns): lower tiles (ti, tj), and the
+// right-hand side tiles (NP, p) on the idle threads (0, p + 1).
+struct SolveTile { bool mine, rhsrow; int ri, cj; };
+template <int TS, int G>
+__device__ __forceinline__ SolveTile solve_tile(int tid, int NP)
+{
+    const int ti = tid / G, tj = tid % G;
+    SolveTile t;
+    t.mine = tj <= ti && ti < NP;
+    t.rhsrow = ti == 0 && tj >= 1 && tj <= NP;
+    t.ri = t.rhsrow ? NP : ti;
+    t.cj = t.rhsrow ? tj - 1 : tj;
+    return t;
+}
+// slots of the per-thread operand map (ints): offsets into H[cur] and T per tile element (-1: the element is 0),
+// s_c indices of the tile's rows and columns (-1: padding / rhs row, where 1 is used through kMapOne)
+constexpr int kMapH = 0, kMapT = 16, kMapSci = 32, kMapScj = 36, kSolveMapSlots = 40;
+constexpr int kMapOne = 1 << 30;       // "scaling 1": the row of a right-hand side tile
+
+// Operand map of k_solve_reduced<TS, G> (run once per solver: the map depends on the camera/pair structure only).
+// grid 1 x NT
+template <int TS, int G>
+__global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem P, int4 *map)
+{
+    static_assert(TS == 4, "the map holds 4 x 4 tiles");
+    constexpr int NT = (G * G + 63) / 64 * 64;
+    const int tid = threadIdx.x;
+    const int NP = (P.n_act + TS - 1) / TS;
+    const SolveTile tl = solve_tile<TS, G>(tid, NP);
+    auto cmap = [&](int ci) -> int { return compact_to_padded(P, ci); };
+    auto t_offset = [&](int i, int j) -> int {                  // as load_T_small
+        int lo = i >> 4, hi = j >> 4, a = i & 15, b = j & 15;
+        if (lo > hi) { const int t = lo; lo = hi; hi = t; const int u = a; a = b; b = u; }
+        const int bit = lo * 8 + hi;
+        const unsigned long long m = P.pair_mask;
+        return ((m >> bit) & 1ull) ? 256 * __popcll(m & ((1ull << bit) - 1ull)) + a * 16 + b : -1;
+    };
+    int off[kSolveMapSlots];
+    for (int q = 0; q < kSolveMapSlots; ++q) off[q] = -1;
+    if (tl.mine || tl.rhsrow) {
+        int mi[TS], mj[TS];
+        for (int r = 0; r < TS; ++r) { mi[r] = tl.mine ? cmap(tl.ri * TS + r) : -1; mj[r] = cmap(tl.cj * TS + r); }
+        for (int r = 0; r < TS; ++r) { off[kMapSci + r] = mi[r]; off[kMapScj + r] = mj[r]; }
+        if (tl.mine) {
+            for (int r = 0; r < TS; ++r)
+                for (int c = 0; c < TS; ++c) {
+                    const int i = mi[r], j = mj[c];
+                    if (i < 0 || j < 0) continue;
+                    if ((i >> 4) == (j >> 4)) off[kMapH + r * TS + c] = 256 * (i >> 4) + (i & 15) * 16 + (j & 15);
+                    off[kMapT + r * TS + c] = t_offset(i, j);
+                }
+        } else {
+            // right-hand side tile: row 0 = g - t_r of the panel's columns (the fused column kFR of H and T)
+            for (int c = 0; c < TS; ++c) {
+                const int j = mj[c];
+                if (j < 0) continue;
+                const int m = j >> 4, b = j & 15;
+                off[kMapH + c] = 256 * m + b * 16 + kFR;
+                off[kMapT + c] = t_offset(j, m * 16 + kFR);
+            }
+            off[kMapSci] = kMapOne;
+        }
+    }
+    for (int q = 0; q < kSolveMapSlots / 4; ++q) map[q * NT + tid] = make_int4(off[4 * q], off[4 * q + 1], off[4 * q + 2], off[4 * q + 3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reduced camera system (DenseSchurComplementSolver): one 256-thread workgroup.
 //   A = S_c (H_cc - T) S_c + D_c^2, rhs = S_c (g_c - t_r); inactive columns (tile padding,
@@ -1284,7 +1359,7 @@ __device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const
 // update -- 16 barriers in total.
 // Back-substitution: one wave, w in registers, rows of L streamed from LDS.  Writes
 // yhat = S_c y (camera step = -yhat) and the candidate camera parameters.
-// grid 1 x 256, dynamic LDS N*(N+1) + 2*N*TS + 2*TS*TS + 2*TS + 5*N doubles.
+// grid 1 x 256, dynamic LDS N*(N+2) + 2*G*(TS*TS+2) + 2*N + 3*NPD doubles.
 // ---------------------------------------------------------------------------------------------
 // G x G threads, thread (ti, tj) owns the TS x TS tile (ti, tj) of the COMPACT system (N = G * TS >= n_act columns);
 // NPD >= n_pad is the capacity of the arrays indexed by padded column
@@ -1294,15 +1369,15 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
     // control block and the static column tables are requested together (one memory round trip); the early
     // exit is taken once they are there
+    PHASE_STAMP(ts0);
     const int ctrl_done = S.ctrl->done;
     constexpr int N = G * TS;
-    constexpr int LD = N + 1;
+    constexpr int LD = N + 2;                       // even: the rows of a diagonal tile are read as 16-byte pairs
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Lm = lds;                 // [N][LD] lower factor (for the back-substitution)
-    double *Xb = Lm + N * LD;         // [2][N][TS] raw panel column (double-buffered)
-    double *Ld = Xb + 2 * N * TS;     // [2][TS][TS] inverse of the diagonal factor
-    double *wq = Ld + 2 * TS * TS;    // [2][TS] rhs slice of the panel
-    double *wp = wq + 2 * TS;         // [N] forward-substituted rhs  w = L^{-1} b
+    double *Lm = lds;                 // [N][LD] lower factor: the diagonal tiles as they are factored, the rest at the end
+    constexpr int XT = TS * TS + 2;   // tile stride of the panel column: 16 lanes tj read 16 tiles at once -- a stride of 16 doubles would put them on two bank pairs
+    double *Xb = Lm + N * LD;         // [2][G][XT] raw panel column, one TS x TS tile per row block (double-buffered)
+    double *wp = Xb + 2 * G * XT;     // [N] forward-substituted rhs  w = L^{-1} b
     double *idg = wp + N;             // [N] 1 / L_kk
     double *yv = idg + N;             // [NPD] solution by padded column
     double *s_sc = yv + NPD;          // [NPD]
@@ -1314,171 +1389,183 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     const int tid = threadIdx.x;
     const int ti = tid / G, tj = tid % G;
     const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
-    // compact index -> padded column (-1 past the last free column), from kernel arguments only
-    auto cmap = [&](int ci) -> int {
-        int base = 0, c0 = P.cam_col0[0];
+    // ---- operands of my tile (lower tiles only) -------------------------------------------------------
+    // The right-hand side rides along as tile row NP: row 0 of tile (NP, p) is the rhs slice of panel p (rows
+    // 1..TS-1 are zero), so the forward substitution w = L^{-1} b falls out of the panel solves and trailing
+    // updates and no thread treats it specially.  Those tiles live on the idle threads (0, p + 1) above the
+    // diagonal -- NOT in the last wave, which must stay free for the look-ahead thread.
+    // Where a thread's operands sit in H, T and s_c depends on the problem's structure only: k_solve_map wrote
+    // the offsets once, so the head of this kernel is two memory round trips (offsets + control block, then the
+    // operands) and next to no index arithmetic.
+    const SolveTile tl = solve_tile<TS, G>(tid, NP);
+    const bool mine = tl.mine, rhsrow = tl.rhsrow;
+    const int ri = tl.ri, cj = tl.cj;                                     // tile (row, column) of this thread
+    int off[kSolveMapSlots];
 #pragma unroll
-        for (int q = 1; q < kMaxCamLds; ++q) { const bool ge = ci >= P.cam_pre[q]; base = ge ? P.cam_pre[q] : base; c0 = ge ? P.cam_col0[q] : c0; }
-        return ci < P.n_act ? c0 + (ci - base) : -1;
-    };
-    // ---- operands of my tile (lower tiles only; the diagonal thread also owns its slice of the rhs) ----
-    // Every address below comes from kernel arguments, so the control block, the scalings, BOTH candidate H
-    // buffers (the current one is picked once the control block is here) and T travel in ONE memory round trip.
-    const bool mine = tj <= ti && ti < NP, diag = ti == tj && ti < NP;
-    int mi_[TS], mj_[TS];
-    double sci[TS], scj[TS], h0[TS][TS], h1[TS][TS], tt[TS][TS], g0[TS], g1[TS], tg[TS];
-#pragma unroll
-    for (int r = 0; r < TS; ++r) { mi_[r] = mine ? cmap(ti * TS + r) : -1; mj_[r] = mine ? cmap(tj * TS + r) : -1; }
-#pragma unroll
-    for (int r = 0; r < TS; ++r) { sci[r] = mi_[r] >= 0 ? S.s_c[mi_[r]] : 0.0; scj[r] = mj_[r] >= 0 ? S.s_c[mj_[r]] : 0.0; }
-#pragma unroll
-    for (int r = 0; r < TS; ++r) {
-#pragma unroll
-        for (int c = 0; c < TS; ++c) {
-            const int i = mi_[r], j = mj_[c];
-            h0[r][c] = 0.0; h1[r][c] = 0.0; tt[r][c] = 0.0;
-            if (i >= 0 && j >= 0) {
-                const int mi = i >> 4, ai = i & 15, mj = j >> 4, bj = j & 15;
-                if (mi == mj) { h0[r][c] = S.H[0][256 * mi + ai * 16 + bj]; h1[r][c] = S.H[1][256 * mi + ai * 16 + bj]; }
-                tt[r][c] = load_T_small(P, S.T, i, j);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < TS; ++r) {
-        const int i = diag ? mi_[r] : -1;
-        g0[r] = 0.0; g1[r] = 0.0; tg[r] = 0.0;
-        if (i >= 0) { const int mj = i >> 4, b = i & 15; g0[r] = S.H[0][256 * mj + b * 16 + kFR]; g1[r] = S.H[1][256 * mj + b * 16 + kFR]; tg[r] = load_T_small(P, S.T, i, mj * 16 + kFR); }
+    for (int q = 0; q < kSolveMapSlots / 4; ++q) {
+        const int4 v = P.solve_map[q * NT + tid];
+        off[4 * q] = v.x; off[4 * q + 1] = v.y; off[4 * q + 2] = v.z; off[4 * q + 3] = v.w;
     }
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
-    const double *H = S.H[cur];
     const int ctrl_fail = S.ctrl->lin_fail;
     for (int i = tid; i < NPD; i += NT) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; yv[i] = 0.0; }
     if (ctrl_done) return;
+    const double *H = S.H[cur];
+    double sci[TS], scj[TS], hh[TS][TS], tt[TS][TS];
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {
+        const int oi = off[kMapSci + r], oj = off[kMapScj + r];
+        sci[r] = oi == kMapOne ? 1.0 : oi >= 0 ? S.s_c[oi] : 0.0;
+        scj[r] = oj >= 0 ? S.s_c[oj] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < TS; ++r)
+#pragma unroll
+        for (int c = 0; c < TS; ++c) {
+            const int oh = off[kMapH + r * TS + c], ot = off[kMapT + r * TS + c];
+            hh[r][c] = oh >= 0 ? H[oh] : 0.0;
+            tt[r][c] = ot >= 0 ? S.T[ot] : 0.0;
+        }
+    PHASE_STAMP(ts0b);
     if (tid == 0) s_fail = ctrl_fail;
-    double a[TS][TS], bd[TS];
-    if (mine) {
+    double a[TS][TS];
+    const double inv_radius = 1.0 / radius;
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {
+#pragma unroll
+        for (int c = 0; c < TS; ++c) {
+            // matrix tiles: S_c (H - T) S_c, damped diagonal; identity on the padding columns.  rhs tiles: row 0 of
+            // the map holds (g, t_r) of the panel's columns, s_c of the ROW is stored as 1 there.
+            const bool dg = mine && ri == cj && r == c;
+            double v = sci[r] * scj[c] * (hh[r][c] - tt[r][c]);
+            if (dg) v = (off[kMapSci + r] >= 0 && off[kMapSci + r] != kMapOne) ? v + fmin(fmax(sci[r] * sci[r] * hh[r][c], dmin), dmax) * inv_radius : 1.0;
+            a[r][c] = v;
+        }
+    }
+    PHASE_STAMP(ts1);
+#ifdef TSCM_PHASE_PROFILE
+    const long long cy1 = clock64();
+#endif
+    // ---- factorisation: one barrier per panel, diagonal tiles factored one panel ahead ---------------------
+    // State at the top of step tk: L_kk (factor of diagonal tile tk) and 1 / diag are in Lm / idg; the tiles of
+    // column tk (rows below the diagonal, the rhs row among them), updated through panel tk-1, are in Ar; the
+    // diagonal tile tk+1, updated through panel tk-1, is in dt.
+    //   * trailing threads (ti > tk, tk <= tj <= ti): X_i = A_i L_kk^{-T} and X_j by forward substitution from the
+    //     raw tiles (every thread forms the two it needs itself: no second barrier), then A_ij -= X_i X_j^T; the
+    //     threads of column tk keep X_i -- their tile of L.  Column tk+1 and diagonal tile tk+2 are published for
+    //     the next step.
+    //   * one thread of the otherwise idle last wave applies panel tk's update to diagonal tile tk+1 alone and
+    //     factors it WHILE the others run the trailing update: the per-panel critical path is
+    //     max(factor, update) instead of their sum.
+    auto publish_tile = [&](double *dst, const double (&t)[TS][TS]) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int c = 0; c < TS; ++c) dst[r * TS + c] = t[r][c];
+    };
+    // Cholesky of the TS x TS tile t (lower part, in place); factor -> Lm, inverse diagonal -> idg
+    auto factor_diag = [&](double (&t)[TS][TS], int tk) {
+        double il[TS];
+#pragma unroll
+        for (int c = 0; c < TS; ++c) {
+            double d = t[c][c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) d -= t[c][q] * t[c][q];
+            if (!(d > 0.0)) { s_fail = 1; d = 1.0; }
+            const double isd = fast_rsqrt(d);
+            t[c][c] = d * isd; il[c] = isd;
+#pragma unroll
+            for (int r = c + 1; r < TS; ++r) {
+                double v = t[r][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= t[r][q] * t[c][q];
+                t[r][c] = v * isd;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < TS; ++r) {
+            idg[tk * TS + r] = il[r];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) Lm[(tk * TS + r) * LD + tk * TS + c] = c <= r ? t[r][c] : 0.0;
+        }
+    };
+    struct PanelFactor { double l[TS][TS], il[TS]; };
+    auto load_factor = [&](PanelFactor &f, int tk) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r) {
+            f.il[r] = idg[tk * TS + r];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) f.l[r][c] = Lm[(tk * TS + r) * LD + tk * TS + c];
+        }
+    };
+    // X = A L^{-T}:  x[r][c] = (A[r][c] - sum_{q < c} x[r][q] L[c][q]) / L[c][c]
+    auto panel_solve = [&](const double *At, const PanelFactor &f, double (&x)[TS][TS]) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
 #pragma unroll
             for (int c = 0; c < TS; ++c) {
-                const int ci = ti * TS + r, cj = tj * TS + c;
-                const int i = mi_[r], j = mj_[c];
-                double v = (ci == cj) ? 1.0 : 0.0;
-                if (i >= 0 && j >= 0) {
-                    const double h = cur ? h1[r][c] : h0[r][c];
-                    v = sci[r] * scj[c] * (h - tt[r][c]);
-                    if (i == j) v += fmin(fmax(sci[r] * sci[r] * h, dmin), dmax) / radius;
-                }
-                a[r][c] = v;
-            }
-        }
-    }
-    if (diag) {
+                double v = At[r * TS + c];
 #pragma unroll
-        for (int r = 0; r < TS; ++r) bd[r] = mi_[r] >= 0 ? sci[r] * ((cur ? g1[r] : g0[r]) - tg[r]) : 0.0;
-    }
-    // ---- factorisation: ONE barrier per panel ------------------------------------------------------
-    // before the barrier of panel tk: the column threads (ti > tk, tj == tk) publish their raw tiles,
-    // the diagonal thread factors its tile, inverts the 4x4 / 8x8 factor and forward-substitutes its
-    // rhs slice; after it every trailing thread forms X_i = A_i L_kk^{-T}, X_j itself and applies the
-    // rank-TS update (LDS buffers alternate between panels, so no second barrier is needed).
+                for (int q = 0; q < c; ++q) v -= x[r][q] * f.l[c][q];
+                x[r][c] = v * f.il[c];
+            }
+    };
+    __shared__ __attribute__((aligned(16))) double s_dt[2][TS * TS];
+    const bool dthread = tid == NT - 1;                     // no tile of its own: NP < G (host-checked)
+    if (cj == 0 && ri > 0 && (mine || rhsrow)) publish_tile(Xb + ri * XT, a);
+    if (ti == 1 && tj == 1 && mine) publish_tile(s_dt[0], a);
+    if (tid == 0) factor_diag(a, 0);
+    __syncthreads();
     for (int tk = 0; tk < NP; ++tk) {
-        double *Ar = Xb + (tk & 1) * (N * TS);          // raw panel column  [N][TS]
-        double *Li = Ld + (tk & 1) * (TS * TS);         // inverse of the diagonal factor (lower)
-        double *wk = wq + (tk & 1) * TS;                // w slice of the panel
-        if (tj == tk && ti > tk && ti < NP) {
+        const double *Ar = Xb + (tk & 1) * (G * XT);
+        double *ArN = Xb + ((tk + 1) & 1) * (G * XT);
+#ifdef TSCM_PHASE_PROFILE
+        __shared__ long long s_ph[8];
+        if (tk == 3 && (dthread || tid == 11 * G + 5)) s_ph[dthread ? 0 : 4] = wall_clock64();
+#endif
+        if (dthread && tk + 1 < NP) {
+            PanelFactor f;
+            load_factor(f, tk);
+            const double *dt = s_dt[tk & 1];
+            double x[TS][TS], t[TS][TS];
+            panel_solve(Ar + (tk + 1) * XT, f, x);
 #pragma unroll
             for (int r = 0; r < TS; ++r)
 #pragma unroll
-                for (int c = 0; c < TS; ++c) Ar[(ti * TS + r) * TS + c] = a[r][c];
-        }
-        if (ti == tk && tj == tk) {
-            double il[TS];
+                for (int c = 0; c <= r; ++c) {
+                    double v = dt[r * TS + c];
 #pragma unroll
-            for (int c = 0; c < TS; ++c) {
-                double d = a[c][c];
-#pragma unroll
-                for (int q = 0; q < c; ++q) d -= a[c][q] * a[c][q];
-                if (!(d > 0.0)) { s_fail = 1; d = 1.0; }
-                const double isd = fast_rsqrt(d);      // this thread is the critical path of the whole kernel
-                a[c][c] = d * isd; il[c] = isd;
-#pragma unroll
-                for (int r = c + 1; r < TS; ++r) {
-                    double v = a[r][c];
-#pragma unroll
-                    for (int q = 0; q < c; ++q) v -= a[r][q] * a[c][q];
-                    a[r][c] = v * isd;
+                    for (int q = 0; q < TS; ++q) v -= x[r][q] * x[c][q];
+                    t[r][c] = v;
                 }
-            }
-            // forward substitution of the rhs slice
-#pragma unroll
-            for (int c = 0; c < TS; ++c) {
-                double w = bd[c];
-#pragma unroll
-                for (int q = 0; q < c; ++q) w -= a[c][q] * bd[q];
-                bd[c] = w * il[c];
-                wk[c] = bd[c];
-                wp[tk * TS + c] = bd[c];
-                idg[tk * TS + c] = il[c];
-            }
-            // inverse of the lower-triangular factor, column by column
-            double inv[TS][TS];
-#pragma unroll
-            for (int c = 0; c < TS; ++c) {
-#pragma unroll
-                for (int r = 0; r < TS; ++r) {
-                    if (r < c) { inv[r][c] = 0.0; continue; }
-                    double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int q = c; q < r; ++q) v -= a[r][q] * inv[q][c];
-                    inv[r][c] = v * il[r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < TS; ++r)
-#pragma unroll
-                for (int c = 0; c < TS; ++c) Li[r * TS + c] = inv[r][c];
+#ifdef TSCM_PHASE_PROFILE
+            if (tk == 3) { asm volatile("" : "+v"(t[3][3])); s_ph[1] = wall_clock64(); }
+#endif
+            factor_diag(t, tk + 1);
+#ifdef TSCM_PHASE_PROFILE
+            if (tk == 3) s_ph[2] = wall_clock64();
+#endif
         }
-        __syncthreads();
-        if (ti > tk && ti < NP && tj >= tk && tj <= ti) {
-            // X_i = A_i L_kk^{-T}:  X[r][c] = sum_{q <= c} A[r][q] * inv[c][q]
+        if ((mine || rhsrow) && ri > tk && cj >= tk && !(ri == cj && ri == tk + 1)) {
+            PanelFactor f;
+            load_factor(f, tk);
             double xi[TS][TS];
-#pragma unroll
-            for (int r = 0; r < TS; ++r)
-#pragma unroll
-                for (int c = 0; c < TS; ++c) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int q = 0; q <= c; ++q) v += Ar[(ti * TS + r) * TS + q] * Li[c * TS + q];
-                    xi[r][c] = v;
-                }
-            if (tj == tk) {
-                // my tile IS the panel column: keep the final factor entries
+            panel_solve(Ar + ri * XT, f, xi);
+            if (cj == tk) {
+                // my tile IS the panel column: keep the final factor entries (rhs row: w of this panel)
 #pragma unroll
                 for (int r = 0; r < TS; ++r)
 #pragma unroll
                     for (int c = 0; c < TS; ++c) a[r][c] = xi[r][c];
+                if (rhsrow) {
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) wp[tk * TS + c] = xi[0][c];
+                }
             } else {
                 double xj[TS][TS];
-                if (ti == tj) {
-#pragma unroll
-                    for (int r = 0; r < TS; ++r)
-#pragma unroll
-                        for (int c = 0; c < TS; ++c) xj[r][c] = xi[r][c];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < TS; ++r)
-#pragma unroll
-                        for (int c = 0; c < TS; ++c) {
-                            double v = 0.0;
-#pragma unroll
-                            for (int q = 0; q <= c; ++q) v += Ar[(tj * TS + r) * TS + q] * Li[c * TS + q];
-                            xj[r][c] = v;
-                        }
-                }
+                panel_solve(Ar + cj * XT, f, xj);          // (diagonal tiles: the same operations as xi -- no divergent copy)
 #pragma unroll
                 for (int r = 0; r < TS; ++r)
 #pragma unroll
@@ -1488,26 +1575,33 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
                         for (int q = 0; q < TS; ++q) v -= xi[r][q] * xj[c][q];
                         a[r][c] = v;
                     }
-                if (ti == tj) {
-#pragma unroll
-                    for (int r = 0; r < TS; ++r) {
-                        double v = bd[r];
-#pragma unroll
-                        for (int q = 0; q < TS; ++q) v -= xi[r][q] * wk[q];
-                        bd[r] = v;
-                    }
-                }
             }
         }
+        {
+            // column tk+1 for the next step and diagonal tile tk+2 for the look-ahead thread: ONE store sequence
+            const bool col = cj == tk + 1 && ri > tk + 1 && (mine || rhsrow), dg = ti == tk + 2 && tj == tk + 2 && mine;
+            if (col || dg) publish_tile(col ? ArN + ri * XT : s_dt[(tk + 1) & 1], a);
+        }
+#ifdef TSCM_PHASE_PROFILE
+        if (tk == 3 && tid == 11 * G + 5) { asm volatile("" : "+v"(a[3][3])); s_ph[5] = wall_clock64(); }
+        if (tk + 1 < NP) __syncthreads();
+        if (tk == 3 && tid == 0) { s_ph[6] = wall_clock64(); printf("  panel 3: D x,t %lld  factor %lld | update %lld | to barrier exit %lld\n", s_ph[1] - s_ph[0], s_ph[2] - s_ph[1], s_ph[5] - s_ph[4], s_ph[6] - s_ph[0]); }
+#else
+        if (tk + 1 < NP) __syncthreads();
+#endif
     }
-    // ---- publish L, back-substitute L^T y = w with one wave -----------------------------------------
-    if (tj <= ti && ti < NP) {
+    // ---- publish L (the diagonal tiles are there already), back-substitute L^T y = w with one wave -----------
+    if (tj < ti && mine) {
 #pragma unroll
         for (int r = 0; r < TS; ++r)
 #pragma unroll
             for (int c = 0; c < TS; ++c) Lm[(ti * TS + r) * LD + tj * TS + c] = a[r][c];
     }
     __syncthreads();
+    PHASE_STAMP(ts2);
+#ifdef TSCM_PHASE_PROFILE
+    const long long cy2 = clock64();
+#endif
     TailOperands tail_ops;
     tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
     if (tid < 64) {
@@ -1550,10 +1644,14 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? cmap(tid + 64 * q) : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
+        for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? compact_to_padded(P, tid + 64 * q) : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
     }
     __syncthreads();
+    PHASE_STAMP(ts3);
     reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred);
+#ifdef TSCM_PHASE_PROFILE
+    if (tid == 0) printf("solve_reduced: ctrl %lld operands %lld  factor %lld (%lld shader clocks)  backsub %lld  tail %lld [10 ns]\n", ts0b - ts0, ts1 - ts0b, ts2 - ts1, cy2 - cy1, ts3 - ts2, wall_clock64() - ts3);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -614,11 +614,12 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
 
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = 4 * sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points);
-    // reduced solve on the compact system: 4 x 4 tiles on 16 x 16 threads (<= 64 free columns), 4 x 4 tiles on 25 x 25
-    // threads (<= 100, e.g. 8 cameras with one constant pose: 98) or 4 x 4 tiles on 32 x 32 threads (<= 128)
+    // reduced solve on the compact system, 4 x 4 tiles, one more tile row for the right-hand side: 16 x 16 threads
+    // (<= 4 cameras: at most 13 panels), 25 x 25 threads (<= 24 panels, e.g. 7 cameras with one constant pose: 85
+    // columns) or 32 x 32 threads (8 cameras: <= 104 columns, 26 panels)
     {
-        auto lds_doubles = [](size_t NN, size_t TT, size_t NPD) { return NN * (NN + 1) + 2 * NN * TT + 2 * TT * TT + 2 * TT + 2 * NN + 3 * NPD; };
-        s->solve_variant = s->n_pad <= 64 ? 0 : s->n_pad > 16 * kMaxCamLds ? 3 : (P.n_act <= 100 ? 1 : 2);
+        auto lds_doubles = [](size_t NN, size_t TT, size_t NPD) { return NN * (NN + 2) + 2 * (NN / TT) * (TT * TT + 2) + 2 * NN + 3 * NPD; };
+        s->solve_variant = s->n_pad <= 64 ? 0 : s->n_pad > 16 * kMaxCamLds ? 3 : (P.n_act <= 96 ? 1 : 2);
         s->lds_solve = sizeof(double) * (s->solve_variant == 0 ? lds_doubles(64, 4, 64) : s->solve_variant == 1 ? lds_doubles(100, 4, 128) : lds_doubles(128, 4, 128));
         if (s->solve_variant == 3) {
             // rigs of 9..32 cameras: the compact system (+ rhs row) lives in global memory
@@ -626,6 +627,17 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
             s->lds_solve = solve_big_lds_bytes(NN, s->n_pad);
             if ((rc = dev_alloc(s, &S.Abig, (size_t)256 * (NN / 16 + 1) * (NN / 16 + 2) / 2))) return rc;      // packed lower triangle of 16x16 blocks, incl. the rhs block row
         }
+    }
+    if (s->solve_variant <= 2) {
+        // where every thread of k_solve_reduced finds its operands (camera / pair structure only): written once
+        const int nt = s->solve_variant == 0 ? 256 : s->solve_variant == 1 ? 640 : 1024;
+        int4 *map = nullptr;
+        if ((rc = dev_alloc(s, &map, (size_t)(kSolveMapSlots / 4) * nt))) return rc;
+        if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_map<4, 16>), dim3(1), dim3(nt), 0, 0, P, map);
+        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_map<4, 25>), dim3(1), dim3(nt), 0, 0, P, map);
+        else hipLaunchKernelGGL((k_solve_map<4, 32>), dim3(1), dim3(nt), 0, 0, P, map);
+        HIP_TRY(hipGetLastError());
+        P.solve_map = map;
     }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     if (s->lds_solve > 64 * 1024) {
