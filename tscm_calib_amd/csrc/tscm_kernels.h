@@ -1282,23 +1282,31 @@ __device__ __forceinline__ int compact_to_padded(const DevProblem &P, int ci)
     for (int q = 1; q < kMaxCamLds; ++q) { const bool ge = ci >= P.cam_pre[q]; base = ge ? P.cam_pre[q] : base; c0 = ge ? P.cam_col0[q] : c0; }
     return ci < P.n_act ? c0 + (ci - base) : -1;
 }
-// Tile of thread tid in k_solve_reduced's G x G grid (NP panels of free columns): lower tiles (ti, tj), and the
-// right-hand side tiles (NP, p) on the idle threads (0, p + 1).
+// Tile of thread tid in k_solve_reduced's G x G grid (NP panels of free columns).  Lower tile (ti, tj) of the matrix on
+// thread ti * G + tj.  The right-hand side tiles (NP, p), p < NP, go to threads that own no matrix tile, counted
+// downwards from the end of the last wave that holds matrix tiles: tile p is needed up to panel step p, so the
+// longest-lived ones share a wave with the longest-lived matrix rows and the early waves retire early.  The
+// look-ahead thread (the last thread of the workgroup) is never used.
 struct SolveTile { bool mine, rhsrow; int ri, cj; };
 template <int TS, int G>
 __device__ __forceinline__ SolveTile solve_tile(int tid, int NP)
 {
-    const int ti = tid / G, tj = tid % G;
+    constexpr int NT = (G * G + 63) / 64 * 64;
+    auto owns = [&](int t) { const int ti = t / G, tj = t % G; return tj <= ti && ti < NP; };
     SolveTile t;
-    t.mine = tj <= ti && ti < NP;
-    t.rhsrow = ti == 0 && tj >= 1 && tj <= NP;
-    t.ri = t.rhsrow ? NP : ti;
-    t.cj = t.rhsrow ? tj - 1 : tj;
+    t.mine = owns(tid); t.rhsrow = false;
+    t.ri = tid / G; t.cj = tid % G;
+    if (t.mine || tid == NT - 1) return t;
+    const int last = min(NT - 2, ((NP - 1) * G + NP - 1) | 63);        // end of the wave of tile (NP-1, NP-1)
+    if (tid > last) return t;
+    int rank = 0;                                                       // free threads in (tid, last]
+    for (int u = tid + 1; u <= last; ++u) rank += owns(u) ? 0 : 1;
+    if (rank < NP) { t.rhsrow = true; t.ri = NP; t.cj = NP - 1 - rank; }
     return t;
 }
 // slots of the per-thread operand map (ints): offsets into H[cur] and T per tile element (-1: the element is 0),
 // s_c indices of the tile's rows and columns (-1: padding / rhs row, where 1 is used through kMapOne)
-constexpr int kMapH = 0, kMapT = 16, kMapSci = 32, kMapScj = 36, kSolveMapSlots = 40;
+constexpr int kMapH = 0, kMapT = 16, kMapSci = 32, kMapScj = 36, kMapTile = 40, kSolveMapSlots = 44;   // kMapTile: row, column, 1 = matrix tile / 2 = rhs tile
 constexpr int kMapOne = 1 << 30;       // "scaling 1": the row of a right-hand side tile
 
 // Operand map of k_solve_reduced<TS, G> (run once per solver: the map depends on the camera/pair structure only).
@@ -1321,6 +1329,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem
     };
     int off[kSolveMapSlots];
     for (int q = 0; q < kSolveMapSlots; ++q) off[q] = -1;
+    off[kMapTile] = tl.ri; off[kMapTile + 1] = tl.cj; off[kMapTile + 2] = tl.mine ? 1 : tl.rhsrow ? 2 : 0;
     if (tl.mine || tl.rhsrow) {
         int mi[TS], mj[TS];
         for (int r = 0; r < TS; ++r) { mi[r] = tl.mine ? cmap(tl.ri * TS + r) : -1; mj[r] = cmap(tl.cj * TS + r); }
@@ -1387,25 +1396,23 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     __shared__ double sred[256];
     const int n = P.n_pad;            // <= N
     const int tid = threadIdx.x;
-    const int ti = tid / G, tj = tid % G;
     const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
     // ---- operands of my tile (lower tiles only) -------------------------------------------------------
     // The right-hand side rides along as tile row NP: row 0 of tile (NP, p) is the rhs slice of panel p (rows
     // 1..TS-1 are zero), so the forward substitution w = L^{-1} b falls out of the panel solves and trailing
-    // updates and no thread treats it specially.  Those tiles live on the idle threads (0, p + 1) above the
-    // diagonal -- NOT in the last wave, which must stay free for the look-ahead thread.
+    // updates and no thread treats it specially.  Those tiles live on idle threads of the last wave that holds
+    // matrix tiles (k_solve_map): the fewer waves take part in a panel step, the less they queue at the LDS.
     // Where a thread's operands sit in H, T and s_c depends on the problem's structure only: k_solve_map wrote
     // the offsets once, so the head of this kernel is two memory round trips (offsets + control block, then the
     // operands) and next to no index arithmetic.
-    const SolveTile tl = solve_tile<TS, G>(tid, NP);
-    const bool mine = tl.mine, rhsrow = tl.rhsrow;
-    const int ri = tl.ri, cj = tl.cj;                                     // tile (row, column) of this thread
     int off[kSolveMapSlots];
 #pragma unroll
     for (int q = 0; q < kSolveMapSlots / 4; ++q) {
         const int4 v = P.solve_map[q * NT + tid];
         off[4 * q] = v.x; off[4 * q + 1] = v.y; off[4 * q + 2] = v.z; off[4 * q + 3] = v.w;
     }
+    const int ri = off[kMapTile], cj = off[kMapTile + 1];                // tile (row, column) of this thread
+    const bool mine = off[kMapTile + 2] == 1, rhsrow = off[kMapTile + 2] == 2;
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
@@ -1501,12 +1508,18 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         }
     };
     // X = A L^{-T}:  x[r][c] = (A[r][c] - sum_{q < c} x[r][q] L[c][q]) / L[c][c]
-    auto panel_solve = [&](const double *At, const PanelFactor &f, double (&x)[TS][TS]) {
+    auto load_tile = [&](const double *src, double (&t)[TS][TS]) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int c = 0; c < TS; ++c) t[r][c] = src[r * TS + c];
+    };
+    auto panel_solve = [&](const double (&At)[TS][TS], const PanelFactor &f, double (&x)[TS][TS]) {
 #pragma unroll
         for (int r = 0; r < TS; ++r)
 #pragma unroll
             for (int c = 0; c < TS; ++c) {
-                double v = At[r * TS + c];
+                double v = At[r][c];
 #pragma unroll
                 for (int q = 0; q < c; ++q) v -= x[r][q] * f.l[c][q];
                 x[r][c] = v * f.il[c];
@@ -1515,7 +1528,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     __shared__ __attribute__((aligned(16))) double s_dt[2][TS * TS];
     const bool dthread = tid == NT - 1;                     // no tile of its own: NP < G (host-checked)
     if (cj == 0 && ri > 0 && (mine || rhsrow)) publish_tile(Xb + ri * XT, a);
-    if (ti == 1 && tj == 1 && mine) publish_tile(s_dt[0], a);
+    if (ri == 1 && cj == 1 && mine) publish_tile(s_dt[0], a);
     if (tid == 0) factor_diag(a, 0);
     __syncthreads();
     for (int tk = 0; tk < NP; ++tk) {
@@ -1526,16 +1539,19 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         if (tk == 3 && (dthread || tid == 11 * G + 5)) s_ph[dthread ? 0 : 4] = wall_clock64();
 #endif
         if (dthread && tk + 1 < NP) {
+            // (all LDS operands requested before the first use: one exposed latency instead of one per group)
             PanelFactor f;
+            double araw[TS][TS], dt[TS][TS], x[TS][TS], t[TS][TS];
             load_factor(f, tk);
-            const double *dt = s_dt[tk & 1];
-            double x[TS][TS], t[TS][TS];
-            panel_solve(Ar + (tk + 1) * XT, f, x);
+            load_tile(Ar + (tk + 1) * XT, araw);
+            load_tile(s_dt[tk & 1], dt);
+            __builtin_amdgcn_sched_barrier(0);
+            panel_solve(araw, f, x);
 #pragma unroll
             for (int r = 0; r < TS; ++r)
 #pragma unroll
                 for (int c = 0; c <= r; ++c) {
-                    double v = dt[r * TS + c];
+                    double v = dt[r][c];
 #pragma unroll
                     for (int q = 0; q < TS; ++q) v -= x[r][q] * x[c][q];
                     t[r][c] = v;
@@ -1550,9 +1566,12 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         }
         if ((mine || rhsrow) && ri > tk && cj >= tk && !(ri == cj && ri == tk + 1)) {
             PanelFactor f;
+            double ai[TS][TS], aj[TS][TS], xi[TS][TS];
             load_factor(f, tk);
-            double xi[TS][TS];
-            panel_solve(Ar + ri * XT, f, xi);
+            load_tile(Ar + ri * XT, ai);
+            load_tile(Ar + cj * XT, aj);
+            __builtin_amdgcn_sched_barrier(0);
+            panel_solve(ai, f, xi);
             if (cj == tk) {
                 // my tile IS the panel column: keep the final factor entries (rhs row: w of this panel)
 #pragma unroll
@@ -1565,7 +1584,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
                 }
             } else {
                 double xj[TS][TS];
-                panel_solve(Ar + cj * XT, f, xj);          // (diagonal tiles: the same operations as xi -- no divergent copy)
+                panel_solve(aj, f, xj);                    // (diagonal tiles: the same operations as xi -- no divergent copy)
 #pragma unroll
                 for (int r = 0; r < TS; ++r)
 #pragma unroll
@@ -1579,7 +1598,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         }
         {
             // column tk+1 for the next step and diagonal tile tk+2 for the look-ahead thread: ONE store sequence
-            const bool col = cj == tk + 1 && ri > tk + 1 && (mine || rhsrow), dg = ti == tk + 2 && tj == tk + 2 && mine;
+            const bool col = cj == tk + 1 && ri > tk + 1 && (mine || rhsrow), dg = ri == tk + 2 && cj == tk + 2 && mine;
             if (col || dg) publish_tile(col ? ArN + ri * XT : s_dt[(tk + 1) & 1], a);
         }
 #ifdef TSCM_PHASE_PROFILE
@@ -1591,11 +1610,11 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
 #endif
     }
     // ---- publish L (the diagonal tiles are there already), back-substitute L^T y = w with one wave -----------
-    if (tj < ti && mine) {
+    if (cj < ri && mine) {
 #pragma unroll
         for (int r = 0; r < TS; ++r)
 #pragma unroll
-            for (int c = 0; c < TS; ++c) Lm[(ti * TS + r) * LD + tj * TS + c] = a[r][c];
+            for (int c = 0; c < TS; ++c) Lm[(ri * TS + r) * LD + cj * TS + c] = a[r][c];
     }
     __syncthreads();
     PHASE_STAMP(ts2);
