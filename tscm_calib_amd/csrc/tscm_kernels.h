@@ -1164,39 +1164,48 @@ __global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
     S.pairpart[(size_t)256 * P.pc_tile[pc] + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-// grid (n_bids * 4) x 256: block (bid, quarter) sums 64 entries of the partial tiles that belong to
-// one camera-pair block, the tile list split four ways across the threads of an entry
-__global__ __launch_bounds__(256) void k_T_reduce(DevProblem P, DevState S)
+// grid (n_bids * 256 / kTEntries) x 1024: block (bid, part) sums kTEntries entries of the partial tiles that belong
+// to one camera-pair block, the tile list split kTSlices ways across the threads of an entry (the kernel is a chain
+// of memory round trips: the more of the list is in flight at once, the shorter it is)
+constexpr int kTEntries = 64, kTSlices = 16;
+__global__ __launch_bounds__(kTEntries * kTSlices) void k_T_reduce(DevProblem P, DevState S)
 {
     if (S.ctrl->done) return;
-    __shared__ double red[4][64];
-    const int bid = blockIdx.x >> 2, quarter = blockIdx.x & 3;
-    const int e = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int entry = quarter * 64 + e;
+    __shared__ double red[kTSlices][kTEntries];
+    constexpr int kParts = 256 / kTEntries;
+    const int bid = blockIdx.x / kParts, part = blockIdx.x % kParts;
+    const int e = threadIdx.x % kTEntries, slice = threadIdx.x / kTEntries;
+    const int entry = part * kTEntries + e;
     const int cb = P.bid_part_ptr[bid], ce = P.bid_part_ptr[bid + 1];
-    const int per = (ce - cb + 3) >> 2;
+    const int per = (ce - cb + kTSlices - 1) / kTSlices;
     const int b0 = cb + slice * per, b1 = min(ce, b0 + per);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
-    int c = b0;
     // the partial tiles of one block are stored contiguously: [bid_part_ptr[bid], bid_part_ptr[bid+1]);
-    // eight loads in flight per thread (mono problems: one block, hundreds of partial tiles -> a latency chain)
+    // eight loads in flight per thread, the ragged end included (no dependent tail loop)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     const double *src = S.pairpart + entry;
-    for (; c + 7 < b1; c += 8) {
-        a0 += src[(size_t)256 * c];       a1 += src[(size_t)256 * (c + 1)];
-        a2 += src[(size_t)256 * (c + 2)]; a3 += src[(size_t)256 * (c + 3)];
-        a4 += src[(size_t)256 * (c + 4)]; a5 += src[(size_t)256 * (c + 5)];
-        a6 += src[(size_t)256 * (c + 6)]; a7 += src[(size_t)256 * (c + 7)];
+    for (int c = b0; c < b1; c += 8) {
+        const double v0 = src[(size_t)256 * c];
+        const double v1 = c + 1 < b1 ? src[(size_t)256 * (c + 1)] : 0.0;
+        const double v2 = c + 2 < b1 ? src[(size_t)256 * (c + 2)] : 0.0;
+        const double v3 = c + 3 < b1 ? src[(size_t)256 * (c + 3)] : 0.0;
+        const double v4 = c + 4 < b1 ? src[(size_t)256 * (c + 4)] : 0.0;
+        const double v5 = c + 5 < b1 ? src[(size_t)256 * (c + 5)] : 0.0;
+        const double v6 = c + 6 < b1 ? src[(size_t)256 * (c + 6)] : 0.0;
+        const double v7 = c + 7 < b1 ? src[(size_t)256 * (c + 7)] : 0.0;
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6; a7 += v7;
     }
-    for (; c + 1 < b1; c += 2) {
-        a0 += src[(size_t)256 * c];
-        a1 += src[(size_t)256 * (c + 1)];
-    }
-    if (c < b1) a0 += src[(size_t)256 * c];
     red[slice][e] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     __syncthreads();
     if (slice == 0) {
         // tiles without a local partial (the pair is only seen on other ranks) are written as zeros
-        S.T[(size_t)256 * bid + entry] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        double v[kTSlices];
+#pragma unroll
+        for (int q = 0; q < kTSlices; ++q) v[q] = red[q][e];
+#pragma unroll
+        for (int w = kTSlices / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int q = 0; q < w; ++q) v[q] += v[q + w];
+        S.T[(size_t)256 * bid + entry] = v[0];
     }
 }
 

@@ -798,7 +798,7 @@ static int enqueue_iteration(LmRun &run)
         if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2]);
         if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3]);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
-        if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * 4), dim3(256), 0, s->stream, P, S);
+        if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
     if (int rc = exchange(run, /*t_buffer=*/true)) return rc;
     for (tscm_solver *s : run.m) {
