@@ -356,6 +356,22 @@ def test_eight_camera_rig(hip_device):
     assert np.max(np.abs(g["cam_gram"] - o["cam_gram"])) <= 1e-11 * np.abs(o["cam_gram"]).max()
 
 
+@pytest.mark.parametrize("C,free_gauge", [(2, False), (3, False), (4, True), (5, False), (6, False), (7, False), (7, True), (8, True)])
+def test_reduced_solver_geometries(hip_device, C, free_gauge):
+    """Every shape of the blocked reduced solve: 16 x 16 threads up to 13 panels (4 cameras, no constant pose: the last
+    panel row shares a wave with the look-ahead thread), 25 x 25 up to 24 panels (5-7 cameras), 32 x 32 above
+    (7 cameras with every pose free: 91 columns -> 23 panels still 25 x 25; 8 cameras: 98 / 104 columns).  With no
+    constant camera pose the system has a gauge freedom that only the LM damping removes (Ceres accepts that too)."""
+    p = synth.make_problem(C, 8, 40 + C)
+    if free_gauge:
+        p.cam_pose_constant[:] = 0
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_, rtol=1e-5 if free_gauge else 1e-6)
+    assert abs(gs["final_cost"] - os_["final_cost"]) <= 1e-5 * os_["final_cost"]
+    if not free_gauge:
+        assert max(H.param_rel_err(pg, po).values()) < 1e-6
+
+
 def test_rccl_code_path_single_rank(hip_device, monkeypatch):
     """The multi-GPU code path (RCCL all-reduce of T, grouped sum/max all-reduce of the staged camera
     tiles, separate k_control) on a one-rank communicator: must reproduce the single-GPU path bit for bit."""
