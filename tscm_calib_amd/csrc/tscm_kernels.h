@@ -638,15 +638,41 @@ __device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int bl
     S.campart2[(size_t)512 * blk + 256 + t] = (b0 + b1) + (b2 + b3);
 }
 
+// All-reduce over the 16 lanes of a DPP row without the LDS crossbar: a butterfly of quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror and row_mirror (after the first two steps every lane of a quad holds the quad's value, so
+// the mirrored partner is as good as the xor partner).  A VALU move per 32-bit half and step, a few clocks of latency
+// each, against ~100 ns per ds_bpermute round trip of __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_allsum(double v)
+{
+    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double row16_allmax(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+    return v;
+}
+
 // deterministic block reductions (256 threads)
-// Block reductions (256 threads; any multiple of 64 works): xor-shuffle tree inside each wave, one LDS exchange between the
+// Block reductions (256 threads; any multiple of 64 works): DPP butterfly inside each 16-lane row, two xor shuffles across the
+// rows of a wave, one LDS exchange between the
 // waves -- two barriers per call, several quantities at once (the previous LDS tree cost ten barriers per
 // quantity: 1.5 us each on the single-block control paths).  Fixed order: bit-reproducible.
 template <int NS>
 __device__ __forceinline__ void block_reduce256(double (&sum)[NS], double &mx, double *sm)   // sm: >= 4 * (NS + 1) doubles
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int i = 0; i < NS; ++i) sum[i] = row16_allsum(sum[i]);
+    mx = row16_allmax(mx);
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) sum[i] += __shfl_xor(sum[i], off);
         mx = fmax(mx, __shfl_xor(mx, off));
@@ -2087,8 +2113,7 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     p[k] = (a < kFA ? s_w[kRecW * sl + 14 * k + a] : 0.0) * yh;
-                    p[k] += __shfl_xor(p[k], 1, 16); p[k] += __shfl_xor(p[k], 2, 16);
-                    p[k] += __shfl_xor(p[k], 4, 16); p[k] += __shfl_xor(p[k], 8, 16);
+                    p[k] = row16_allsum(p[k]);
                 }
                 if (a == 0) {
 #pragma unroll
