@@ -356,7 +356,7 @@ def test_eight_camera_rig(hip_device):
     assert np.max(np.abs(g["cam_gram"] - o["cam_gram"])) <= 1e-11 * np.abs(o["cam_gram"]).max()
 
 
-@pytest.mark.parametrize("C,free_gauge", [(2, False), (3, False), (4, True), (5, False), (6, False), (7, False), (7, True), (8, True)])
+@pytest.mark.parametrize("C,free_gauge", [(2, False), (3, False), (4, True), (5, False), (6, False), (7, False), (7, True), (8, False), (8, True)])
 def test_reduced_solver_geometries(hip_device, C, free_gauge):
     """Every shape of the blocked reduced solve: 16 x 16 threads up to 13 panels (4 cameras, no constant pose: the last
     panel row shares a wave with the look-ahead thread), 25 x 25 up to 24 panels (5-7 cameras), 32 x 32 above
