@@ -44,6 +44,7 @@ constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 do
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
 constexpr int kCamG1 = 16;         // first-level fan-in of the per-camera tile reduction
+constexpr int kSmallBids = 10;     // camera-pair blocks of a rig of <= 4 cameras: their partial-tile ranges travel as kernel arguments
 constexpr int kMaxCamLds = 8;      // n_pad = 16*C <= 128: reduced system solved in registers/LDS (k_solve_reduced)
 constexpr int kMaxCam = 32;        // larger rigs: k_solve_reduced_big factors the system in global memory (n_pad <= 512)
 constexpr int kMaxLog = 256;
@@ -163,6 +164,7 @@ struct DevProblem {
     // presence mask (bit mi * 8 + mj) by a population count: kernel arguments only, no dependent table load.
     unsigned long long pair_mask;
     const short *bid_lut;              // [C*C] tile of block (mi, mj), mi <= mj; -1 = no board is seen by both
+    int bid_part_small[kSmallBids + 1]; // bid_part_ptr by value when n_bids <= kSmallBids (no memory round trip in front of the partial tiles)
     const int4 *solve_map;             // [kSolveMapSlots / 4][threads of k_solve_reduced] operand offsets of every thread (k_solve_map)
 };
 
@@ -176,6 +178,7 @@ struct DevState {
     double *s_b, *s_c;
     double *fac;                       // [B][kFac] e-block factors
     double *pairpart, *T;
+    int *t_count;                      // arrival counter of the fused T reduction + reduced solve (k_solve_reduced<..., true>)
     double *yhat;
     double *Abig;                      // compact reduced system + rhs row in 16x16 blocks, rigs of more than kMaxCamLds cameras only
     double *bs_part, *st_part;
@@ -1190,23 +1193,18 @@ __global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
     S.pairpart[(size_t)256 * P.pc_tile[pc] + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-// grid (n_bids * 256 / kTEntries) x 1024: block (bid, part) sums kTEntries entries of the partial tiles that belong
-// to one camera-pair block, the tile list split kTSlices ways across the threads of an entry (the kernel is a chain
-// of memory round trips: the more of the list is in flight at once, the shorter it is)
 constexpr int kTEntries = 64, kTSlices = 16;
-__global__ __launch_bounds__(kTEntries * kTSlices) void k_T_reduce(DevProblem P, DevState S)
+// block blk of a (n_bids * 256 / ENTRIES)-block grid of ENTRIES * kTSlices threads, partial tiles [cb, ce) of its
+// camera-pair block; the summation order of an entry depends on kTSlices only, so every geometry produces the same bits
+template <int ENTRIES>
+__device__ __forceinline__ void t_reduce_block(const DevState &S, int bid, int part, int cb, int ce, double (*red)[ENTRIES])
 {
-    if (S.ctrl->done) return;
-    __shared__ double red[kTSlices][kTEntries];
-    constexpr int kParts = 256 / kTEntries;
-    const int bid = blockIdx.x / kParts, part = blockIdx.x % kParts;
-    const int e = threadIdx.x % kTEntries, slice = threadIdx.x / kTEntries;
-    const int entry = part * kTEntries + e;
-    const int cb = P.bid_part_ptr[bid], ce = P.bid_part_ptr[bid + 1];
+    const int e = threadIdx.x % ENTRIES, slice = threadIdx.x / ENTRIES;
+    const int entry = part * ENTRIES + e;
     const int per = (ce - cb + kTSlices - 1) / kTSlices;
     const int b0 = cb + slice * per, b1 = min(ce, b0 + per);
-    // the partial tiles of one block are stored contiguously: [bid_part_ptr[bid], bid_part_ptr[bid+1]);
-    // eight loads in flight per thread, the ragged end included (no dependent tail loop)
+    // the partial tiles of one block are stored contiguously; eight loads in flight per thread, the ragged end
+    // included (no dependent tail loop)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     const double *src = S.pairpart + entry;
     for (int c = b0; c < b1; c += 8) {
@@ -1233,6 +1231,17 @@ __global__ __launch_bounds__(kTEntries * kTSlices) void k_T_reduce(DevProblem P,
             for (int q = 0; q < w; ++q) v[q] += v[q + w];
         S.T[(size_t)256 * bid + entry] = v[0];
     }
+}
+// grid (n_bids * 256 / kTEntries) x 1024: block (bid, part) sums kTEntries entries of the partial tiles that belong to
+// one camera-pair block, the tile list split kTSlices ways across the threads of an entry (the kernel is a chain of
+// memory round trips: the more of the list is in flight at once, the shorter it is)
+__global__ __launch_bounds__(kTEntries * kTSlices) void k_T_reduce(DevProblem P, DevState S)
+{
+    if (S.ctrl->done) return;
+    __shared__ double red[kTSlices][kTEntries];
+    constexpr int kParts = 256 / kTEntries;
+    const int bid = blockIdx.x / kParts;
+    t_reduce_block<kTEntries>(S, bid, blockIdx.x % kParts, P.bid_part_ptr[bid], P.bid_part_ptr[bid + 1], red);
 }
 
 // T(i, j) for padded columns i, j of the camera side; the lower blocks are the transposed upper ones
@@ -1407,10 +1416,35 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem
 // ---------------------------------------------------------------------------------------------
 // G x G threads, thread (ti, tj) owns the TS x TS tile (ti, tj) of the COMPACT system (N = G * TS >= n_act columns);
 // NPD >= n_pad is the capacity of the arrays indexed by padded column
-template <int TS, int G = 16, int NPD = 64>
+// FUSED (256-thread variant, one GPU): the launch carries the T reduction as workgroups 1 .. n_bids * 256 / kFusedEntries;
+// workgroup 0 is the solver and waits for their tiles behind an arrival counter (release -> counter -> acquire) after it
+// has requested everything else.  Unlike the producers of the earlier hand-off experiments these have written 20 KB, not
+// megabytes, when they release -- and a launch with its 5 us is gone.
+constexpr int kFusedEntries = 256 / kTSlices;        // 16 entries x 16 slices = the solver's 256 threads
+constexpr int kSpinMax = 1 << 16;                   // x ~64 ns: a hand-off that has not come by then fails the step instead of hanging
+template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
 __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S)
 {
     constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
+    if constexpr (FUSED) {
+        static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
+        if (blockIdx.x > 0) {
+            constexpr int kParts = 256 / kFusedEntries;
+            const int bid = ((int)blockIdx.x - 1) / kParts, part = ((int)blockIdx.x - 1) % kParts;
+            const int cb = P.bid_part_small[bid], ce = P.bid_part_small[bid + 1];      // kernel arguments: the partial tiles are the first thing requested
+            if (S.ctrl->done) return;
+            __shared__ double red[kTSlices][kFusedEntries];
+            t_reduce_block<kFusedEntries>(S, bid, part, cb, ce, red);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(S.t_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
     // control block and the static column tables are requested together (one memory round trip); the early
     // exit is taken once they are there
     PHASE_STAMP(ts0);
@@ -1465,13 +1499,26 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
 #pragma unroll
     for (int r = 0; r < TS; ++r)
 #pragma unroll
-        for (int c = 0; c < TS; ++c) {
-            const int oh = off[kMapH + r * TS + c], ot = off[kMapT + r * TS + c];
-            hh[r][c] = oh >= 0 ? H[oh] : 0.0;
-            tt[r][c] = ot >= 0 ? S.T[ot] : 0.0;
+        for (int c = 0; c < TS; ++c) { const int oh = off[kMapH + r * TS + c]; hh[r][c] = oh >= 0 ? H[oh] : 0.0; }
+    int t_late = 0;
+    if constexpr (FUSED) {
+        // everything that does not depend on T is in flight; now the tiles of the other workgroups
+        if (tid == 0) {
+            const int need = (int)gridDim.x - 1;
+            int spins = 0;
+            while (__hip_atomic_load(S.t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spins < kSpinMax) { __builtin_amdgcn_s_sleep(2); ++spins; }
+            t_late = spins >= kSpinMax;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(S.t_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < TS; ++r)
+#pragma unroll
+        for (int c = 0; c < TS; ++c) { const int ot = off[kMapT + r * TS + c]; tt[r][c] = ot >= 0 ? S.T[ot] : 0.0; }
     PHASE_STAMP(ts0b);
-    if (tid == 0) s_fail = ctrl_fail;
+    if (tid == 0) s_fail = ctrl_fail | t_late;
     double a[TS][TS];
     const double inv_radius = 1.0 / radius;
 #pragma unroll

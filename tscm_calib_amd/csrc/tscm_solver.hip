@@ -86,6 +86,7 @@ struct tscm_solver {
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0, lds_gram = 0, lds_bs = 0;
     int bs_threads = 128;               // geometry of k_backsub_prep: 128 threads / 16 boards or 256 / 32
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
+    bool fuse_reduce = true;            // TSCM_NO_FUSED_REDUCE=1 (read at creation) keeps k_T_reduce a launch of its own
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     // dominant-kernel timing
@@ -518,6 +519,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.pc_end, pc_end))) return rc;
     if ((rc = dev_upload(s, &P.pc_tile, pc_tile))) return rc;
     if ((rc = dev_upload(s, &P.bid_part_ptr, bid_part_ptr))) return rc;
+    for (int b = 0; b <= kSmallBids; ++b) P.bid_part_small[b] = bid_part_ptr[std::min(b, n_bids)];
     if ((rc = dev_upload(s, &P.sslot, sslot))) return rc;
     if ((rc = dev_upload(s, &P.sboard, sboard))) return rc;
     if ((rc = dev_upload(s, &P.pair_board, pair_board))) return rc;
@@ -599,6 +601,9 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.fac, (size_t)kFac * B))) return rc;
     if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
     if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
+    s->fuse_reduce = getenv("TSCM_NO_FUSED_REDUCE") == nullptr;
+    if ((rc = dev_alloc(s, &S.t_count, 1))) return rc;
+    HIP_TRY(hipMemset(S.t_count, 0, sizeof(int)));
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
     S.n_bs_blocks = (B + 15) / 16;                  // (upper bound for the allocation; set to the geometry's group count below)
     S.n_st_blocks = (B + 255) / 256;
@@ -788,6 +793,10 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
     return 0;
 }
 
+// one GPU, reduced system of at most 64 columns: the T reduction rides in the reduced solve's launch (k_solve_reduced<..., true>);
+// with a communicator the all-reduce of T sits between the two
+static bool fused_reduce(const tscm_solver *s) { return s->fuse_reduce && s->solve_variant == 0 && !s->comm && s->P.n_bids > 0 && s->P.n_bids <= kSmallBids; }
+
 static int enqueue_iteration(LmRun &run)
 {
     for (tscm_solver *s : run.m) {
@@ -798,13 +807,14 @@ static int enqueue_iteration(LmRun &run)
         if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2]);
         if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3]);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
-        if (P.n_bids) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
+        if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
     if (int rc = exchange(run, /*t_buffer=*/true)) return rc;
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
+        if (fused_reduce(s)) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + P.n_bids * (256 / kFusedEntries)), dim3(256), s->lds_solve, s->stream, P, S);
+        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
         else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
         else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
         else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
