@@ -391,6 +391,23 @@ def test_rccl_code_path_single_rank(hip_device, monkeypatch):
     assert np.array_equal(q.intr, ref.intr) and np.array_equal(q.cam_rt, ref.cam_rt) and np.array_equal(q.board_rt, ref.board_rt)
 
 
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_fused_and_separate_T_reduction_agree_bit_for_bit(hip_device, monkeypatch, cfg):
+    """One GPU, <= 4 cameras: the T reduction rides in the reduced solve's launch (workgroups behind an arrival counter).
+    TSCM_NO_FUSED_REDUCE=1 at solver creation keeps it a launch of its own (the path every communicator run takes);
+    the summation order of a tile entry is the same in both, so the whole solve must be."""
+    p = synth.make_config(cfg)
+    a, b = p.copy().normalised(), p.copy().normalised()
+    with api.Solver(a) as s:
+        sa = s.solve()
+    monkeypatch.setenv("TSCM_NO_FUSED_REDUCE", "1")
+    with api.Solver(b) as s:
+        sb = s.solve()
+    assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+    assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
+    assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
 def test_invalid_arguments(hip_device):
     from tscm_calib_amd.lib import TscmError
     p = H.small_rig(4, 4, seed=1)
