@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem
 // has requested everything else.  Unlike the producers of the earlier hand-off experiments these have written 20 KB, not
 // megabytes, when they release -- and a launch with its 5 us is gone.
 constexpr int kFusedEntries = 256 / kTSlices;        // 16 entries x 16 slices = the solver's 256 threads
-constexpr int kSpinMax = 1 << 16;                   // x ~64 ns: a hand-off that has not come by then fails the step instead of hanging
+constexpr int kSpinMax = 1 << 24;                   // x ~64 ns = a second: only a hand-off that never comes fails the step (instead of hanging the stream)
 template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
 __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S)
 {
