@@ -9,3 +9,5 @@ python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])): print(f"{r['Name'][:40]:42s} {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us  {r['Percentage']}%")
 PY
+# medians from the trace (the means above include the early-exit launches after ctrl->done)
+python3 $GRAFT_REPO_ROOT/tools/kernel_medians.py $GRAFT_REPO_ROOT/gpurun_out/prof_$tag $GRAFT_REPO_ROOT/gpurun_out/${tag}_kernel_medians.csv
