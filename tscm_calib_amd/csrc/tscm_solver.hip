@@ -912,6 +912,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         h->opt.max_invalid = opt.max_num_consecutive_invalid_steps;
         h->opt.jacobi_scaling = opt.jacobi_scaling;
         HIP_TRY(hipMemcpyAsync(S.ctrl, h, sizeof(CtrlHead), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(S.t_count, 0, sizeof(int), s->stream));        // arrival counter of the fused T reduction: every solve starts from zero
         if (reset) {
             HIP_TRY(hipMemcpyAsync(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice, s->stream));
             HIP_TRY(hipMemcpyAsync(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice, s->stream));
