@@ -41,8 +41,6 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     // wave-uniform constants through the constant address space: scalar loads into SGPR operands; the
     // float copies k_view_prep stores behind the doubles feed the fp32 derivative math directly
     typedef const float __attribute__((address_space(4))) *fptr4;
-    const cptr4 cc = (cptr4)(S.cconst + kCStride * cam);
-    const fptr4 cf = (fptr4)(S.cconst + kCStride * cam + kCConst);
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
@@ -57,6 +55,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
+    const cptr4 cc = (cptr4)(S.cconst[tgt] + kCStride * cam);
+    const fptr4 cf = (fptr4)(S.cconst[tgt] + kCStride * cam + kCConst);
+    const RecLane rl = rec_lane(lane, (unsigned)P.V);
     const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
     const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
     // Per-view metadata (corner count, record slot) of a block of <= 64 views sits in lane registers and is
@@ -128,16 +129,16 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                 const f2 N0 = HM * (Xf * q) - (f2){ fk.x, 0.f };           // -d(u,v)/dX
                 const f2 N1 = HM * (Yf * q) - (f2){ 0.f, fk.y };           // -d(u,v)/dY
                 const f2 N2 = HM * kz;                                     // -d(u,v)/dZ
-                fu[6 * RP] = N0.x; fv[6] = N0.y;
-                fu[7 * RP] = N1.x; fv[7] = N1.y;
-                fu[8 * RP] = N2.x; fv[8] = N2.y;
+                fu[tc_tc(0) * RP] = N0.x; fv[tc_tc(0)] = N0.y;
+                fu[tc_tc(1) * RP] = N1.x; fv[tc_tc(1)] = N1.y;
+                fu[tc_tc(2) * RP] = N2.x; fv[tc_tc(2)] = N2.y;
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {                           // w_b: -A (x e_k0 + y e_k1)
                     const float h0 = xf * cs[9 + 6 * kk] + yf * cs[12 + 6 * kk];
                     const float h1 = xf * cs[10 + 6 * kk] + yf * cs[13 + 6 * kk];
                     const float h2 = xf * cs[11 + 6 * kk] + yf * cs[14 + 6 * kk];
                     const f2 w = N0 * h0 + N1 * h1 + N2 * h2;
-                    fu[kk * RP] = w.x; fv[kk] = w.y;
+                    fu[(kTcWb + kk) * RP] = w.x; fv[kTcWb + kk] = w.y;
                 }
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {                           // w_c: -A (dR_c/dw_k Pw)
@@ -146,16 +147,16 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                     const float g1 = D[3] * P0 + D[4] * P1 + D[5] * P2;
                     const float g2 = D[6] * P0 + D[7] * P1 + D[8] * P2;
                     const f2 w = N0 * g0 + N1 * g1 + N2 * g2;
-                    fu[(3 + kk) * RP] = w.x; fv[3 + kk] = w.y;
+                    fu[(kTcWc + kk) * RP] = w.x; fv[kTcWc + kk] = w.y;
                 }
-                fu[9 * RP] = -mxf;  fv[9] = -myf;
-                fu[10 * RP] = -1.f; fv[10] = -1.f;
+                fu[kTcF * RP] = -mxf;  fv[kTcF] = -myf;
+                fu[kTcOne * RP] = -1.f; fv[kTcOne] = -1.f;
                 const float kxi = c3 * c2 * e1, klam = c3 * e2, kal = e3 * cf[46];
                 const f2 a = HM * kxi, b = HM * klam, c = HM * kal;
-                fu[11 * RP] = a.x; fv[11] = a.y;
-                fu[12 * RP] = b.x; fv[12] = b.y;
-                fu[13 * RP] = c.x; fv[13] = c.y;
-                fu[14 * RP] = (float)ru; fv[14] = (float)rv;
+                fu[kTcXi * RP] = a.x;  fv[kTcXi] = a.y;
+                fu[kTcLam * RP] = b.x; fv[kTcLam] = b.y;
+                fu[kTcAl * RP] = c.x;  fv[kTcAl] = c.y;
+                fu[kTcR * RP] = (float)ru; fv[kTcR] = (float)rv;
             } else if (lane < prev_nv) {
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.f;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
         }
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
         camU += accU; camV += accV;
-        store_view_record(r_rec, lane, accU, accV, cc, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), (unsigned)P.V);
+        store_view_record(r_rec, lane, accU, accV, cc, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), rl);
     }
     }   // block of <= 64 views
     // r^T r of the camera tile (entry [14][14] = lane (col 14, kq 2), reg 3) comes from the fp64 sum

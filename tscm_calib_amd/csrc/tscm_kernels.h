@@ -4,11 +4,15 @@
 //   obs_u/obs_v      SoA corner observations, re-packed so the views of one camera are
 //                    contiguous and sorted by board: a wave streams them with unit stride.
 //   rec[2]           per-view Schur pieces written by the Gram kernel, two regions in one allocation:
-//                      W region [V][84]  E^T [F | r]   6 x 14 row-major (cols 0-12 = W, col 13 = E^T r)
-//                      E region [V][48]  E^T E 6 x 6 (36), then E^T r (6) and diag(E^T E) (6)
+//                      W region [V][84]  E^T [F | r]   COLUMN-major: 14 columns (F order, column 13 = E^T r) x 6 rows
+//                      E region [V][18]  E^T E_wb      3 columns (the w_b columns) x 6 rows: rows 0-2 w_b x w_b,
+//                                                      rows 3-5 t_b x w_b
+//                    The t_b x t_b block of E^T E is not stored: it is (E_tb^T F_tc) R_c, three FMAs per entry from
+//                    the t_c columns of W and the camera rotation the view was evaluated with (tb_tb; cconst is
+//                    double-buffered like the records for that reason).
 //                    views in board-major slot order; the Schur-complement and back-substitution kernels stream
-//                    the W region, the e-block factorisation and the board statistics only the E region.
-//                    double buffered: index ctrl->cur = system at x, cur^1 = candidate.
+//                    the W region, the e-block factorisation and the board statistics read the E region and two
+//                    pieces of W.  double buffered: index ctrl->cur = system at x, cur^1 = candidate.
 //   H_stage          per camera a 16x16 tile [F | r]^T [F | r]  (13x13 Gram, col 13 =
 //                    F^T r, [13][13] = r^T r) + 8 scalars + one gradient-max slot per rank; fixed address so that the
 //                    exchange back-end can all-reduce it without knowing the device-side buffer index.
@@ -25,10 +29,10 @@
 
 namespace tscm {
 
-constexpr int kRecW = 84;          // doubles per view in the W region: E^T [F | r], 6 x 14 row-major
-constexpr int kRecE = 48;          // doubles per view in the E region: E^T E (36), E^T r (6), diag(E^T E) (6)
-constexpr int kRecEG = 36;         // offset of E^T r / diag inside an E record
+constexpr int kRecW = 84;          // doubles per view in the W region: E^T [F | r], 14 columns x 6 rows, column-major
+constexpr int kRecE = 18;          // doubles per view in the E region: E^T E_wb, 3 columns x 6 rows, column-major
 constexpr int kRec = kRecW + kRecE;  // doubles per view over both regions (allocation size, offset limits)
+constexpr int kWcolTc = 3;         // W columns of t_c: F index 3, 4, 5 (the gradient column E^T r is F index kFR = 13)
 // per-board factor record (doubles)
 constexpr int kFac = 56;
 constexpr int kFacM = 0;           // [15] L_ik / L_ii, i > k, packed i (i - 1) / 2 + k
@@ -38,6 +42,13 @@ constexpr int kFacI = 36;          // [6]  1 / L_ii
 constexpr int kFacZ = 42;          // [6]  z = L^-1 S_b E^T r
 constexpr int kFacD = 48;          // [6]  D^2 (damping of the scaled block)
 constexpr int kTcols = 15;         // columns of the single MFMA Gram tile (see k_eval_gram)
+// Tile columns (= tile rows): 0-2 w_b | 3 t_c0 | 4-6 w_c | 7 t_c1 | 8 f* | 9 one* | 10 xi | 11 t_c2 | 12 lambda | 13 alpha |
+// 14 r | 15 zero.  The accumulator of v_mfma_f64_16x16x4 keeps rows kq + 4 * reg of column col in lane (col, kq): with
+// the t_c rows at 3, 7, 11 ONE lane (kq = 3) holds all three of them in registers 0, 1, 2 -- the t_b rows
+// (J_tb = J_tc R_c) are nine FMAs with scalar operands there, no cross-lane traffic -- and the w_b rows 0, 1, 2 sit in
+// register 0 of the lanes kq = 0, 1, 2.
+constexpr int kTcWb = 0, kTcWc = 4, kTcF = 8, kTcOne = 9, kTcXi = 10, kTcLam = 12, kTcAl = 13, kTcR = 14;
+__host__ __device__ constexpr int tc_tc(int j) { return 3 + 4 * j; }
 constexpr int kVConst = 27;        // per-view constants: r1, r2, t_b, R_c dR_b/dw_k [:,0:2]
 constexpr int kCConst = 48;        // per-camera constants: R_c, t_c, dR_c/dw_k, fx fy cx cy xi lambda beta 1/(1-alpha)^2
 constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 doubles, then the same 48 values as floats
@@ -85,6 +96,30 @@ __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d2 buf_load_2f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_2f64(__amdgpu_buffer_rsrc_t r, unsigned voff, double a, double b)
+{
+    const d2 v = { a, b };
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, (int)voff, 0, 0);
+}
+
+// Wave priority experiments of k_eval_gram (make PRIO=n; s_setprio takes an immediate, p is wave-uniform)
+#ifndef TSCM_PRIO
+#define TSCM_PRIO 10
+#endif
+__device__ __forceinline__ void set_prio(int p)
+{
+    switch (p & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 
 // record regions (V = views of this rank)
 __device__ __forceinline__ const double *rec_w(const double *rec, int slot) { return rec + (size_t)kRecW * slot; }
@@ -171,7 +206,8 @@ struct DevProblem {
 struct DevState {
     double *cam_rt[2], *intr[2], *board_rt[2];
     double *board_pc, *cam_pc;
-    double *vconst, *cconst;
+    double *vconst;
+    double *cconst[2];                 // per-camera constants of the point the records of the same index were evaluated at
     double *rec[2];
     double *campart, *campart2;
     double *H[2], *H_stage;
@@ -262,7 +298,7 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
         double crt[3], Rc[9], dRc[27];
         for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);
-        double *o = S.cconst + kCStride * m;
+        double *o = S.cconst[tgt] + kCStride * m;
         for (int k = 0; k < 9; ++k) o[k] = Rc[k];
         for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
         for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
@@ -296,85 +332,82 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
 }
 
 // tile column -> (parity mask) bookkeeping shared by the hot kernel's epilogue and k_finalize_eval.
-// Tile columns: 0-2 w_b | 3-5 w_c | 6-8 t_c | 9 f* | 10 one* | 11 xi | 12 lambda | 13 alpha | 14 r.
 //   f*   = -X/k on u-rows, -Y/k on v-rows : fx is its u-half, fy its v-half
 //   one* = -1 on every row                 : cx is its u-half, cy its v-half
 // so with separate Gram tiles for the u-rows (GU) and the v-rows (GV) the true products are
 //   <a, b> = sum over parities in mask(a) & mask(b) of G_par[tile(a)][tile(b)].
 // F index (record / H layout): 0-2 w_c, 3-5 t_c, 6 fx, 7 fy, 8 cx, 9 cy, 10 xi, 11 lambda, 12 alpha, 13 r.
-__device__ __forceinline__ int f_tile(int f) { return f < 6 ? f + 3 : (f < 10 ? 9 + ((f - 6) >> 1) : f + 1); }
+__host__ __device__ __forceinline__ constexpr int f_tile(int f)
+{
+    return f < 3 ? kTcWc + f : f < 6 ? tc_tc(f - 3) : f < 8 ? kTcF : f < 10 ? kTcOne : f == 10 ? kTcXi : f == 11 ? kTcLam : f == 12 ? kTcAl : kTcR;
+}
 __device__ __forceinline__ int f_mask(int f) { return (f >= 6 && f < 10) ? (1 << ((f - 6) & 1)) : 3; }
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue of the Gram kernels (fp64 and fp32-Jacobian variant): one view's two accumulator tiles (u-rows, v-rows)
-// -> its record, entirely in registers (cross-lane shuffles, no LDS phases).
-// D layout: lane (col, kq) holds rows kq + 4*reg of tile column col.  E rows of the record:
-//   e = kq       (w_b rows = tile rows 0..2: reg 0 of the lanes with kq < 3)
-//   e = 3 + l    (t_b rows = sum_j R_c[j][l] * tile row 6+j; rows 6,7 are reg 1 of kq = 2,3, row 8 is
-//                 reg 2 of kq = 0) -- lane (col, kq = l) builds row 3 + l of its column.
-// Thirteen UNCONDITIONAL buffer stores: a lane without an entry for a slot stores to an offset past the end of the
-// record array, which the buffer bounds check drops.  No divergent branch around a memory instruction is left in the
-// view loop, so the compiler knows exactly how many stores follow the prefetch loads and waits for those loads with
-// vmcnt(13) -- not for the stores themselves.
-// cc: the camera's constants (R_c in [0, 9)) through the constant address space; slot: the view's record slot.
+// -> its record, entirely in the lane's own registers.
+// D layout: lane (col, kq) holds rows kq + 4*reg of tile column col (see the tile-column table above):
+//   lanes kq < 3   register 0 = w_b row kq of their column              -> record row kq
+//   lanes kq == 3  registers 0, 1, 2 = the t_c rows of their column     -> t_b row l = sum_j R_c[j][l] * (t_c row j),
+//                  record rows 3, 4, 5 (row 3 leaves with the w_b rows in one store, rows 4 | 5 as one 16-byte store)
+// The columns f* and one* store their u-row part (fx, cx) and next to it the v-row part = total - u-part (fy, cy).
+// The record is column-major, so a lane's entries are adjacent: FOUR stores per view (13 in round 2, with 20
+// ds_bpermute, three vector loads of R_c and ~90 integer instructions of offset arithmetic around them); lanes without
+// an entry store past the end of the buffer, which the bounds check drops.  Neither the t_b x t_b block of E^T E
+// (consumers derive it: tb_tb) nor its never-read upper triangle nor copies of E^T r / the diagonal are written.
 // ---------------------------------------------------------------------------------------------
 typedef const double __attribute__((address_space(4))) *cptr4;
 
-__device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, int lane, const d4 &accU, const d4 &accV, cptr4 cc, unsigned slot, unsigned V)
+// lane-constant part of the record addressing, computed once per kernel: byte offset of the lane's row-kq entry inside
+// the allocation for slot 0 (region base included) and the byte stride per slot of its region
+struct RecLane { unsigned off, stride; };
+__device__ __forceinline__ RecLane rec_lane(int lane, unsigned V)
 {
-    // lane-constant record offsets are rebuilt per view from an opaque copy of the lane id: ~15 integer
-    // instructions instead of registers that stay live (and get spilled) across the whole view loop
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    const int col = le & 15, kq = le >> 4;
-    // region-relative byte offset of this lane's main entry: E^T E for the w_b columns, E^T [F | r] otherwise
-    // F index: 0-2 w_c, 3-5 t_c, 6 fx, 7 fy, 8 cx, 9 cy, 10 xi, 11 lambda, 12 alpha, 13 r
-    const bool in_e = col <= 2;
-    const unsigned cA = 8u * (unsigned)(in_e ? 6 * kq + col
-                                      : col <= 8 ? kRecW / 6 * kq + col - 3
-                                      : col == 9 ? kRecW / 6 * kq + 6 : col == 10 ? kRecW / 6 * kq + 8
-                                      : kRecW / 6 * kq + col - 1);
-    const unsigned offW = 8u * (unsigned)kRecW * slot;                                       // wave-uniform
-    const unsigned offE = 8u * ((unsigned)kRecW * V + (unsigned)kRecE * slot);
-    const d4 sT = accU + accV;
-    const double t6 = __shfl(sT[1], col + 32), t7 = __shfl(sT[1], col + 48), t8 = __shfl(sT[2], col);
-    const double u6 = __shfl(accU[1], col + 32), u7 = __shfl(accU[1], col + 48), u8 = __shfl(accU[2], col);
-    const int l = kq < 3 ? kq : 0;
-    // R_c[j][l], j = 0..2: three uniform candidates per entry, selected by the lane's l
-    const double r0 = l == 0 ? cc[0] : l == 1 ? cc[1] : cc[2];
-    const double r1 = l == 0 ? cc[3] : l == 1 ? cc[4] : cc[5];
-    const double r2 = l == 0 ? cc[6] : l == 1 ? cc[7] : cc[8];
-    const double mT_lo = sT[0], mT_hi = r0 * t6 + r1 * t7 + r2 * t8;   // rows kq and 3+kq (u+v)
-    const double mU_lo = accU[0], mU_hi = r0 * u6 + r1 * u7 + r2 * u8; // their u-row parts
-    const double a7_lo = __shfl(mT_lo, lane + 1), a8_lo = __shfl(mT_lo, lane + 2);
-    const double a7_hi = __shfl(mT_hi, lane + 1), a8_hi = __shfl(mT_hi, lane + 2);
-    constexpr unsigned BAD = 0xffffe000u;
-    auto st = [&](bool ok, unsigned byte_off, unsigned soff, double v) { buf_store_f64(r_rec, ok ? byte_off : BAD, soff, v); };
-    const bool k3 = kq < 3, split = col == 9 || col == 10, c6 = k3 && col == 6, c14 = k3 && col == 14, main = k3 && col != 15;
-    // main entries: rows kq (lo) and 3 + kq (hi) of this lane's column; fx|fy and cx|cy store their u-part here.
-    // (lanes of both regions in one instruction: the region base travels in the lane offset)
-    const unsigned oA = cA + (in_e ? offE : offW);
-    st(main, oA, 0u, split ? mU_lo : mT_lo);
-    st(main, oA + (in_e ? 8u * 18u : 8u * 3u * (kRecW / 6)), 0u, split ? mU_hi : mT_hi);
-    // ... and their v-part (= total - u-part) next to it
-    st(k3 && split, cA + 8u, offW, mT_lo - mU_lo);
-    st(k3 && split, cA + 8u + 8u * 3u * (kRecW / 6), offW, mT_hi - mU_hi);
-    // E^T E, t_b columns: sum_j R_c[j][l'] * M[e][6 + j]   (lanes of tile column 6)
-    const unsigned oB = 8u * (unsigned)(6 * kq + 3);
-    double vhi_kq = 0.0;
-#pragma unroll
-    for (int lp = 0; lp < 3; ++lp) {
-        const double vlo = cc[lp] * mT_lo + cc[3 + lp] * a7_lo + cc[6 + lp] * a8_lo;
-        const double vhi = cc[lp] * mT_hi + cc[3 + lp] * a7_hi + cc[6 + lp] * a8_hi;
-        st(c6, oB + 8u * lp, offE, vlo);
-        st(c6, oB + 8u * 18u + 8u * lp, offE, vhi);
-        if (lp == kq) vhi_kq = vhi;
+    const int col = lane & 15, kq = lane >> 4;
+    RecLane r;
+    if (col < 3) { r.off = 8u * ((unsigned)kRecW * V + 6u * (unsigned)col + (unsigned)kq); r.stride = 8u * kRecE; }
+    else if (col == 15) { r.off = 0xffffe000u; r.stride = 0u; }
+    else {
+        // tile column -> F index (W column); f* and one* are the first of a (u-part, v-part) column pair
+        const int f = (col & 3) == 3 ? kWcolTc + (col >> 2) : col < 8 ? col - kTcWc : col == kTcF ? 6 : col == kTcOne ? 8 : col == kTcXi ? 10 : col - 1;
+        r.off = 8u * (6u * (unsigned)f + (unsigned)kq); r.stride = 8u * kRecW;
     }
-    // diag(E^T E): w_b part from the lanes (col == kq), t_b part from the lanes of column 6
-    st((k3 && col == kq) || c6, 8u * (unsigned)(kRecEG + (col == 6 ? 9 : 6)) + 8u * (unsigned)kq, offE, col == 6 ? vhi_kq : mT_lo);
-    // compact E^T r
-    st(c14, 8u * (unsigned)kRecEG + 8u * (unsigned)kq, offE, mT_lo);
-    st(c14, 8u * (unsigned)(kRecEG + 3) + 8u * (unsigned)kq, offE, mT_hi);
+    return r;
+}
+
+// t_b x t_b entry (l, lp) of one view's E^T E from the t_c columns of its W record (column-major) and the rotation of
+// the camera it was evaluated with -- the SAME three operations, in the same order, the Gram kernel's epilogue used
+// when it still stored the block: the values are bit-identical.
+template <typename PW, typename PR>
+__host__ __device__ __forceinline__ double tb_tb(PW W, PR Rc, int l, int lp)
+{
+    double t = Rc[3 + lp] * W[6 * (kWcolTc + 1) + 3 + l];
+    t = fma(Rc[lp], W[6 * kWcolTc + 3 + l], t);
+    return fma(Rc[6 + lp], W[6 * (kWcolTc + 2) + 3 + l], t);
+}
+
+__device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, int lane, const d4 &accU, const d4 &accV, cptr4 cc, unsigned slot, RecLane rl)
+{
+    int le = lane;
+    asm volatile("" : "+v"(le));             // the lane predicates are rebuilt per view (a compare each) instead of living in SGPR pairs
+    const int col = le & 15;
+    const bool k3 = le >= 48, split = col == kTcF || col == kTcOne;
+    constexpr unsigned BAD = 0xffffe000u;
+    const unsigned off = rl.off + __umul24(slot, rl.stride);
+    const double t0 = accU[0] + accV[0], t1 = accU[1] + accV[1], t2 = accU[2] + accV[2];
+    // t_b rows l = 0, 1, 2 (of use in the lanes kq == 3): u+v and the u-row part
+    double tbT[3], tbU[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        tbT[l] = fma(cc[6 + l], t2, fma(cc[l], t0, cc[3 + l] * t1));
+        tbU[l] = fma(cc[6 + l], accU[2], fma(cc[l], accU[0], cc[3 + l] * accU[1]));
+    }
+    const double selT = k3 ? tbT[0] : t0, selU = k3 ? tbU[0] : accU[0];      // record row kq (kq < 3) / row 3 (kq == 3)
+    buf_store_f64(r_rec, off, 0u, split ? selU : selT);
+    buf_store_2f64(r_rec, (k3 ? off : BAD) + 8u, split ? tbU[1] : tbT[1], split ? tbU[2] : tbT[2]);
+    // ... and the v-row parts of f* / one* in the next record column
+    buf_store_f64(r_rec, (split ? off : BAD) + 48u, 0u, selT - selU);
+    buf_store_2f64(r_rec, (split && k3 ? off : BAD) + 56u, tbT[1] - tbU[1], tbT[2] - tbU[2]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -397,6 +430,62 @@ __device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, 
 // dynamic LDS: 16*rp + kCst + 2*n_points doubles (the kCst block is only used by k_eval_gram_f32).
 
 // ---------------------------------------------------------------------------------------------
+#ifdef TSCM_WAVE_TIMELINE
+constexpr int kTimelineWaves = 8192;
+__device__ long long g_timeline[4 * kTimelineWaves];     // per wave of k_eval_gram: HW_ID, XCC_ID, start, end (10 ns ticks)
+#endif
+#ifndef TSCM_EXP
+#define TSCM_EXP 3     // bit 0: full tiles through gram_full (0 = round 2's paired loop, for A/B runs), bit 1: first MFMA with C = 0
+#endif
+#ifndef TSCM_GRAM_DEPTH
+#define TSCM_GRAM_DEPTH 4
+#endif
+// Gram contraction of one row half of a view, full tile of KS k-steps: every operand is its OWN ds_read_b64 (serviced
+// in two 32-lane groups with banks mod 64: conflict-free at a pitch of 2 * odd), requested D steps ahead of the MFMA
+// that consumes it.  The compiler fuses neighbouring plain loads into ds_read2_b64, which is serviced in 16-lane groups
+// with banks mod 32 -- two-way conflicts at this pitch, 16 LDS cycles instead of 4 per pair: the source of
+// SQ_LDS_BANK_CONFLICT in round 2's counters -- and waits for each pair right after requesting it.  Hence inline
+// assembly with explicit counts: LDS operations of a wave complete in order, so after lgkmcnt(n) everything but the n
+// youngest requests has arrived whatever else (scalar loads included) is in flight.
+template <int OFF>
+__device__ __forceinline__ double ds_read_f64(unsigned addr)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(double &v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N)); }
+__device__ __forceinline__ unsigned lds_addr(const double *p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) double *)p;
+}
+template <int KS, int D, bool ZERO_C, int T = 0>
+__device__ __forceinline__ void gram_steps(unsigned addr, double (&a)[KS], d4 &acc)
+{
+    if constexpr (T < KS) {
+        if constexpr (T + D < KS) a[T + D] = ds_read_f64<32 * (T + D)>(addr);
+        lgkm_wait<(KS - 1 - T < D ? KS - 1 - T : D)>(a[T]);
+        if constexpr (ZERO_C && T == 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T], a[T], d4{ 0.0, 0.0, 0.0, 0.0 }, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T], a[T], acc, 0, 0, 0);
+        gram_steps<KS, D, ZERO_C, T + 1>(addr, a, acc);
+    }
+}
+template <int KS, int D, bool ZERO_C, int T = 0>
+__device__ __forceinline__ void gram_prime(unsigned addr, double (&a)[KS])
+{
+    if constexpr (T < D && T < KS) { a[T] = ds_read_f64<32 * T>(addr); gram_prime<KS, D, ZERO_C, T + 1>(addr, a); }
+}
+template <int KS, bool ZERO_C>
+__device__ __forceinline__ void gram_full(const double *fp, d4 &acc)
+{
+    constexpr int D = TSCM_GRAM_DEPTH;
+    const unsigned addr = lds_addr(fp);
+    double a[KS];
+    gram_prime<KS, D, ZERO_C>(addr, a);
+    gram_steps<KS, D, ZERO_C>(addr, a, acc);
+}
+
 template <int RPC>   // RPC > 0: compile-time LDS pitch (HV = RPC - 2): all tile offsets become immediates
 __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, int cand)
 {
@@ -410,6 +499,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     // the control block is read together with the static chunk tables (one memory round trip, not two);
     // the early exit is taken right before the first view
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
+#ifdef TSCM_WAVE_TIMELINE
+    // profiling builds only (make EXTRA=-DTSCM_WAVE_TIMELINE): start / end time and hardware slot of every wave of the
+    // launches of LM iteration 5 into g_timeline; tscm_debug_wave_timeline copies it out, tools/wave_timeline.py groups
+    // the waves by SIMD
+    const long long tl_t0 = wall_clock64();
+    const int tl_iter = S.ctrl->iteration;
+#endif
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps chunk/view/cnt in SGPRs
     double *lds = lds_all + (size_t)wave * P.lds_wave;     // every wave works in its own LDS region
@@ -421,13 +517,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     const int chunk = blockIdx.x * 4 + wave;
     const int cam = P.chunk_cam[chunk];
     for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
-    // camera constants: read through the constant address space (uniform address, written by an earlier
-    // kernel) -> scalar loads straight into SGPR operands, no v_readlane pair per use
-    const cptr4 ccs = (cptr4)(S.cconst + kCStride * cam);
     const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
-    auto CC = [&](int k) { return ccs[k]; };                                          // camera constants (see k_view_prep)
     // rows of lanes without a corner are kept at zero instead of being re-written every pass
     if (lane < HV) {
 #pragma unroll
@@ -441,6 +533,11 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
+    // camera constants: read through the constant address space (uniform address, written by an earlier
+    // kernel) -> scalar loads straight into SGPR operands, no v_readlane pair per use
+    const cptr4 ccs = (cptr4)(S.cconst[tgt] + kCStride * cam);
+    auto CC = [&](int k) { return ccs[k]; };                                          // camera constants (see k_view_prep)
+    const RecLane rl = rec_lane(lane, (unsigned)P.V);
     const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
     const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
     // Per-view metadata (corner count, record slot) of a block of <= 64 views sits in lane registers and is
@@ -448,6 +545,28 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     // sum.  No dependent global load -- and therefore no in-order vmcnt wait behind the previous view's
     // record stores -- is left inside the view loop.
     int off_next = vb < ve ? P.view_obs[vb] : 0;
+#if TSCM_PRIO
+#ifdef TSCM_PRIO_BLK
+    const int wid = (int)(blockIdx.x >> 8) & 3;
+#else
+    const int wid = (int)__builtin_amdgcn_s_getreg(6148) & 3;      // HW_ID.wave_id: slot of this wave on its SIMD
+#endif
+    auto prio = [&](int ph, int view) {
+        if (TSCM_PRIO == 1) { if (ph == 0) set_prio(view + wid); }
+        else if (TSCM_PRIO == 2) set_prio(view + ph + wid);
+        else if (TSCM_PRIO == 3) set_prio(ph == 0 ? 1 : ph == 3 ? 2 : 3);
+        else if (TSCM_PRIO == 4) set_prio(ph == 0 ? 3 : ph == 3 ? 1 : 0);
+        else if (TSCM_PRIO == 5) { if (ph == 0) set_prio(3 - min(3, 4 * (view - vb) / max(1, ve - vb))); }
+        else if (TSCM_PRIO == 6) { if (ph == 0) set_prio((int)(__builtin_amdgcn_s_memtime() >> 12) + wid); }
+        else if (TSCM_PRIO == 7) { if (ph == 0) set_prio(3 - ((view - vb) & 3)); }
+        else if (TSCM_PRIO == 8) { const int q = 3 - min(3, 4 * (view - vb) / max(1, ve - vb)); set_prio(ph == 0 ? min(3, q + 1) : ph == 3 ? q : max(0, q - 1)); }
+        else if (TSCM_PRIO == 9) { const int h = 2 * (view - vb) < ve - vb ? 2 : 0; set_prio(h + (ph == 0 || ph == 3 ? 1 : 0)); }
+        else if (TSCM_PRIO == 10) { if (ph == 0) set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4)); }
+    };
+#define PRIO(ph, view) prio(ph, view)
+#else
+#define PRIO(ph, view)
+#endif
     for (int vbase = vb; vbase < ve; vbase += 64) {
     const int vend = min(ve, vbase + 64);
     int m_cnt = 0, m_slot = 0;
@@ -462,6 +581,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         const int off = off_next;
         off_next = off + cnt;
         wave_lds_fence();                       // previous view's epilogue has finished with LDS
+        PRIO(0, view);
         const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);      // this view's 27 constants: scalar loads
         auto VC = [&](int k) { return vcs[k]; };
         d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
@@ -504,17 +624,17 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 // -A = -d(u,v)/dPc  (the t_c columns)
                 const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
                 const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
-                fu[6 * RP] = n00; fv[6] = n10;
-                fu[7 * RP] = n01; fv[7] = n11;
-                fu[8 * RP] = n02; fv[8] = n12;
+                fu[tc_tc(0) * RP] = n00; fv[tc_tc(0)] = n10;
+                fu[tc_tc(1) * RP] = n01; fv[tc_tc(1)] = n11;
+                fu[tc_tc(2) * RP] = n02; fv[tc_tc(2)] = n12;
                 // w_b: -A (x e_k0 + y e_k1)
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
                     const double h0 = x * VC(9 + 6 * kk) + y * VC(12 + 6 * kk);
                     const double h1 = x * VC(10 + 6 * kk) + y * VC(13 + 6 * kk);
                     const double h2 = x * VC(11 + 6 * kk) + y * VC(14 + 6 * kk);
-                    fu[kk * RP] = n00 * h0 + n01 * h1 + n02 * h2;
-                    fv[kk] = n10 * h0 + n11 * h1 + n12 * h2;
+                    fu[(kTcWb + kk) * RP] = n00 * h0 + n01 * h1 + n02 * h2;
+                    fv[kTcWb + kk] = n10 * h0 + n11 * h1 + n12 * h2;
                 }
                 // w_c: -A (dR_c/dw_k Pw)
 #pragma unroll
@@ -522,21 +642,21 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                     const double g0 = CC(12 + 9 * kk + 0) * Pw0 + CC(12 + 9 * kk + 1) * Pw1 + CC(12 + 9 * kk + 2) * Pw2;
                     const double g1 = CC(12 + 9 * kk + 3) * Pw0 + CC(12 + 9 * kk + 4) * Pw1 + CC(12 + 9 * kk + 5) * Pw2;
                     const double g2 = CC(12 + 9 * kk + 6) * Pw0 + CC(12 + 9 * kk + 7) * Pw1 + CC(12 + 9 * kk + 8) * Pw2;
-                    fu[(3 + kk) * RP] = n00 * g0 + n01 * g1 + n02 * g2;
-                    fv[(3 + kk)] = n10 * g0 + n11 * g1 + n12 * g2;
+                    fu[(kTcWc + kk) * RP] = n00 * g0 + n01 * g1 + n02 * g2;
+                    fv[kTcWc + kk] = n10 * g0 + n11 * g1 + n12 * g2;
                 }
                 // f* and one*
-                fu[9 * RP] = -mx;   fv[9] = -my;
-                fu[10 * RP] = -1.0; fv[10] = -1.0;
+                fu[kTcF * RP] = -mx;   fv[kTcF] = -my;
+                fu[kTcOne * RP] = -1.0; fv[kTcOne] = -1.0;
                 // xi, lambda, alpha: -du/dk * dk/dparam
                 const double hu = fxk * mx, hv = fyk * my;
                 const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * CC(46);
-                fu[11 * RP] = hu * kxi;  fv[11] = hv * kxi;
-                fu[12 * RP] = hu * klam; fv[12] = hv * klam;
-                fu[13 * RP] = hu * kal;  fv[13] = hv * kal;
+                fu[kTcXi * RP] = hu * kxi;   fv[kTcXi] = hv * kxi;
+                fu[kTcLam * RP] = hu * klam; fv[kTcLam] = hv * klam;
+                fu[kTcAl * RP] = hu * kal;   fv[kTcAl] = hv * kal;
                 // residual = observed - projected (multi_calib.h:192-193)
-                fu[14 * RP] = ou - (fx * mx + CC(41));
-                fv[14] = ov - (fy * my + CC(42));
+                fu[kTcR * RP] = ou - (fx * mx + CC(41));
+                fv[kTcR] = ov - (fy * my + CC(42));
             } else if (lane < prev_nv) {
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.0;
@@ -556,6 +676,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
             }
             wave_lds_fence();
+            PRIO(1, view);
             const int nv = min(64, cnt - c0);
             prev_nv = nv;
             const int ksteps = (nv + 3) >> 2;
@@ -563,7 +684,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
             // pairs of k-steps; operands of the next pair are fetched while the current MFMAs issue
             const double *fp = Fl + col * RP + kq;      // lane (col, kq) feeds tile column col, row 4t + kq
             const int tmax = (HV >> 2) - 2;
-            {
+            constexpr int KSF = RPC > 0 ? (RPC - 2) / 4 : 1;      // k-steps of a full tile
+            const bool full_tile = (TSCM_EXP & 1) && RPC > 0 && ksteps == KSF;
+            if (full_tile && !(ablate & 1)) gram_full<KSF, (TSCM_EXP & 2) != 0>(fp, accU);
+            else {
                 double a0 = fp[0], a1 = fp[4];
                 for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
                     const int tn = min(t + 2, tmax);
@@ -579,7 +703,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = fv[c];
             }
             wave_lds_fence();
-            {
+            PRIO(2, view);
+            if (full_tile && !(ablate & 1)) gram_full<KSF, (TSCM_EXP & 2) != 0>(fp, accV);
+            else {
                 double a0 = fp[0], a1 = fp[4];
                 for (int t = 0; t < ksteps && !(ablate & 1); t += 2) {
                     const int tn = min(t + 2, tmax);
@@ -596,11 +722,20 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         // wait for a load with stores in flight is a vmcnt(0) -- a wait placed right after the stores (the top
         // of the next view) would expose the whole store latency.  The geometry is done with cst by now.
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
+        PRIO(3, view);
         camU += accU; camV += accV;
         if (ablate & 2) continue;
-        store_view_record(r_rec, lane, accU, accV, ccs, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), (unsigned)P.V);
+        store_view_record(r_rec, lane, accU, accV, ccs, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), rl);
     }
     }   // block of <= 64 views
+#ifdef TSCM_WAVE_TIMELINE
+    if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) {
+        g_timeline[4 * chunk] = (long long)__builtin_amdgcn_s_getreg(63492);     // HW_ID
+        g_timeline[4 * chunk + 1] = (long long)__builtin_amdgcn_s_getreg(6164);  // XCC_ID
+        g_timeline[4 * chunk + 2] = tl_t0;
+        g_timeline[4 * chunk + 3] = wall_clock64();
+    }
+#endif
     // the four waves of the workgroup (same camera) sum their tiles through LDS in a fixed order
     wave_lds_fence();
 #pragma unroll
@@ -725,8 +860,12 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
         if (q1 > q0 && !P.board_const[b]) {         // constant pose blocks are not part of the reduced program
             double g[6] = { 0, 0, 0, 0, 0, 0 }, dg[6] = { 0, 0, 0, 0, 0, 0 };
             for (int q = q0; q < q1; ++q) {
-                const double *rec = rec_e(S.rec[tgt], P.V, q);
-                for (int i = 0; i < 6; ++i) { g[i] += rec[kRecEG + i]; dg[i] += rec[kRecEG + 6 + i]; }
+                const double *W = rec_w(S.rec[tgt], q);
+                for (int i = 0; i < 6; ++i) g[i] += W[6 * kFR + i];
+                if (init) {                     // diag(E^T E) is only needed for the Jacobi scaling
+                    const double *E = rec_e(S.rec[tgt], P.V, q), *Rc = S.cconst[tgt] + kCStride * P.slot_cam[q];
+                    for (int i = 0; i < 3; ++i) { dg[i] += E[6 * i + i]; dg[3 + i] += tb_tb(W, Rc, i, i); }
+                }
             }
             for (int i = 0; i < 6; ++i) {
                 const double x = S.board_rt[tgt][6 * b + i];
@@ -956,12 +1095,12 @@ __device__ __forceinline__ void factor_board(const DevProblem &P, const DevState
 #pragma unroll
     for (int i = 0; i < 21; ++i) M[i] = 0.0;
     for (int q = q0; q < q1; ++q) {
-        const double *rec = rec_e(S.rec[cur], P.V, q);
+        const double *E = rec_e(S.rec[cur], P.V, q), *W = rec_w(S.rec[cur], q), *Rc = S.cconst[cur] + kCStride * P.slot_cam[q];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
-            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += rec[i * 6 + j];
-            g[i] += rec[kRecEG + i];
+            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] += j < 3 ? E[6 * j + i] : tb_tb(W, Rc, i - 3, j - 3);
+            g[i] += W[6 * kFR + i];
         }
     }
     if (!factor_core(M, g, sb, radius, dmin, dmax, S.fac + (size_t)kFac * b, P.board_const[b] != 0)) S.ctrl->lin_fail = 1;
@@ -1039,6 +1178,13 @@ __device__ __forceinline__ void y_column_operands(const FacFwd &F, const double 
     s1 = first ? a45 : 0.0;
 }
 
+// the t_b x t_c blocks (3 x 3, one per view) a board's factorisation needs to rebuild its t_b x t_b block, staged in
+// LDS as r[3 * jc + l]; indexed like the W record they were taken from so that tb_tb serves both
+struct RawTc {
+    const double *r;
+    __device__ __forceinline__ double operator[](int i) const { return r[3 * (i / 6 - kWcolTc) + (i % 6 - 3)]; }
+};
+
 template <int NV>
 __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0)
 {
@@ -1050,7 +1196,10 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     if (ctrl_done) return;
     PHASE_STAMP(ts0);
     constexpr int NT = NV * (NV + 1) / 2;
-    __shared__ double sumE[kChunkBoards][kRecE];
+    // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
+    // 3 x 3 block t_b x t_c of W (9 NV): the t_b x t_b block is built from those in phase 0b with each view's R_c
+    constexpr int NE = 24 + 9 * NV, NJ = (NE + 15) / 16;
+    __shared__ double sumE[kChunkBoards][NE];
     __shared__ __attribute__((aligned(16))) double facl[kChunkBoards][kFac];
     __shared__ double tiles[4][NT][256];
     const int chunk = chunk0 + blockIdx.x;
@@ -1059,22 +1208,31 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     const int a = lane & 15, kq = lane >> 4;
     const int c0 = desc.x, nbd = desc.y - desc.x, slot0 = desc.z;       // boards c0 .. c0 + nbd - 1 (<= kChunkBoards), views at slots slot0 + NV * i
     const double *rec = S.rec[cur];
-    // ---- requests: the E records of the boards this lane sums (phase 0a), the W columns of the four groups of four
-    //      boards its wave contracts (phase 1), the Jacobi scaling of the board it factors (phase 0b)
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(rec, sizeof(double) * (size_t)kRecW * P.V);
+    // ---- requests: the pieces of the records of the boards this lane gathers (phase 0a), the W columns of the four
+    //      groups of four boards its wave contracts (phase 1), the Jacobi scaling of the board it factors (phase 0b)
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(rec, sizeof(double) * (size_t)kRec * P.V);
     constexpr unsigned BAD = 0xffffe000u;
-    double ev[4][3];
+    double ev[4][NJ];
     {
         const int e = tid & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int bf = 16 * i + (tid >> 4);
-            const double *E = rec_e(rec, P.V, slot0 + NV * min(bf, nbd - 1));
+        for (int j = 0; j < NJ; ++j) {
+            // entry e + 16 j of the list above: offset of its first term inside the allocation relative to the board's
+            // first view, stride between the views' terms (0: a single term)
+            const int idx = e + 16 * j;
+            const int pv = idx < 24 ? 0 : (idx - 24) / 9, r9 = idx < 24 ? 0 : (idx - 24) % 9;
+            const bool summed = idx < 24;
+            const unsigned first = idx < 18 ? 8u * ((unsigned)kRecW * (unsigned)P.V + (unsigned)idx)
+                                 : idx < 24 ? 8u * (unsigned)(6 * kFR + idx - 18)
+                                 : 8u * (unsigned)(kRecW * pv + 6 * (kWcolTc + r9 / 3) + 3 + r9 % 3);
+            const unsigned per_slot = idx < 18 ? 8u * kRecE : 8u * kRecW;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int i = 0; i < 4; ++i) {
+                const int bf = 16 * i + (tid >> 4);
+                const unsigned o0 = idx < NE ? first + per_slot * (unsigned)(slot0 + NV * min(bf, nbd - 1)) : BAD;
                 double acc = 0.0;
 #pragma unroll
-                for (int p = 0; p < NV; ++p) acc += E[kRecE * p + e + 16 * j];
+                for (int p = 0; p < NV; ++p) acc += buf_load_f64(r_w, (p == 0 || summed) ? o0 : BAD, per_slot * (unsigned)p);
                 ev[i][j] = acc;
             }
         }
@@ -1083,23 +1241,30 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int bg = 16 * wave + 4 * g + kq;
-        const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + (unsigned)a) : BAD;
+        const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + 6u * (unsigned)a) : BAD;
 #pragma unroll
         for (int p = 0; p < NV; ++p)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) w[g][p][k] = buf_load_f64(r_w, base, 8u * (unsigned)(kRecW * p + 14 * k));
+            for (int k = 0; k < 3; ++k) {          // column a of the view's W: six adjacent doubles
+                const d2 v = buf_load_2f64(r_w, base, 8u * (unsigned)(kRecW * p + 2 * k));
+                w[g][p][2 * k] = v[0]; w[g][p][2 * k + 1] = v[1];
+            }
     }
     double sb[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) sb[i] = tid < nbd ? S.s_b[6 * (c0 + tid) + i] : 1.0;
     const bool board_is_const = tid < nbd && P.board_const[c0 + tid] != 0;
-    // ---- phase 0a: 16 lanes per board, 16 boards per pass; the NV E records of a board are adjacent ----------------
+    // the boards of a chunk share their camera set: the rotation of view p's camera is chunk-uniform
+    const double *Rcp[NV];
+#pragma unroll
+    for (int p = 0; p < NV; ++p) Rcp[p] = S.cconst[cur] + kCStride * P.slot_cam[slot0 + p];
+    // ---- phase 0a: 16 lanes per board, 16 boards per pass ------------------------------------------------------------
     {
         const int e = tid & 15, grp = tid >> 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) sumE[16 * i + grp][e + 16 * j] = ev[i][j];
+            for (int j = 0; j < NJ; ++j) if (e + 16 * j < NE) sumE[16 * i + grp][e + 16 * j] = ev[i][j];
     }
     __syncthreads();
     PHASE_STAMP(ts1);
@@ -1109,8 +1274,16 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
-            for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = sumE[tid][6 * i + j];
-            g[i] = sumE[tid][kRecEG + i];
+            for (int j = 0; j <= i; ++j) {
+                if (j < 3) M[i * (i + 1) / 2 + j] = sumE[tid][6 * j + i];
+                else {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < NV; ++p) acc += tb_tb(RawTc{ &sumE[tid][24 + 9 * p] }, Rcp[p], i - 3, j - 3);
+                    M[i * (i + 1) / 2 + j] = acc;
+                }
+            }
+            g[i] = sumE[tid][18 + i];
         }
         if (!factor_core(M, g, sb, radius, dmin, dmax, facl[tid], board_is_const)) S.ctrl->lin_fail = 1;
     }
@@ -1179,7 +1352,7 @@ __global__ __launch_bounds__(256) void k_pair_gram(DevProblem P, DevState S)
         load_fac_fwd(S.fac, __builtin_amdgcn_readfirstlane(P.pair_board[p]), F);     // p is wave-uniform
         double wi[6], wj[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { wi[k] = a < 14 ? Wi[14 * k + a] : 0.0; wj[k] = a < 14 ? Wj[14 * k + a] : 0.0; }
+        for (int k = 0; k < 6; ++k) { wi[k] = a < 14 ? Wi[6 * a + k] : 0.0; wj[k] = a < 14 ? Wj[6 * a + k] : 0.0; }
         double i0, i1, j0, j1;
         y_column_operands(F, wi, a == kFR, kq, i0, i1);
         y_column_operands(F, wj, a == kFR, kq, j0, j1);
@@ -2073,7 +2246,7 @@ __device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, 
     double crt[3], Rc[9], dRc[27];
     for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
     rotation_and_derivatives(crt, Rc, dRc);
-    double *o = S.cconst + kCStride * m;
+    double *o = S.cconst[tgt] + kCStride * m;
     for (int k = 0; k < 9; ++k) o[k] = Rc[k];
     for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
     for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
@@ -2159,7 +2332,7 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
                 double p[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    p[k] = (a < kFA ? s_w[kRecW * sl + 14 * k + a] : 0.0) * yh;
+                    p[k] = (a < kFA ? s_w[kRecW * sl + 6 * a + k] : 0.0) * yh;
                     p[k] = row16_allsum(p[k]);
                 }
                 if (a == 0) {

@@ -592,7 +592,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.board_pc, (size_t)kBoardConst * B))) return rc;
     if ((rc = dev_alloc(s, &S.cam_pc, (size_t)kCamConst * C))) return rc;
     if ((rc = dev_alloc(s, &S.vconst, (size_t)kVStride * V))) return rc;
-    if ((rc = dev_alloc(s, &S.cconst, (size_t)kCStride * C))) return rc;
+    for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(s, &S.cconst[k], (size_t)kCStride * C))) return rc;
     if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)(P.n_chunks / 4)))) return rc;
     if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C * kCamG1))) return rc;
     if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal + world))) return rc;
@@ -1152,21 +1152,30 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     hipLaunchKernelGGL(k_finalize_eval, dim3(P.C), dim3(256), 0, s->stream, P, S, 0, -1);        // camera blocks only
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipGetLastError());
-    std::vector<double> rec((size_t)kRec * s->V), H(256 * (size_t)s->C);
+    std::vector<double> rec((size_t)kRec * s->V), H(256 * (size_t)s->C), cc((size_t)kCStride * s->C);
     if (s->V) HIP_TRY(hipMemcpy(rec.data(), S.rec[0], sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(H.data(), S.H_stage, sizeof(double) * H.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cc.data(), S.cconst[0], sizeof(double) * cc.size(), hipMemcpyDeviceToHost));
     if (board_gram) std::memset(board_gram, 0, sizeof(double) * 36 * (size_t)s->B);
     if (board_grad) std::memset(board_grad, 0, sizeof(double) * 6 * (size_t)s->B);
     if (view_cross) std::memset(view_cross, 0, sizeof(double) * 90 * (size_t)p->n_views);
     for (int dv = 0; dv < s->V; ++dv) {
-        const double *rw = rec.data() + (size_t)kRecW * s->h_view_slot[dv];                           // E^T [F | r], 6 x 14
-        const double *re = rec.data() + (size_t)kRecW * s->V + (size_t)kRecE * s->h_view_slot[dv];  // E^T E, 6 x 6
+        // the view's record: W = E^T [F | r] (14 columns x 6 rows, column-major), E = E^T E_wb (3 columns x 6 rows); the
+        // t_b x t_b block of E^T E follows from the t_c columns of W and the camera rotation (tb_tb), the block above
+        // the diagonal by symmetry -- what the device-side consumers do
+        const double *rw = rec.data() + (size_t)kRecW * s->h_view_slot[dv];
+        const double *re = rec.data() + (size_t)kRecW * s->V + (size_t)kRecE * s->h_view_slot[dv];
+        const double *Rc = cc.data() + (size_t)kCStride * s->h_view_cam[dv];
         const int b = s->b0 + s->board_perm[s->h_view_board[dv]], ov = s->dev2orig[dv];
         for (int i = 0; i < 6; ++i) {
-            if (board_gram) for (int j = 0; j < 6; ++j) board_gram[36 * (size_t)b + 6 * i + j] += re[6 * i + j];
-            if (board_grad) board_grad[6 * (size_t)b + i] += rw[14 * i + kFR];
+            if (board_gram)
+                for (int j = 0; j < 6; ++j) {
+                    const int hi = std::max(i, j), lo = std::min(i, j);
+                    board_gram[36 * (size_t)b + 6 * i + j] += lo < 3 ? re[6 * lo + hi] : tb_tb(rw, Rc, hi - 3, lo - 3);
+                }
+            if (board_grad) board_grad[6 * (size_t)b + i] += rw[6 * kFR + i];
             if (view_cross) {
-                for (int j = 0; j < 13; ++j) view_cross[90 * (size_t)ov + 15 * i + j] = rw[14 * i + j];
+                for (int j = 0; j < 13; ++j) view_cross[90 * (size_t)ov + 15 * i + j] = rw[6 * j + i];
             }
         }
     }
@@ -1341,3 +1350,14 @@ extern "C" int tscm_shard_frames(const tscm_problem *p, int world, int *owner)
     std::copy(o.begin(), o.end(), owner);
     return 0;
 }
+
+#ifdef TSCM_WAVE_TIMELINE
+// profiling builds only: the per-wave timeline of the last recorded k_eval_gram launch (tools/wave_timeline.py)
+extern "C" int tscm_debug_wave_timeline(long long *out, int max_waves)
+{
+    const int n = std::min(max_waves, tscm::kTimelineWaves);
+    if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_timeline), sizeof(long long) * 4 * (size_t)n) != hipSuccess) return TSCM_E_HIP;
+    return n;
+}
+#endif
