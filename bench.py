@@ -40,7 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ITERS_PER_SOLVE = int(os.environ.get("TSCM_BENCH_ITERS_PER_SOLVE", "50"))
+# (the library takes at most TSCM_MAX_ITERATIONS = 255 iterations per solve)
+ITERS_PER_SOLVE = min(255, max(1, int(os.environ.get("TSCM_BENCH_ITERS_PER_SOLVE", "50"))))
 # algorithmic work of one k_eval_gram launch (DESIGN.md "roofline accounting")
 FLOP_MFMA_PER_CORNER = 836           # Gram contraction 2P(P+1)+4P with P=19
 FLOP_VALU_PER_CORNER = 600           # hand-structured residual + analytic Jacobian
@@ -52,7 +53,16 @@ HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
 CPU_BASELINE_ITERS = 8
-EVENT_STRIDE = 8
+EVENT_STRIDE_MAX = 8                 # an event pair holds the stream for a few microseconds: long runs time every 8th launch
+MIN_TIMED_LAUNCHES = 8               # ... short runs time more of them, so that at least this many are measured
+
+
+def event_stride(steps: int) -> int:
+    """Launches of the dominant kernel in the timed region: one per LM iteration plus the iteration-0 evaluation of
+    every solve.  Every k-th is bracketed by HIP events, k as large as EVENT_STRIDE_MAX allows while still timing
+    MIN_TIMED_LAUNCHES of them."""
+    launches = steps + math.ceil(steps / ITERS_PER_SOLVE)
+    return max(1, min(EVENT_STRIDE_MAX, launches // MIN_TIMED_LAUNCHES))
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -67,28 +77,55 @@ def _free_port() -> int:
 
 def launch_ranks(n: int, argv) -> int:
     """Start n rank processes of this script (one per GPU) and wait for them.  Runs in a parent that has not loaded
-    the library or touched HIP; the children are fresh interpreters (subprocess, never exec after GPU init)."""
+    the library or touched HIP; the children are fresh interpreters (subprocess, never exec after GPU init).
+    MASTER_PORT is only the base of the side channel's port search (rank 0 binds the first free port above it and the
+    others probe the same list, authenticated by a token that contains this launch's random id), so it does not matter
+    if somebody else takes the probed port between here and there.  Whatever ends the launcher -- a rank that fails, an
+    exception, SIGINT / SIGTERM -- ends the remaining ranks too."""
+    import signal
     import uuid
     port = _free_port()
     run = uuid.uuid4().hex
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), TSCM_RDZV_PORT=str(port), TSCM_RDZV_RUN=run)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def _raise(signum, _frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old = {sig: signal.signal(sig, _raise) for sig in (signal.SIGINT, signal.SIGTERM)}
     rc = 0
-    pending = list(procs)
-    while pending:
-        for p in list(pending):
-            code = p.poll()
-            if code is None:
-                continue
-            pending.remove(p)
-            if code != 0:
-                rc = rc or code
-                for q in pending:             # a rank died: its peers would wait for it forever
-                    q.terminate()
-        time.sleep(0.05)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), TSCM_RDZV_RUN=run)
+            env.pop("TSCM_RDZV_PORT", None)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:             # a rank died: its peers would wait for it forever
+                        q.terminate()
+            time.sleep(0.05)
+    except BaseException:
+        rc = rc or 130
+        raise
+    finally:
+        for p in procs:                           # nothing outlives the launcher
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 
@@ -113,6 +150,9 @@ class _StubSolver:
 
     def kernel_time(self, enable=True):
         return 0, 0.0
+
+    def exchange_time(self):
+        return (0, 0.0), (0, 0.0)
 
     def close(self):
         pass
@@ -295,21 +335,32 @@ def main():
     natural = solver.solve_resident(reset=True, **extra)
     if args.warmup > 0:
         run_iterations(solver, args.warmup, **extra)
-    # HIP events around every EVENT_STRIDE-th launch of the dominant kernel (each pair holds the stream for ~6 us)
-    solver.kernel_time(enable=0 if os.environ.get("TSCM_BENCH_NO_EVENTS") else EVENT_STRIDE)
+    # HIP events around every stride-th launch of the dominant kernel (each pair holds the stream for ~6 us) -- and,
+    # with a communicator, around every stride-th all-reduce of each kind
+    stride = 0 if os.environ.get("TSCM_BENCH_NO_EVENTS") else event_stride(args.steps)
+    solver.kernel_time(enable=stride)
+    solver.exchange_time()
     barrier()
     t0 = time.perf_counter()
     run_iterations(solver, args.steps, **extra)
     barrier()
     elapsed_local = time.perf_counter() - t0
     launches, kms = solver.kernel_time(enable=False)
+    (n_xt, ms_xt), (n_xh, ms_xh) = solver.exchange_time()
     elapsed = chan.allreduce_max(elapsed_local) if chan else elapsed_local
+    if stub:
+        n_local = int(full.n_corners / world)
+    else:
+        from tscm_calib_amd.problem import shard_frames
+        n_local = full.n_corners if world == 1 else shard_frames(full, rank, world).n_corners
+    # what every rank did, gathered on rank 0 (N > 1): the first run on real hardware has to explain itself
+    mine = {"rank": rank, "corners": n_local, "us_per_step": 1e6 * elapsed_local / args.steps,
+            "eval_kernel_us": 1e3 * kms / max(launches, 1), "eval_launches_timed": launches,
+            "allreduce_T_us": 1e3 * ms_xt / max(n_xt, 1), "allreduce_H_us": 1e3 * ms_xh / max(n_xh, 1),
+            "allreduces_timed": [n_xt, n_xh]}
+    per_rank = chan.gather(mine) if chan else [mine]
 
     if rank == 0:
-        n_local = int(full.n_corners / world) if stub else None
-        if not stub:
-            from tscm_calib_amd.problem import shard_frames
-            n_local = full.n_corners if world == 1 else shard_frames(full, rank, world).n_corners
         avg_ms = kms / max(launches, 1)
         flops = n_local * FLOP_PER_CORNER
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -317,7 +368,11 @@ def main():
         roof = {
             "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else "k_eval_gram", "bound": "mfma",
             "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-            "traffic": None, "launches": launches, "launches_timed_every": EVENT_STRIDE, "avg_launch_ms": avg_ms,
+            "traffic": None, "launches": launches, "timed_launches": launches, "launches_timed_every": stride, "avg_launch_ms": avg_ms,
+            # share of the step the dominant kernel accounts for; the iteration-0 evaluation of every solve is in the
+            # timed region (and among the timed launches) but is not a step
+            "share_of_step": (avg_ms * (args.steps + math.ceil(args.steps / ITERS_PER_SOLVE)) / (1e3 * elapsed)) if elapsed > 0 else 0.0,
+            "iteration0_evals_in_timed_region": math.ceil(args.steps / ITERS_PER_SOLVE),
             "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
             "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
         }
@@ -365,6 +420,19 @@ def main():
                               "create_seconds_incl_H2D_of_observations": t_create},
             "roofline": roof,
         }
+        if world > 1 or multi:
+            # per iteration every rank runs its share of the kernels plus two sum all-reduces (T after the Schur
+            # complement, H_stage after the evaluation); an all-reduce's HIP-event time includes the wait for the
+            # slowest peer, so rank_compute_us = the rank's step time minus its two collectives is a lower bound of
+            # the time its own kernels need
+            out["corners_per_rank"] = [r["corners"] for r in per_rank]
+            out["rank_compute_us"] = [r["us_per_step"] - r["allreduce_T_us"] - r["allreduce_H_us"] for r in per_rank]
+            out["allreduce_ms"] = {
+                "T": max(r["allreduce_T_us"] for r in per_rank) * 1e-3, "H_stage": max(r["allreduce_H_us"] for r in per_rank) * 1e-3,
+                "per_step": max(r["allreduce_T_us"] + r["allreduce_H_us"] for r in per_rank) * 1e-3,
+                "timed_every": stride, "note": "HIP events on the solver stream around ncclAllReduce, max over ranks of each rank's mean",
+            }
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(full, local_rank)
         print(json.dumps(out), flush=True)

@@ -13,6 +13,7 @@
 #include <tscm/tscm_calib.hpp>
 
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 
 template <typename T>
@@ -63,6 +64,20 @@ int main(int argc, char **argv)
                mono0.summary.rmse, mono0.intrinsic_[0], cameras[0].intrinsic_[0]);
 
         tscm::MultiCalib mul_calib(cameras, worlds);           // main.cpp:233
+        if (argc > 4 && std::string(argv[4]) == "sharded") {
+            // the multi-GPU form of the same call (one process per GPU in production; here one rank): the frames are
+            // sharded over the ranks of a communicator, every rank ends with all parameters
+            unsigned char id[TSCM_UNIQUE_ID_BYTES];
+            tscm_comm *comm = nullptr;
+            if (tscm_comm_unique_id(id) != 0 || tscm_comm_create(id, 0, 1, 0, &comm) != 0) { fprintf(stderr, "tscm_comm_create: %s\n", tscm_last_error()); return 1; }
+            tscm_options o;
+            tscm_default_options(&o, 0);
+            o.exec_flags |= TSCM_EXEC_KEEP_SINGLE_RANK_COMM;    // run the communicator code path although it has one rank
+            mul_calib.set_sharding(0, 1, comm);
+            mul_calib.calibrate(&o);
+            mul_calib.set_sharding(0, 1, nullptr);
+            tscm_comm_destroy(comm);
+        } else
         mul_calib.calibrate();                                 // main.cpp:234
         printf("%s  iterations %d  final cost %.6e\n", mul_calib.summary.message, mul_calib.summary.num_iterations - 1, mul_calib.summary.final_cost);
         for (int m = 0; m < C; ++m) printf("camera_%d reprojection error: %.6f\n", m, mul_calib.camera_error[m]);

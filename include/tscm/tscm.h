@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define TSCM_ABI_VERSION 2   /* 2: tscm_problem.board_pose_constant (appended; zero-initialised structs keep their meaning) */
+#define TSCM_ABI_VERSION 3   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
+                             /*    zero-initialised structs keep their meaning)                                  */
 
 enum {
     TSCM_OK = 0,
@@ -102,7 +103,20 @@ typedef struct tscm_options {
                                          /* fp32 (packed VALU + fp32 MFMA), projection, */
                                          /* residuals, cost and the whole linear solve  */
                                          /* stay fp64: north_star's 1e-3 tier          */
+    int exec_flags;                      /* 0 (default).  Execution variants that do   */
+                                         /* not change the mathematics (TSCM_EXEC_*)   */
 } tscm_options;
+
+/* tscm_options.exec_flags.  The results are the same bits with or without the first two; they select code paths that
+ * a one-GPU box would otherwise never run (the tests use them), the third one is fault injection. */
+enum {
+    TSCM_EXEC_SEPARATE_T_REDUCE = 1,       /* keep the Schur-complement tile reduction a launch of its own instead of   */
+                                           /* riding in the reduced solve's launch (what every communicator run does)   */
+    TSCM_EXEC_KEEP_SINGLE_RANK_COMM = 2,   /* run the communicator code path (two all-reduces, separate control step)   */
+                                           /* even when the attached communicator has one rank                          */
+    TSCM_EXEC_TEST_WITHHOLD_HANDOFF = 0x100 /* TEST ONLY: one producer of the fused hand-off never reports in; the solve */
+                                           /* must end with TSCM_E_HIP within the hand-off's time bound                 */
+};
 
 /* ceres::IterationSummary subset */
 typedef struct tscm_iteration {
@@ -179,6 +193,11 @@ void tscm_solver_destroy(tscm_solver *s);
  * enable = 0: off; n >= 1: bracket every n-th launch (an event pair delays the stream by a few microseconds, so a
  * benchmark samples instead of timing every launch). */
 int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches, double *total_ms);
+/* ... and of the two per-iteration exchanges of a sharded solve (the all-reduce of the Schur-complement tiles T and of
+ * the staged camera tiles H_stage; the reference has no counterpart -- SURVEY 5: "measure it separately from compute"),
+ * sampled at the same rate while tscm_solver_kernel_time has the timers armed: number of timed collectives and their
+ * total milliseconds since the last call.  Zeros without a communicator. */
+int tscm_solver_exchange_time(tscm_solver *s, int *n_T, double *ms_T, int *n_H, double *ms_H);
 
 /* One-shot drop-ins ------------------------------------------------------------
  * tscm_solve_multi replaces the Ceres block of MultiCalib::calibrate()

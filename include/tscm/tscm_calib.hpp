@@ -367,9 +367,10 @@ public:
         P.cam_pose_constant = cc.data(); P.mono = 0;
         tscm_options o;
         if (options) o = *options; else tscm_default_options(&o, 0);
-        if (world_ > 1) {
+        if (comm_) {
             // frame-sharded over the ranks of set_sharding(): every rank builds this same problem, keeps the boards it owns
-            // and ends with ALL parameters updated (tscm.h, "multi-GPU")
+            // and ends with ALL parameters updated (tscm.h, "multi-GPU").  (A one-rank communicator is legal: the library
+            // then solves as if there were none, unless the options carry TSCM_EXEC_KEEP_SINGLE_RANK_COMM.)
             tscm_solver *s = nullptr;
             check(tscm_solver_create_sharded(&P, device_, rank_, world_, &s));
             int rc = tscm_solver_set_comm(s, comm_);

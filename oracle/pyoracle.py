@@ -85,8 +85,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        # TSCM_ORACLE_LIB: another build of the same sources (tests/test_oracle_sanitizers.py loads liboracle_asan.so
+        # into an interpreter started with the sanitizer runtime preloaded)
+        path = os.environ.get("TSCM_ORACLE_LIB")
+        if not path:
+            build()
+            path = _LIB_PATH
+        L = C.CDLL(path)
         dp = C.POINTER(C.c_double)
         L.orc_default_options.argtypes = [C.POINTER(OrcOptions), C.c_int]
         L.orc_project.argtypes = [dp, dp, dp]

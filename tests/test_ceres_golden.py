@@ -54,3 +54,24 @@ def test_hip_path_against_real_ceres(hip_device, path):
     with api.Solver(p) as s:
         summary = s.solve()
     _compare(gold, summary, p)
+
+
+PINNED_FIXTURES = {        # sha256 of what tools/ceres_harness/export_problems.py writes (tests/golden/README.md)
+    "config1_mono": "7b9d375e973957dc919f88684e6e4fd44a8bc4be0671f77abd262d685c594985",
+    "rig4x6": "9e7e4945bc9897ef1acf562d38d5aa149a3e1867bcfc2215f6021b9aab2c8116",
+    "rig4x30": "53b5953c90f2af9987b6d0c5ca6a6bef43e5819ca5f80e60b3727375887455e5",
+    "mono40": "fd464e6cf01292fe7a317bf6854753b44ca9ddf603e684f788c930b6a3061e90",
+    "config3": "3447fb5d2f624ae21026bb3320aab6218440db5701c8b17f8bf8bb35480b6a4b",
+}
+
+
+def test_exported_fixture_problems_are_the_pinned_ones(tmp_path):
+    """A Ceres golden made on another machine is only worth something if it was made from the same inputs: the fixture
+    problems are regenerated from seeds, and their bytes are pinned here and in tests/golden/README.md."""
+    import hashlib
+    from export_problems import FIXTURES, write_problem
+    assert set(FIXTURES) == set(PINNED_FIXTURES)
+    for name, make in FIXTURES.items():
+        f = tmp_path / (name + ".bin")
+        write_problem(make(), str(f))
+        assert hashlib.sha256(f.read_bytes()).hexdigest() == PINNED_FIXTURES[name], name

@@ -26,7 +26,7 @@ def _cmp_trace(gs, os_, rtol=1e-6):
 
 def test_native_library_is_loaded(hip_device):
     from tscm_calib_amd import lib
-    assert lib.lib().tscm_abi_version() == 2
+    assert lib.lib().tscm_abi_version() == 3
     assert lib.lib().tscm_device_count() >= 1
 
 
@@ -372,19 +372,19 @@ def test_reduced_solver_geometries(hip_device, C, free_gauge):
         assert max(H.param_rel_err(pg, po).values()) < 1e-6
 
 
-def test_rccl_code_path_single_rank(hip_device, monkeypatch):
+def test_rccl_code_path_single_rank(hip_device):
     """The multi-GPU code path (RCCL all-reduce of T, grouped sum/max all-reduce of the staged camera
-    tiles, separate k_control) on a one-rank communicator: must reproduce the single-GPU path bit for bit."""
+    tiles, separate k_control) on a one-rank communicator (tscm_options.exec_flags: TSCM_EXEC_KEEP_SINGLE_RANK_COMM):
+    must reproduce the single-GPU path bit for bit."""
     p = H.small_rig(4, 10, seed=33)
     ref = p.copy().normalised()
     with api.Solver(ref) as s:
         rs = s.solve()
-    monkeypatch.setenv("TSCM_FORCE_COMM", "1")
     comm = api.Comm(api.Comm.unique_id(), 0, 1, 0)
     q = p.copy().normalised()
     with api.Solver(q) as s:
         s.set_comm(comm)
-        qs = s.solve()
+        qs = s.solve(exec_flags=lib.EXEC_KEEP_SINGLE_RANK_COMM)
         s.set_comm(None)
     comm.close()
     assert qs["num_iterations"] == rs["num_iterations"] and qs["message"] == rs["message"]
@@ -392,20 +392,42 @@ def test_rccl_code_path_single_rank(hip_device, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [1, 3])
-def test_fused_and_separate_T_reduction_agree_bit_for_bit(hip_device, monkeypatch, cfg):
+def test_fused_and_separate_T_reduction_agree_bit_for_bit(hip_device, cfg):
     """One GPU, <= 4 cameras: the T reduction rides in the reduced solve's launch (workgroups behind an arrival counter).
-    TSCM_NO_FUSED_REDUCE=1 at solver creation keeps it a launch of its own (the path every communicator run takes);
-    the summation order of a tile entry is the same in both, so the whole solve must be."""
+    tscm_options.exec_flags = TSCM_EXEC_SEPARATE_T_REDUCE keeps it a launch of its own (the path every communicator run
+    takes); the summation order of a tile entry is the same in both, so the whole solve must be."""
     p = synth.make_config(cfg)
     a, b = p.copy().normalised(), p.copy().normalised()
     with api.Solver(a) as s:
         sa = s.solve()
-    monkeypatch.setenv("TSCM_NO_FUSED_REDUCE", "1")
     with api.Solver(b) as s:
-        sb = s.solve()
+        sb = s.solve(exec_flags=lib.EXEC_SEPARATE_T_REDUCE)
     assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
     assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
     assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
+def test_late_handoff_is_a_hard_error(hip_device):
+    """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
+    counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld
+    (fault injection, TSCM_EXEC_TEST_WITHHOLD_HANDOFF) the call must return TSCM_E_HIP within the time bound -- not hang,
+    and not go on as a rejected step -- and the same solver must work again afterwards (monotonic counter, reset per solve)."""
+    import time
+    from tscm_calib_amd.lib import TscmError
+    p = H.small_rig(4, 10, seed=33)
+    ref = p.copy().normalised()
+    with api.Solver(ref) as s:
+        rs = s.solve()
+    q = p.copy().normalised()
+    with api.Solver(q) as s:
+        t0 = time.time()
+        with pytest.raises(TscmError) as e:
+            s.solve(exec_flags=lib.EXEC_TEST_WITHHOLD_HANDOFF)
+        assert e.value.code == -3 and "hand-off" in str(e.value)            # TSCM_E_HIP
+        assert time.time() - t0 < 10.0
+        assert np.array_equal(q.intr, p.copy().normalised().intr)          # the caller's parameters were not touched
+        qs = s.solve()                                                      # ... and the next solve is unaffected
+    assert qs["num_iterations"] == rs["num_iterations"] and np.array_equal(q.intr, ref.intr) and np.array_equal(q.board_rt, ref.board_rt)
 
 
 def test_invalid_arguments(hip_device):

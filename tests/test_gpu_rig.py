@@ -229,3 +229,30 @@ def test_rig_init_and_calibrate_with_many_cameras(hip_device, C):
     q = rig.problem_from_rig(inp, g)
     s = api.calibrate(q, hip_device)
     assert s["termination_type"] == 0 and s["rmse"] < 0.25
+
+
+def test_cpp_class_mirror_sharded_branch(hip_device, tmp_path):
+    """MultiCalib::set_sharding + the sharded branch of calibrate() (tscm_solver_create_sharded / set_comm / solve with a
+    real RCCL communicator, here of one rank with TSCM_EXEC_KEEP_SINGLE_RANK_COMM so that the two all-reduces and the
+    separate control step do run): compiled from the same header, the result is the plain calibrate()'s, bit for bit."""
+    import os, struct, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "multicalib_demo")
+    csrc = os.path.join(root, "tscm_calib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++11", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "multicalib_demo.cpp"),
+                           "-L", csrc, "-ltscm_hip", "-Wl,-rpath," + csrc, "-o", exe])
+    p = synth.make_problem(4, 12, 29)
+    inp = synth.make_rig_input(p)
+    C, B, n = inp.n_cameras, inp.n_boards, inp.n_points
+    with open(tmp_path / "rig.bin", "wb") as f:
+        f.write(struct.pack("5i", C, B, n, 9, 6))
+        for a in (inp.worlds, inp.intr, inp.has, inp.Rt, inp.pix_u, inp.pix_v):
+            f.write(np.ascontiguousarray(a).tobytes())
+    res = {}
+    for mode in ("plain", "sharded"):
+        args = [exe, str(tmp_path / "rig.bin"), str(tmp_path / f"{mode}.bin"), str(tmp_path / f"{mode}.yaml")] + ([mode] if mode == "sharded" else [])
+        out = subprocess.check_output(args).decode()
+        assert "average reproject error" in out
+        res[mode] = open(tmp_path / f"{mode}.bin", "rb").read()
+    nd = 6 * C + 9 * C + 6 * B + C + 2
+    assert res["plain"][:8 * nd + 8] == res["sharded"][:8 * nd + 8]          # parameters, error report, termination, iterations

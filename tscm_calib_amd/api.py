@@ -94,6 +94,13 @@ class Solver:
         _l.check(_l.lib().tscm_solver_kernel_time(self._h, int(enable), C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def exchange_time(self):
+        """((timed, total_ms) of the all-reduce of T, (timed, total_ms) of the all-reduce of H_stage) since the last call;
+        sampled at kernel_time()'s rate.  Zeros without a communicator."""
+        nt, nh, mt, mh = C.c_int(0), C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        _l.check(_l.lib().tscm_solver_exchange_time(self._h, C.byref(nt), C.byref(mt), C.byref(nh), C.byref(mh)))
+        return (nt.value, mt.value), (nh.value, mh.value)
+
 
 class Comm:
     """RCCL communicator (one per process/GPU)."""

@@ -146,6 +146,7 @@ struct CtrlHead {
     int done, term_type, term_reason, iteration;
     int cur, lin_fail, num_successful, num_unsuccessful;
     int num_invalid, n_log, lm_iterations, fin_count;   // fin_count: arrival counter of k_finalize_eval
+    int fault, pad0;                    // fault: a device-side hand-off timed out (sticky; the host turns it into TSCM_E_HIP)
     double radius, decrease_factor;
     double x_cost, x_norm, gmax, gnorm;
     double model_cam, stepsq_cam;
@@ -1594,9 +1595,15 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem
 // has requested everything else.  Unlike the producers of the earlier hand-off experiments these have written 20 KB, not
 // megabytes, when they release -- and a launch with its 5 us is gone.
 constexpr int kFusedEntries = 256 / kTSlices;        // 16 entries x 16 slices = the solver's 256 threads
-constexpr int kSpinMax = 1 << 24;                   // x ~64 ns = a second: only a hand-off that never comes fails the step (instead of hanging the stream)
+// A hand-off that has not come after this long is a device fault, not a numerical event: the solver workgroup sets the
+// sticky ctrl->fault together with ctrl->done (every later kernel of the stream exits at once) and the host returns
+// TSCM_E_HIP.  s_memrealtime ticks: 100 MHz whatever the shader clock does.
+constexpr long long kHandoffTimeoutTicks = 50 * 1000 * 1000;          // 0.5 s
+// epoch: 1, 2, ... = the number of fused launches of this solve so far, this one included (the host resets the
+// counter to zero in front of every solve).  The arrival counter is MONOTONIC: a launch waits for epoch * producers,
+// so late arrivals of a launch that was given up on can never be mistaken for this launch's.
 template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
-__global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S)
+__global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S, int epoch, int withhold)
 {
     constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
     if constexpr (FUSED) {
@@ -1610,7 +1617,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
             t_reduce_block<kFusedEntries>(S, bid, part, cb, ce, red);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) {
+            if (threadIdx.x == 0 && !(withhold && blockIdx.x == 1)) {      // (withhold: fault injection, TSCM_EXEC_TEST_WITHHOLD_HANDOFF)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_fetch_add(S.t_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1673,25 +1680,34 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     for (int r = 0; r < TS; ++r)
 #pragma unroll
         for (int c = 0; c < TS; ++c) { const int oh = off[kMapH + r * TS + c]; hh[r][c] = oh >= 0 ? H[oh] : 0.0; }
-    int t_late = 0;
     if constexpr (FUSED) {
         // everything that does not depend on T is in flight; now the tiles of the other workgroups
+        __shared__ int s_late;
         if (tid == 0) {
-            const int need = (int)gridDim.x - 1;
-            int spins = 0;
-            while (__hip_atomic_load(S.t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && spins < kSpinMax) { __builtin_amdgcn_s_sleep(2); ++spins; }
-            t_late = spins >= kSpinMax;
+            const int need = epoch * ((int)gridDim.x - 1);
+            const long long t_start = wall_clock64();
+            int late = 0;
+            while (__hip_atomic_load(S.t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t_start > kHandoffTimeoutTicks) { late = 1; break; }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(S.t_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (late) {
+                // not a failed linear solve (that would merely shrink the trust region and go on): the stream's work stops here
+                S.ctrl->fault = 1; S.ctrl->term_type = 2; S.ctrl->done = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            }
+            s_late = late;
         }
         __syncthreads();
+        if (s_late) return;
     }
 #pragma unroll
     for (int r = 0; r < TS; ++r)
 #pragma unroll
         for (int c = 0; c < TS; ++c) { const int ot = off[kMapT + r * TS + c]; tt[r][c] = ot >= 0 ? S.T[ot] : 0.0; }
     PHASE_STAMP(ts0b);
-    if (tid == 0) s_fail = ctrl_fail | t_late;
+    if (tid == 0) s_fail = ctrl_fail;
     double a[TS][TS];
     const double inv_radius = 1.0 / radius;
 #pragma unroll

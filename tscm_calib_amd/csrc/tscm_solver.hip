@@ -20,6 +20,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace tscm;
@@ -86,16 +87,20 @@ struct tscm_solver {
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0, lds_gram = 0, lds_bs = 0;
     int bs_threads = 128;               // geometry of k_backsub_prep: 128 threads / 16 boards or 256 / 32
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
-    bool fuse_reduce = true;            // TSCM_NO_FUSED_REDUCE=1 (read at creation) keeps k_T_reduce a launch of its own
+    bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
+    int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
+    int withhold = 0;                   // this solve: TSCM_EXEC_TEST_WITHHOLD_HANDOFF
+    tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     // dominant-kernel timing
-    int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel with HIP events
-    unsigned eval_launches = 0;
+    int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel (and every n-th exchange) with HIP events
+    unsigned ev_count[3] = { 0, 0, 0 }; // occurrences so far, by kind: 0 dominant kernel, 1 exchange of T, 2 exchange of H_stage
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<int> ev_kind;
     size_t ev_used = 0;
-    int t_launches = 0;
-    double t_ms = 0.0;
+    int t_launches[3] = { 0, 0, 0 };
+    double t_ms[3] = { 0.0, 0.0, 0.0 };
 };
 
 template <typename T>
@@ -154,6 +159,7 @@ extern "C" void tscm_default_options(tscm_options *o, int mono)
     o->jacobi_scaling = 1;
     o->check_every = 4;
     o->jacobian_fp32 = 0;
+    o->exec_flags = 0;
 }
 
 static int validate(const tscm_problem *p)
@@ -601,7 +607,6 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.fac, (size_t)kFac * B))) return rc;
     if ((rc = dev_alloc(s, &S.pairpart, 256 * (size_t)P.n_tiles))) return rc;
     if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
-    s->fuse_reduce = getenv("TSCM_NO_FUSED_REDUCE") == nullptr;
     if ((rc = dev_alloc(s, &S.t_count, 1))) return rc;
     HIP_TRY(hipMemset(S.t_count, 0, sizeof(int)));
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
@@ -660,16 +665,22 @@ extern "C" int tscm_solver_create(const tscm_problem *p, int device, tscm_solver
     return tscm_solver_create_sharded(p, device, 0, 1, out);
 }
 
+static tscm_comm *effective_comm(const tscm_solver *s, int exec_flags)
+{
+    tscm_comm *c = s->comm_reg;
+    return (c && (c->world > 1 || c->group || (exec_flags & TSCM_EXEC_KEEP_SINGLE_RANK_COMM))) ? c : nullptr;
+}
+
 extern "C" int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm)
 {
     if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
     if (comm && comm->device != s->device) return fail(TSCM_E_INVALID, "communicator and solver live on different devices");
     if (comm && (comm->world != s->world || comm->rank != s->rank))
         return fail(TSCM_E_INVALID, "communicator rank / world differ from the solver's shard (tscm_solver_create_sharded)");
-    // a single-rank RCCL communicator is a no-op; TSCM_FORCE_COMM=1 keeps it anyway so that the RCCL code path
-    // (separate k_control, stream-ordered all-reduces) can be exercised on one GPU
-    const bool force = std::getenv("TSCM_FORCE_COMM") != nullptr;
-    s->comm = (comm && (comm->world > 1 || force || comm->group)) ? comm : nullptr;
+    // a single-rank RCCL communicator is a no-op unless a solve asks for its code path (separate k_control,
+    // stream-ordered all-reduces) with TSCM_EXEC_KEEP_SINGLE_RANK_COMM: effective_comm()
+    s->comm_reg = comm;
+    s->comm = effective_comm(s, 0);
     return 0;
 }
 
@@ -691,27 +702,39 @@ extern "C" int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, c
 }
 
 // one launch of the dominant kernel, optionally bracketed by HIP events on the solver's stream
+// HIP-event brackets on the solver's stream: every `timing`-th occurrence of a kind (0 = the dominant kernel, 1 = the
+// exchange of T, 2 = the exchange of H_stage) is timed; an event pair holds the stream for a few microseconds, so the
+// sampling keeps the measurement out of the result
+static int timed_begin(tscm_solver *s, int kind, hipStream_t stream, hipEvent_t *e1)
+{
+    *e1 = nullptr;
+    if (!(s->timing > 0 && (s->ev_count[kind]++ % (unsigned)s->timing) == 0)) return 0;
+    if (s->ev_used == s->ev.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+        s->ev.emplace_back(a, b);
+        s->ev_kind.push_back(0);
+    }
+    s->ev_kind[s->ev_used] = kind;
+    const hipEvent_t e0 = s->ev[s->ev_used].first;
+    *e1 = s->ev[s->ev_used].second;
+    ++s->ev_used;
+    HIP_TRY(hipEventRecord(e0, stream));
+    return 0;
+}
+
+// one launch of the dominant kernel, optionally bracketed by HIP events on the solver's stream
 static int launch_eval(tscm_solver *s, int cand)
 {
     const DevProblem &P = s->P;
     if (P.n_chunks == 0) return 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    // (an event pair costs about 3 us of stream time per side: sampling keeps the measurement out of the result)
-    const bool timed = s->timing > 0 && (s->eval_launches++ % (unsigned)s->timing) == 0;
-    if (timed) {
-        if (s->ev_used == s->ev.size()) {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-            s->ev.emplace_back(a, b);
-        }
-        e0 = s->ev[s->ev_used].first; e1 = s->ev[s->ev_used].second; ++s->ev_used;
-        HIP_TRY(hipEventRecord(e0, s->stream));
-    }
+    hipEvent_t e1 = nullptr;
+    if (int rc = timed_begin(s, 0, s->stream, &e1)) return rc;
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
     if (s->f32_jacobian) hipLaunchKernelGGL(k_eval_gram_f32, dim3(P.n_chunks / 4), dim3(256), s->lds_eval32, s->stream, P, s->S, cand);
     else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
     else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
-    if (timed) HIP_TRY(hipEventRecord(e1, s->stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, s->stream));
     return 0;
 }
 
@@ -720,7 +743,8 @@ static int collect_timing(tscm_solver *s)
     for (size_t i = 0; i < s->ev_used; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev[i].first, s->ev[i].second));
-        s->t_ms += ms; s->t_launches += 1;
+        const int k = s->ev_kind[i];
+        s->t_ms[k] += ms; s->t_launches[k] += 1;
     }
     s->ev_used = 0;
     return 0;
@@ -729,11 +753,22 @@ static int collect_timing(tscm_solver *s)
 extern "C" int tscm_solver_kernel_time(tscm_solver *s, int enable, int *launches, double *total_ms)
 {
     if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
-    if (launches) *launches = s->t_launches;
-    if (total_ms) *total_ms = s->t_ms;
-    s->t_launches = 0; s->t_ms = 0.0;
+    if (launches) *launches = s->t_launches[0];
+    if (total_ms) *total_ms = s->t_ms[0];
+    s->t_launches[0] = 0; s->t_ms[0] = 0.0;
     s->timing = enable < 0 ? 0 : enable;
-    s->eval_launches = 0;
+    s->ev_count[0] = s->ev_count[1] = s->ev_count[2] = 0;
+    return 0;
+}
+
+extern "C" int tscm_solver_exchange_time(tscm_solver *s, int *n_T, double *ms_T, int *n_H, double *ms_H)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    if (n_T) *n_T = s->t_launches[1];
+    if (ms_T) *ms_T = s->t_ms[1];
+    if (n_H) *n_H = s->t_launches[2];
+    if (ms_H) *ms_H = s->t_ms[2];
+    s->t_launches[1] = s->t_launches[2] = 0; s->t_ms[1] = s->t_ms[2] = 0.0;
     return 0;
 }
 
@@ -764,13 +799,18 @@ static int exchange(LmRun &run, bool t_buffer)
     if (!s0->comm) return 0;
     const size_t n = t_buffer ? 256 * (size_t)s0->P.n_bids : 256 * (size_t)s0->P.C + kScal + s0->P.world;
     if (n == 0) return 0;
+    hipEvent_t e1 = nullptr;
     if (s0->comm->group) {
         tscm_local_group *g = s0->comm->group;      // pointer tables: [0, world) the members' T, [world, 2 world) their H_stage (run_lm)
+        if (int rc = timed_begin(s0, t_buffer ? 1 : 2, g->stream, &e1)) return rc;
         hipLaunchKernelGGL(k_xchg_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g->stream, g->d_ptrs + (t_buffer ? 0 : g->world), g->world, n);
+        if (e1) HIP_TRY(hipEventRecord(e1, g->stream));
         return 0;
     }
     double *buf = t_buffer ? s0->S.T : s0->S.H_stage;
+    if (int rc = timed_begin(s0, t_buffer ? 1 : 2, s0->stream, &e1)) return rc;
     NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, s0->comm->comm, s0->stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, s0->stream));
     return 0;
 }
 
@@ -813,10 +853,10 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        if (fused_reduce(s)) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + P.n_bids * (256 / kFusedEntries)), dim3(256), s->lds_solve, s->stream, P, S);
-        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S);
-        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S);
-        else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S);
+        if (fused_reduce(s)) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + P.n_bids * (256 / kFusedEntries)), dim3(256), s->lds_solve, s->stream, P, S, ++s->t_epoch, s->withhold);
+        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S, 0, 0);
+        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S, 0, 0);
+        else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S, 0, 0);
         else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
         if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
         if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
@@ -852,8 +892,34 @@ struct LmRunGuard {
 
 static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset);
 
-// An RCCL rank that leaves the loop on an error would leave its peers blocked in their next all-reduce: abort the
-// communicator so that they fail too (the communicator is unusable afterwards, like after any RCCL error).
+// Waits for the solver's stream.  With a multi-rank RCCL communicator a peer that has failed (or died) leaves this
+// rank's all-reduce kernel spinning for ever -- over the intra-node transports an ncclCommAbort on the FAILING rank does
+// not reach the others -- so the wait is a poll with a watchdog: no completion within kCommWatchdogSeconds aborts the
+// communicator locally and fails the call with TSCM_E_RCCL.  (A whole solve of the largest supported problem is well
+// under a second of device time; the bound only has to exceed the start-up skew between the rank processes.)
+constexpr double kCommWatchdogSeconds = 60.0;
+static int sync_stream(tscm_solver *s)
+{
+    tscm_comm *c = s->comm;
+    if (!c || c->group || !c->comm || c->world <= 1) { HIP_TRY(hipStreamSynchronize(s->stream)); return 0; }
+    const double t0 = wall();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { HIP_TRY(q); }
+        if (wall() - t0 > kCommWatchdogSeconds) {
+            (void)ncclCommAbort(c->comm);
+            c->comm = nullptr;
+            return fail(TSCM_E_RCCL, "no progress on the solver stream within the watchdog interval: a peer rank has failed or is gone (communicator aborted)");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
+// An RCCL rank that leaves the loop on an error aborts its communicator (unusable afterwards, like after any RCCL
+// error).  That does NOT unblock its peers by itself: they leave their next all-reduce through the watchdog of
+// sync_stream (TSCM_E_RCCL), or are torn down by whoever started the ranks (bench.py's launcher ends all ranks as soon
+// as one exits non-zero).  A failed rank must not be re-used: start a fresh process.
 static int run_lm(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset)
 {
     const int rc = run_lm_inner(run, opt_in, sums, reset);
@@ -876,6 +942,12 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     if (opt.max_num_iterations < 0 || opt.max_num_iterations > TSCM_MAX_ITERATIONS) return fail(TSCM_E_INVALID, "max_num_iterations must be in [0, 255]");
     HIP_TRY(hipSetDevice(s0->device));
     LmRunGuard guard{ run };
+    for (tscm_solver *s : run.m) {
+        s->comm = effective_comm(s, opt.exec_flags);
+        s->fuse_reduce = !(opt.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE);
+        s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
+        s->t_epoch = 0;
+    }
     if (s0->comm && !s0->comm->group && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
     if (s0->comm && s0->comm->group) {
         // a local group runs on ONE stream: lock step by stream order, no events
@@ -931,11 +1003,11 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         if (it % check_every == 0 || it == opt.max_num_iterations) {
             // every rank takes the same decisions from the same all-reduced bits: polling one member is enough
             HIP_TRY(hipMemcpyAsync(s0->h_ctrl, s0->S.ctrl, 64, hipMemcpyDeviceToHost, s0->stream));
-            HIP_TRY(hipStreamSynchronize(s0->stream));
+            if ((rc = sync_stream(s0))) return rc;
             done = s0->h_ctrl->done != 0;
         }
     }
-    HIP_TRY(hipStreamSynchronize(s0->stream));
+    if ((rc = sync_stream(s0))) return rc;
     const double t1 = wall();
     HIP_TRY(hipGetLastError());
     for (size_t r = 0; r < run.m.size(); ++r) {
@@ -945,6 +1017,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         tscm_summary *sum = &sums[r];
         HIP_TRY(hipMemcpy(h, S.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
         if ((rc = collect_timing(s))) return rc;
+        if (h->fault) return fail(TSCM_E_HIP, "a device-side hand-off (Schur-complement tiles -> reduced solve) did not arrive within its time bound: the solve was stopped");
         if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
         // the accepted point lives in buffer `cur`; make it buffer 0 for the next resident solve
         if (h->cur != 0) {
@@ -978,8 +1051,8 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
 extern "C" int tscm_solver_solve_resident(tscm_solver *s, const tscm_options *opt_in, tscm_summary *sum, int reset)
 {
     if (!s || !sum) return fail(TSCM_E_INVALID, "NULL argument");
-    if (s->comm && s->comm->group && s->world > 1) return fail(TSCM_E_INVALID, "member of a local group: use tscm_solver_solve_group");
-    if (s->world > 1 && !s->comm) return fail(TSCM_E_INVALID, "sharded solver without a communicator (tscm_solver_set_comm)");
+    if (s->comm_reg && s->comm_reg->group && s->world > 1) return fail(TSCM_E_INVALID, "member of a local group: use tscm_solver_solve_group");
+    if (s->world > 1 && !s->comm_reg) return fail(TSCM_E_INVALID, "sharded solver without a communicator (tscm_solver_set_comm)");
     LmRun run;
     run.m.push_back(s);
     return run_lm(run, opt_in, sum, reset);
@@ -992,7 +1065,7 @@ extern "C" int tscm_solver_solve_group(tscm_solver **solvers, int n, const tscm_
     for (int r = 0; r < n; ++r) {
         tscm_solver *s = solvers[r];
         if (!s || s->world != n || s->rank != r) return fail(TSCM_E_INVALID, "solvers[r] must be shard r of n (tscm_solver_create_sharded)");
-        if (n > 1 && (!s->comm || !s->comm->group || s->comm->group != solvers[0]->comm->group))
+        if (n > 1 && (!s->comm_reg || !s->comm_reg->group || s->comm_reg->group != solvers[0]->comm_reg->group))
             return fail(TSCM_E_INVALID, "the solvers of a group need the communicators of ONE tscm_comm_create_local call");
         run.m.push_back(s);
     }
@@ -1021,7 +1094,7 @@ extern "C" int tscm_solver_gather_boards(tscm_solver *s, double *board_rt)
 {
     if (!s || (!board_rt && s->B_total)) return fail(TSCM_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(s->device));
-    if (!s->comm || s->world == 1 || s->comm->group) return tscm_solver_download_params(s, nullptr, nullptr, board_rt);   // local groups share the caller's array
+    if (!s->comm_reg || s->world == 1 || s->comm_reg->group) return tscm_solver_download_params(s, nullptr, nullptr, board_rt);   // local groups share the caller's array
     if (s->B_total == 0) return 0;
     double *full = nullptr;
     const size_t n = 6 * (size_t)s->B_total;
@@ -1032,7 +1105,7 @@ extern "C" int tscm_solver_gather_boards(tscm_solver *s, double *board_rt)
         if (int rc = tscm_solver_download_params(s, nullptr, nullptr, mine.data())) return rc;     // owned boards at their own positions
         HIP_TRY(hipMemcpy(full, mine.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
-    NCCL_TRY(ncclAllReduce(full, full, n, ncclDouble, ncclSum, s->comm->comm, s->stream));
+    NCCL_TRY(ncclAllReduce(full, full, n, ncclDouble, ncclSum, s->comm_reg->comm, s->stream));
     HIP_TRY(hipMemcpyAsync(board_rt, full, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;

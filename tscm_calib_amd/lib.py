@@ -17,6 +17,10 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libtscm_hip.so")
 UNIQUE_ID_BYTES = 128
 MAX_ITERATIONS = 255
+# tscm_options.exec_flags (tscm.h)
+EXEC_SEPARATE_T_REDUCE = 1
+EXEC_KEEP_SINGLE_RANK_COMM = 2
+EXEC_TEST_WITHHOLD_HANDOFF = 0x100
 
 E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
            -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM"}
@@ -46,7 +50,7 @@ class COptions(C.Structure):
         ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
         ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
         ("max_num_consecutive_invalid_steps", C.c_int), ("jacobi_scaling", C.c_int), ("check_every", C.c_int),
-        ("jacobian_fp32", C.c_int),
+        ("jacobian_fp32", C.c_int), ("exec_flags", C.c_int),
     ]
 
 
@@ -106,7 +110,7 @@ EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_default_options",
     "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
-    "tscm_solver_kernel_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
+    "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
     "tscm_shard_frames", "tscm_solver_create_sharded", "tscm_comm_create_local", "tscm_solver_solve_group",
@@ -161,6 +165,7 @@ def lib():
     L.tscm_solver_destroy.argtypes = [vp]
     L.tscm_solver_destroy.restype = None
     L.tscm_solver_kernel_time.argtypes = [vp, C.c_int, ip, dp]
+    L.tscm_solver_exchange_time.argtypes = [vp, ip, dp, ip, dp]
     L.tscm_solve_multi.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary)]
     L.tscm_solve_mono.argtypes = [C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CSummary)]
     L.tscm_eval_functor.argtypes = [C.POINTER(CProblem), C.c_int, dp, dp, dp, dp, dp]

@@ -8,7 +8,8 @@ processes of a multi-GPU run must contain exactly one HIP runtime and one RCCL, 
 Rendezvous: the environment of `torchrun` / `python -m torch.distributed.run` (RANK, WORLD_SIZE, MASTER_ADDR,
 MASTER_PORT) or of bench.py's own launcher.  torchrun's c10d store owns MASTER_PORT itself, so rank 0 listens on
 the first free port of MASTER_PORT+1 .. MASTER_PORT+32 and the other ranks probe the same list; a token derived from
-the launch parameters keeps strangers (and stale runs) out.  TSCM_RDZV_PORT pins the port instead.
+the launch parameters and the launcher's process id keeps strangers (and stale ranks of earlier launches) out.
+TSCM_RDZV_PORT pins the port instead; TSCM_RDZV_NONCE replaces the process id (ranks started by different parents).
 """
 from __future__ import annotations
 
@@ -24,7 +25,11 @@ _SPAN = 32
 
 
 def _token(addr: str, port: int, world: int) -> bytes:
-    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + os.environ.get("TSCM_RDZV_RUN", "")
+    """What the ranks of ONE launch share and a stale rank of an earlier launch does not: the launcher's random id
+    (bench.py's own launcher), and the launcher process itself -- under a static torchrun rendezvous
+    TORCHELASTIC_RUN_ID is a constant and MASTER_PORT may be re-used, but every rank of a launch is a child of the same
+    agent process (single node: the side channel is a loopback star)."""
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + os.environ.get("TSCM_RDZV_RUN", "") + "|" + os.environ.get("TSCM_RDZV_NONCE", str(os.getppid()))
     return hashlib.sha256(f"{addr}|{port}|{world}|{run}".encode()).digest()[:16]
 
 
