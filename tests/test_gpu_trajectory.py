@@ -36,7 +36,7 @@ def _compare(gs, os_, upto=None, cost_rtol=1e-5, radius_rtol=2e-2):
         assert a["iteration"] == b["iteration"] and a["step_is_valid"] == b["step_is_valid"]
         assert abs(a["cost"] - b["cost"]) <= cost_rtol * abs(b["cost"]), (a["iteration"], a["cost"], b["cost"])
         assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= radius_rtol * abs(b["trust_region_radius"]), a["iteration"]
-        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-3 * max(b["step_norm"], 1e-9), a["iteration"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= radius_rtol * max(b["step_norm"], 1e-9), a["iteration"]
 
 
 def _both(p, **kw):
@@ -84,11 +84,15 @@ def test_config2_mono_forced_50_iterations_noise_floor(hip_device):
     pg, po, gs, os_ = _both(synth.make_config(2))
     rel = [abs(it["cost_change"]) / it["cost"] for it in os_["iterations"]]
     assert _pattern(os_).count("r") >= 3
-    # compared in full up to the last iteration before the oracle's cost changes have been below 1e-7 of the cost ...
+    # everything (decisions, cost, radius, step norm) up to the first iteration whose cost change is below 1e-7 of the
+    # cost in the oracle's own run: from there on rho -- a ratio of two differences of nearly equal numbers -- carries a
+    # few digits, and the radius rule radius / max(1/3, 1 - (2 rho - 1)^3) passes that on to everything after it
     settled = next(i for i in range(2, len(rel)) if rel[i] < 1e-7)
-    upto = min(51, settled + 20)                      # ... plus twenty more: in practice ~30 of the 50 agree to the last decision
-    _compare(gs, os_, upto=upto)
-    # ... and by cost to the end: both crawl down the same valley
+    assert 5 <= settled <= 15
+    _compare(gs, os_, upto=settled)
+    # ... the decisions for ten more iterations (in practice about thirty of the fifty agree) ...
+    assert _pattern(gs)[:settled + 10] == _pattern(os_)[:settled + 10]
+    # ... and the cost to the end: both crawl down the same valley
     for a, b in zip(gs["iterations"], os_["iterations"]):
         assert abs(a["cost"] - b["cost"]) <= 1e-6 * b["cost"]
     assert abs(gs["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
