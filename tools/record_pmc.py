@@ -2,7 +2,10 @@
 """Turns the two PMC passes of tools/pmc.sh (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs of `bench.py --steps 10
 --warmup 0 --no-cpu-baseline`) into profiles/pmc_eval_gram.json / pmc_side_kernels.json entries.
 
-    python tools/record_pmc.py gpurun_out/pmc_<fetch tag> gpurun_out/pmc_<write tag> [config]
+    python tools/record_pmc.py gpurun_out/pmc_<fetch tag> gpurun_out/pmc_<write tag> [config] [gpurun_out/pmc_<sq pass> ...]
+
+Further pass directories (SQ_* / GRBM_* counters) are averaged over the k_eval_gram dispatches into the entry's
+`sq_round3` block.
 
 Units and corrections as MI355X_MICROARCH.md prescribes and tools/calib_fetch.hip confirmed on these boxes: both counters
 report KB; FETCH_SIZE counts half of the bytes of this library's 8 B/lane and 16 B/lane loads (x2), WRITE_SIZE is exact.
@@ -35,6 +38,7 @@ def per_kernel(d, counter):
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
     config = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    sq_dirs = sys.argv[4:]
     fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
     write, _ = per_kernel(write_dir, "WRITE_SIZE")
     sha = bench._kernel_src_sha()
@@ -49,15 +53,27 @@ def main():
     n_corners = {4: 2160000}.get(config)
     keep = {k: v for k, v in doc.get(f"config{config}", {}).items() if k.startswith("sq")}       # SQ counter blocks are recorded separately
     doc[f"config{config}"] = {
-        "kernel_src_sha": sha, "round": 2,
+        "kernel_src_sha": sha, "round": 3,
         "FETCH_SIZE_KB_per_launch": ev["FETCH_SIZE_KB_per_launch"], "WRITE_SIZE_KB_per_launch": ev["WRITE_SIZE_KB_per_launch"],
         "read_bytes_corrected": ev["read_bytes_corrected"], "hbm_bytes_per_launch": ev["hbm_bytes_per_launch"],
         "algorithmic_bytes_per_launch": n_corners * bench.BYTES_PER_CORNER if n_corners else None,
         "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/pmc.sh), averaged over the k_eval_gram dispatches; "
-                "hbm = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes). Writes are the kernel's OUTPUT: 132 doubles per view of Schur records + per-workgroup camera tiles.",
+                "hbm = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes). Writes are the kernel's OUTPUT: 102 doubles per view of Schur records (132 in round 2) + per-workgroup camera tiles.",
     }
     doc[f"config{config}"].update(keep)
-    doc[f"config{config}_all_kernels_round2"] = {"kernel_src_sha": sha, "per_launch": kernels}
+    if sq_dirs:
+        sq = {}
+        for d in sq_dirs:
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+            tot, n = collections.defaultdict(float), collections.Counter()
+            for r in csv.DictReader(open(f)):
+                if "k_eval_gram" in r["Kernel_Name"]:
+                    tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+            for c in tot:
+                sq[c] = tot[c] / n[c]
+        sq["passes"] = "tools/pmc.sh, one rocprofv3 --pmc pass per directory: " + ", ".join(os.path.basename(d) for d in sq_dirs) + "; per k_eval_gram dispatch"
+        doc[f"config{config}"]["sq_round3"] = sq
+    doc[f"config{config}_all_kernels_round3"] = {"kernel_src_sha": sha, "per_launch": kernels}
     json.dump(doc, open(path, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:34s} read {v['read_bytes_corrected'] / 1e6:7.2f} MB  write {v['write_bytes'] / 1e6:7.2f} MB")

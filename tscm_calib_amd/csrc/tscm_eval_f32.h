@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
         const int off = off_next;
         off_next = off + cnt;
         wave_lds_fence();                       // previous view's epilogue has finished with LDS
+#if TSCM_PRIO
+        set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));      // priority by progress: see k_eval_gram
+#endif
         const cptr4 cst = (cptr4)(S.vconst + (size_t)kVStride * view);                 // this view's constants, doubles
         const fptr4 cs = (fptr4)(S.vconst + (size_t)kVStride * view + kVFloatOff);     // ... and floats
         d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
             if (c0 == 0) {
                 // Prefetch of the next view, issued once the current view's observations have been consumed: the
                 // loads reuse the same registers (no copy that would have to wait for them), and everything
-                // between here and their use at the top of the next view is 13 unconditional stores.
+                // between here and their use at the top of the next view is four unconditional stores.
                 // Always issued (the block's last view re-reads itself; lanes past the corner count read past
                 // the end of the buffer, i.e. zero): unconditional loads keep the vmcnt bookkeeping exact.
                 const int vn = min(view + 1, vend - 1);

@@ -107,7 +107,7 @@ __device__ __forceinline__ void buf_store_2f64(__amdgpu_buffer_rsrc_t r, unsigne
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, (int)voff, 0, 0);
 }
 
-// Wave priority experiments of k_eval_gram (make PRIO=n; s_setprio takes an immediate, p is wave-uniform)
+// Wave priority rule of k_eval_gram (see there; s_setprio takes an immediate, p is wave-uniform)
 #ifndef TSCM_PRIO
 #define TSCM_PRIO 10
 #endif
@@ -547,22 +547,18 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     // record stores -- is left inside the view loop.
     int off_next = vb < ve ? P.view_obs[vb] : 0;
 #if TSCM_PRIO
-#ifdef TSCM_PRIO_BLK
-    const int wid = (int)(blockIdx.x >> 8) & 3;
-#else
-    const int wid = (int)__builtin_amdgcn_s_getreg(6148) & 3;      // HW_ID.wave_id: slot of this wave on its SIMD
-#endif
+    // Wave priority by progress.  The four waves of a SIMD share the fp64 pipe, and the arbiter serves the OLDEST wave
+    // first: left alone they finish one after the other (46 / 57 / 68 / 79 us into the launch at config 4), and the last
+    // ten microseconds of the kernel run on one wave per SIMD, whose dependent chains cannot fill the pipe.  A wave that
+    // is further along in its chunk than its neighbours gives way: the priority falls from 3 to 0 over each half of
+    // the chunk (eighths of its views, mod 4), so whoever is behind by an eighth outranks whoever is ahead, and the
+    // four finish within 6 us of each other (59 / 61 / 63 / 65 us after the epilogue rewrite).  The assignment of views
+    // to waves is untouched: the results are the same bits.  (TSCM_PRIO=0: off; 4, 5: the other rules of the A/B runs in
+    // profiles/r03_eval_gram_ab.txt -- by phase: geometry high, MFMA low; by quarters of the chunk.)
     auto prio = [&](int ph, int view) {
-        if (TSCM_PRIO == 1) { if (ph == 0) set_prio(view + wid); }
-        else if (TSCM_PRIO == 2) set_prio(view + ph + wid);
-        else if (TSCM_PRIO == 3) set_prio(ph == 0 ? 1 : ph == 3 ? 2 : 3);
-        else if (TSCM_PRIO == 4) set_prio(ph == 0 ? 3 : ph == 3 ? 1 : 0);
+        if (TSCM_PRIO == 4) set_prio(ph == 0 ? 3 : ph == 3 ? 1 : 0);
         else if (TSCM_PRIO == 5) { if (ph == 0) set_prio(3 - min(3, 4 * (view - vb) / max(1, ve - vb))); }
-        else if (TSCM_PRIO == 6) { if (ph == 0) set_prio((int)(__builtin_amdgcn_s_memtime() >> 12) + wid); }
-        else if (TSCM_PRIO == 7) { if (ph == 0) set_prio(3 - ((view - vb) & 3)); }
-        else if (TSCM_PRIO == 8) { const int q = 3 - min(3, 4 * (view - vb) / max(1, ve - vb)); set_prio(ph == 0 ? min(3, q + 1) : ph == 3 ? q : max(0, q - 1)); }
-        else if (TSCM_PRIO == 9) { const int h = 2 * (view - vb) < ve - vb ? 2 : 0; set_prio(h + (ph == 0 || ph == 3 ? 1 : 0)); }
-        else if (TSCM_PRIO == 10) { if (ph == 0) set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4)); }
+        else { if (ph == 0) set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4)); }
     };
 #define PRIO(ph, view) prio(ph, view)
 #else
@@ -665,7 +661,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
             if (c0 == 0) {
                 // Prefetch of the next view, issued once the current view's observations have been consumed: the
                 // loads reuse the same registers (no copy that would have to wait for them), and everything
-                // between here and their use at the top of the next view is 13 unconditional stores.
+                // between here and their use at the top of the next view is four unconditional stores.
                 // Always issued (the block's last view re-reads itself; lanes past the corner count read past
                 // the end of the buffer, i.e. zero): unconditional loads keep the vmcnt bookkeeping exact.
                 const int vn = min(view + 1, vend - 1);
