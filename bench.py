@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--poses-fixed", action="store_true",
                     help="hold every board / view pose block constant (the intrinsics-only form of config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exec-flags", type=int, default=0,
+                    help="tscm_options.exec_flags for every solve (A/B runs: 4 = TSCM_EXEC_GRAM_16X16, 1 = separate T reduction)")
     ap.add_argument("--jacobian-fp32", action="store_true",
                     help="north_star's 1e-3 tier: fp32 derivatives + fp32 MFMA contraction (default: all fp64, the headline)")
     args = ap.parse_args()
@@ -332,6 +334,8 @@ def main():
 
     # natural solve (reference options, termination tests on): untimed, doubles as warmup
     extra = dict(jacobian_fp32=1) if args.jacobian_fp32 else {}
+    if args.exec_flags:
+        extra["exec_flags"] = args.exec_flags
     natural = solver.solve_resident(reset=True, **extra)
     if args.warmup > 0:
         run_iterations(solver, args.warmup, **extra)

@@ -114,6 +114,8 @@ enum {
                                            /* riding in the reduced solve's launch (what every communicator run does)   */
     TSCM_EXEC_KEEP_SINGLE_RANK_COMM = 2,   /* run the communicator code path (two all-reduces, separate control step)   */
                                            /* even when the attached communicator has one rank                          */
+    TSCM_EXEC_GRAM_16X16 = 4,              /* the Gram contraction of the dominant kernel on v_mfma_f64_16x16x4 (one tile,  */
+                                           /* rounds 1-3a) instead of three v_mfma_f64_4x4x4_4b per four rows (A/B runs)   */
     TSCM_EXEC_TEST_WITHHOLD_HANDOFF = 0x100 /* TEST ONLY: one producer of the fused hand-off never reports in; the solve */
                                            /* must end with TSCM_E_HIP within the hand-off's time bound                 */
 };

@@ -26,6 +26,14 @@ def record(config):
         n = lib.lib().tscm_debug_wave_timeline(buf.ctypes.data_as(ctypes.c_void_p), 8192)
         if n <= 0:
             raise SystemExit(f"tscm_debug_wave_timeline: {n}")
+        ph = np.zeros(5 * 8192, dtype=np.int64)
+        if hasattr(lib.lib(), "tscm_debug_wave_phases") and lib.lib().tscm_debug_wave_phases(ph.ctypes.data_as(ctypes.c_void_p), 8192) > 0 and ph.any():
+            ph = ph.reshape(-1, 5)[:n]
+            ph = ph[ph.sum(axis=1) > 0]
+            nv = p.n_views / max(1, len(ph))
+            names = ["geometry", "MFMA u-rows", "v-row copy", "MFMA v-rows", "epilogue"]
+            print("shader clocks per view and wave (mean over the waves, k_eval_gram4): " +
+                  ", ".join(f"{nm} {ph[:, k].mean() / nv:.0f}" for k, nm in enumerate(names)) + f"; total {ph.sum(axis=1).mean() / nv:.0f}")
     rows = []
     for w in range(n):
         hw, xcc, t0, t1 = (int(x) for x in buf[4 * w:4 * w + 4])

@@ -1,0 +1,345 @@
+// tscm_eval_gram4.h -- the dominant kernel with the Gram contraction on v_mfma_f64_4x4x4_4b_f64 (round 3).
+//
+// Same inputs, same outputs, same bits as k_eval_gram<58> (tscm_kernels.h); what changes is the matrix instruction.
+// Measured on gfx950 (tools/ubench_mfma64.hip, four waves per SIMD): v_mfma_f64_16x16x4_f64 occupies the fp64 pipe for
+// ~90 clocks (2048 flop: 23 flop/clock/SIMD -- the 49 TFLOP/s ceiling bench.py reports), v_mfma_f64_4x4x4_4b_f64 for
+// ~12.5 clocks (4 blocks of 4x4x4 = 512 flop: 41 flop/clock/SIMD), and the 16x16 tile computes every off-diagonal
+// block of the symmetric Gram twice.  With the 16 tile columns in four groups of four, the ten block pairs (I <= J)
+// fit THREE 4x4x4 instructions per four rows (twelve block slots): 37.5 clocks instead of 90.
+//
+// Operand layout of the instruction (tools/probe_mfma4x4.hip): lane l: k = l / 16, block = (l % 16) / 4, A_b[i][k] with
+// i = l % 4, B_b[k][j] with j = l % 4; result D_b[i][j] in lane 16 i + 4 b + j.  So lane (c = l % 16, k = l / 16)
+// supplies element (tile column c, row 4 t + k) as A operand -- the vector N the 16x16 kernel reads -- block b of the
+// result holds rows of column group b, and the B operand decides which column group they meet:
+//   q0  B = N                         pairs (0,0) (1,1) (2,2) (3,3)
+//   q1  B = N rotated by one group     pairs (0,1) (1,2) (2,3) (3,0)
+//   q2  B = groups [2, 3, 1, 1]        pairs (0,2) (1,3) (2,1) (3,1)
+// i.e. all ten unordered pairs, and every pair (b, 1) with the column group of the t_c columns as the COLUMN group:
+// there the three t_c entries of a tile column sit in the three adjacent lanes of a quad, and the t_b rows
+// (J_tb = J_tc R_c) are three quad-broadcast DPP moves and three FMAs per register -- no LDS crossbar, no cross-row move.
+// Entries of the 4x4x4 result are bit-identical to those of the 16x16x4 tile (tools/check_mfma4x4.hip), the epilogue
+// performs the same operations in the same order, and the camera tile is handed on in the 16x16 layout and column
+// numbering of k_eval_gram: the whole solve is bit-identical (tools/regress_bits.py).
+//
+// Tile columns here (groups of four):  0-2 w_b, 3 r | 4-6 t_c, 7 alpha | 8-10 w_c, 11 f* | 12 one*, 13 xi, 14 lambda, 15 zero.
+// LDS tile: element (k-step t, column c, row k) at double t * 68 + 4 c + (k ^ 2 (c >> 3)):
+//   * the three operand vectors are conflict-free ds_read_b64 (32-lane groups, banks mod 64: columns c and c + 8 would
+//     share a bank pair, the xor puts them on complementary halves);
+//   * a corner's lane writes row (t, k) = (lane / 4, lane % 4) of a column: 16 lanes x 8 bytes on 32 distinct banks
+//     (k-step stride 68 doubles = 8 dwords mod 32).
+// Boards of up to 56 corners (one pass, 14 k-steps); larger boards and the fp32 tier stay with k_eval_gram / _f32.
+#pragma once
+// (included from tscm_kernels.h inside namespace tscm)
+
+constexpr int kG4Stride = 68;                   // doubles per k-step of the tile
+constexpr int kG4KS = 14;                       // k-steps: 56 rows
+constexpr int kG4Tile = kG4KS * kG4Stride;      // 952 doubles per wave (also covers the 512-double camera-tile exchange)
+__host__ __device__ inline int eval_gram4_lds_doubles(int n_points) { return kG4Tile + 2 * n_points; }
+
+// tile columns of this kernel
+constexpr int kG4Wb = 0, kG4R = 3, kG4Tc = 4, kG4Al = 7, kG4Wc = 8, kG4F = 11, kG4One = 12, kG4Xi = 13, kG4Lam = 14;
+// ... -> tile column of k_eval_gram (the camera tile is handed on in that numbering)
+__device__ __forceinline__ constexpr int g4_old_col(int c)
+{
+    return c < 3 ? kTcWb + c : c == 3 ? kTcR : c < 7 ? tc_tc(c - 4) : c == 7 ? kTcAl : c < 11 ? kTcWc + (c - 8) : c == 11 ? kTcF
+         : c == 12 ? kTcOne : c == 13 ? kTcXi : c == 14 ? kTcLam : 15;
+}
+// ... -> W column (F index) of the record; f* / one* are the first of a (u-part, v-part) pair; -1: none (w_b, zero)
+__device__ __forceinline__ constexpr int g4_wcol(int c)
+{
+    return c < 3 ? -1 : c == 3 ? kFR : c < 7 ? kWcolTc + (c - 4) : c == 7 ? 12 : c < 11 ? c - 8 : c == 11 ? 6 : c == 12 ? 8 : c == 13 ? 10 : c == 14 ? 11 : -1;
+}
+// column group block b of the result meets in instruction q
+__device__ __forceinline__ constexpr int g4_cgroup(int b, int q) { return q == 0 ? b : q == 1 ? ((b + 1) & 3) : (b == 0 ? 2 : b == 1 ? 3 : 1); }
+__device__ __forceinline__ int g4_elem(int c, int k) { return 4 * c + (k ^ ((c >> 3) << 1)); }     // within a k-step
+
+// one k-step: three operand vectors, three instructions; operands requested D k-steps ahead
+template <int KS, int D, int T = 0>
+__device__ __forceinline__ void gram4_steps(unsigned aN, unsigned aR, unsigned aB, double (&n)[KS], double (&r)[KS], double (&b)[KS], double (&acc)[3])
+{
+    if constexpr (T < KS) {
+        if constexpr (T + D < KS) {
+            n[T + D] = ds_read_f64<8 * kG4Stride * (T + D)>(aN);
+            r[T + D] = ds_read_f64<8 * kG4Stride * (T + D)>(aR);
+            b[T + D] = ds_read_f64<8 * kG4Stride * (T + D)>(aB);
+        }
+        constexpr int newer = 3 * (KS - 1 - T < D ? KS - 1 - T : D);      // requests younger than this k-step's three
+        lgkm_wait<newer + 2>(n[T]);
+        if constexpr (T == 0) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], n[T], 0.0, 0, 0, 0);
+        else acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], n[T], acc[0], 0, 0, 0);
+        lgkm_wait<newer + 1>(r[T]);
+        if constexpr (T == 0) acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], r[T], 0.0, 0, 0, 0);
+        else acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], r[T], acc[1], 0, 0, 0);
+        lgkm_wait<newer>(b[T]);
+        if constexpr (T == 0) acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], b[T], 0.0, 0, 0, 0);
+        else acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], b[T], acc[2], 0, 0, 0);
+        gram4_steps<KS, D, T + 1>(aN, aR, aB, n, r, b, acc);
+    }
+}
+template <int KS, int D, int T = 0>
+__device__ __forceinline__ void gram4_prime(unsigned aN, unsigned aR, unsigned aB, double (&n)[KS], double (&r)[KS], double (&b)[KS])
+{
+    if constexpr (T < D && T < KS) {
+        n[T] = ds_read_f64<8 * kG4Stride * T>(aN);
+        r[T] = ds_read_f64<8 * kG4Stride * T>(aR);
+        b[T] = ds_read_f64<8 * kG4Stride * T>(aB);
+        gram4_prime<KS, D, T + 1>(aN, aR, aB, n, r, b);
+    }
+}
+__device__ __forceinline__ void gram4_full(unsigned aN, unsigned aR, unsigned aB, double (&acc)[3])
+{
+    constexpr int D = 2;
+    double n[kG4KS], r[kG4KS], b[kG4KS];
+    gram4_prime<kG4KS, D>(aN, aR, aB, n, r, b);
+    gram4_steps<kG4KS, D>(aN, aR, aB, n, r, b, acc);
+}
+
+// t_b entry of this lane's quad: lanes j = 0, 1, 2 of a quad hold the t_c0, t_c1, t_c2 entries of one tile column; lane
+// j = l gets R_c[0][l] x0 + R_c[1][l] x1 + R_c[2][l] x2 in the operation order of store_view_record (c_m = R_c[m][l])
+__device__ __forceinline__ double quad_tb(double x, double c0, double c1, double c2)
+{
+    const double x0 = dpp_f64<0x00>(x), x1 = dpp_f64<0x55>(x), x2 = dpp_f64<0xAA>(x);
+    return fma(c2, x2, fma(c0, x0, c1 * x1));
+}
+
+__global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S, int cand)
+{
+#ifdef TSCM_ABLATE
+    constexpr int ablate = TSCM_ABLATE;      // profiling builds only (make ABLATE=n): 1 no MFMA phases, 2 no epilogue, 4 no geometry
+#else
+    constexpr int ablate = 0;
+#endif
+    const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
+#ifdef TSCM_WAVE_TIMELINE
+    const long long tl_t0 = wall_clock64();
+    const int tl_iter = S.ctrl->iteration;
+    long long tl_ph[5] = { 0, 0, 0, 0, 0 };      // shader clocks per phase, summed over the chunk: geometry, MFMA u, copy, MFMA v, epilogue
+#define TL_STAMP(var) const long long var = (long long)__builtin_readcyclecounter()
+#define TL_ADD(k, a, b) tl_ph[k] += (b) - (a)
+#else
+#define TL_STAMP(var)
+#define TL_ADD(k, a, b)
+#endif
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lds_wave = eval_gram4_lds_doubles(P.n_points);
+    double *lds = lds_all + (size_t)wave * lds_wave;
+    double *Fl = lds;                          // the tile: holds the u-rows, then the v-rows
+    double *bxy = lds + kG4Tile;
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + wave;
+    const int cam = P.chunk_cam[chunk];
+    for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
+    const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
+    double camU[3] = { 0.0, 0.0, 0.0 }, camV[3] = { 0.0, 0.0, 0.0 };
+    for (int i = lane; i < kG4Tile; i += 64) Fl[i] = 0.0;     // rows of lanes without a corner, the zero column, the padding
+    int prev_nv = 0;
+    double pf_u = 0.0, pf_v = 0.0;
+    int warm = 0;
+    if (ctrl_done) return;
+    const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
+    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
+    const cptr4 ccs = (cptr4)(S.cconst[tgt] + kCStride * cam);
+    auto CC = [&](int k) { return ccs[k]; };
+    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
+    const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
+    // ---- lane roles ------------------------------------------------------------------------------------------------
+    // as a corner: row (t, k) of the tile
+    double *fu_lo = Fl + (lane >> 2) * kG4Stride + (lane & 3), *fu_hi = Fl + (lane >> 2) * kG4Stride + ((lane & 3) ^ 2);
+    // as an MFMA lane: k = i = lane / 16, c16 = 4 b + j
+    const int li = lane >> 4, c16 = lane & 15, lb = c16 >> 2, lj = c16 & 3;
+    const unsigned lds0 = lds_addr(Fl);
+    const unsigned aN = lds0 + 8u * (unsigned)g4_elem(c16, li);
+    const unsigned aR = lds0 + 8u * (unsigned)g4_elem((c16 + 4) & 15, li);
+    const unsigned aB = lds0 + 8u * (unsigned)g4_elem(4 * g4_cgroup(lb, 2) + lj, li);
+    // R_c[m][j] of this lane's quad position (t_b rows), fixed for the chunk
+    const double rc0 = lj == 0 ? ccs[0] : lj == 1 ? ccs[1] : ccs[2];
+    const double rc1 = lj == 0 ? ccs[3] : lj == 1 ? ccs[4] : ccs[5];
+    const double rc2 = lj == 0 ? ccs[6] : lj == 1 ? ccs[7] : ccs[8];
+    // record offsets of this lane's entries in the seven stores of a view (bytes inside the view's W / E record; lanes
+    // without an entry store past the end of the buffer).  Columns by group: see g4_wcol.
+    constexpr unsigned BAD = 0xffffe000u;
+    unsigned o1e = BAD, o1w = BAD, o2 = BAD, o3e = BAD, o4 = BAD, o5 = BAD, o6 = BAD;
+    {
+        const int b = lb, j = lj, i = li;
+        auto W = [](int wcol, int row) { return 8u * (unsigned)(6 * wcol + row); };
+        const int f1 = g4_wcol(4 + i), f1j = g4_wcol(4 + j), f2 = g4_wcol(8 + i), f2j = g4_wcol(8 + j), f3 = g4_wcol(12 + i);
+        if (b == 0 && j < 3 && i < 3) { o1e = 8u * (unsigned)(6 * j + i); o3e = 8u * (unsigned)(6 * i + 3 + j); }
+        if (b == 0 && j == 3 && i < 3) o1w = W(kFR, i);                      // w_b rows x r
+        if (b == 1 && j < 3) o1w = W(f1, 3 + j);                             // t_b rows x (t_c | alpha)
+        if (b == 0 && i < 3) o2 = W(f1j, i);                                 // w_b rows x (t_c | alpha)
+        if (b == 0 && i == 3 && j < 3) o2 = W(kFR, 3 + j);                   // t_b rows x r
+        if (b == 3 && j < 3 && i < 3) o2 = W(f3, j);                         // w_b rows x (one* | xi | lambda), held transposed
+        if (b == 0 && i < 3) o4 = W(f2j, i);                                 // w_b rows x (w_c | f*)
+        if (b == 2 && j < 3) o4 = W(f2, 3 + j);                              // t_b rows x (w_c | f*)
+        if (b == 3 && j < 3 && i < 3) o4 = W(f3, 3 + j);                     // t_b rows x (one* | xi | lambda)
+        if (b == 3 && i == 0 && j < 3) { o5 = W(9, j); o6 = W(9, 3 + j); }   // v-row parts: cy
+        if (b == 0 && j == 3 && i < 3) o6 = W(7, i);                         // ... fy
+        if (b == 2 && i == 3 && j < 3) o6 = W(7, 3 + j);
+    }
+    int off_next = vb < ve ? P.view_obs[vb] : 0;
+    for (int vbase = vb; vbase < ve; vbase += 64) {
+    const int vend = min(ve, vbase + 64);
+    int m_cnt = 0, m_slot = 0;
+    if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
+    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));
+    {
+        const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
+        if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
+    }
+    for (int view = vbase; view < vend; ++view) {
+        const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
+        off_next += cnt;
+        wave_lds_fence();                       // the previous view's MFMA phase has finished with the tile
+#if TSCM_PRIO
+        set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));      // priority by progress: see k_eval_gram
+#endif
+        TL_STAMP(ts0);
+        const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);
+        auto VC = [&](int k) { return vcs[k]; };
+        const bool valid = lane < cnt;
+        double fv[16];                          // v-rows wait in registers until the u-rows have been consumed (index = tile column)
+        auto PUT = [&](int c, double u, double v) { (c < 8 ? fu_lo : fu_hi)[4 * c] = u; fv[c] = v; };
+        if (valid && !(ablate & 4)) {
+            const double x = bxy[2 * lane], y = bxy[2 * lane + 1];
+            const double ou = pf_u, ov = pf_v;
+            // board -> world -> camera (multi_calib.h:158-167)
+            const double Pw0 = x * VC(0) + y * VC(3) + VC(6);
+            const double Pw1 = x * VC(1) + y * VC(4) + VC(7);
+            const double Pw2 = x * VC(2) + y * VC(5) + VC(8);
+            const double X = CC(0) * Pw0 + CC(1) * Pw1 + CC(2) * Pw2 + CC(9);
+            const double Y = CC(3) * Pw0 + CC(4) * Pw1 + CC(5) * Pw2 + CC(10);
+            const double Z = CC(6) * Pw0 + CC(7) * Pw1 + CC(8) * Pw2 + CC(11);
+            const double fx = CC(39), fy = CC(40), xi = CC(43), lam = CC(44), beta = CC(45);
+            // triple sphere (multi_calib.h:170-178)
+            const double rho2 = X * X + Y * Y;
+            double d1, id1, d2, id2, d3, id3;
+            sqrt_and_inverse(rho2 + Z * Z, d1, id1);
+            const double z1 = Z + xi * d1;
+            sqrt_and_inverse(rho2 + z1 * z1, d2, id2);
+            const double z2 = z1 + lam * d2;
+            sqrt_and_inverse(rho2 + z2 * z2, d3, id3);
+            const double k = z2 + beta * d3;
+            const double ik = fast_rcp(k);
+            const double mx = X * ik, my = Y * ik;
+            const double c1 = 1.0 + xi * Z * id1;
+            const double c2 = 1.0 + lam * z1 * id2;
+            const double c3 = 1.0 + beta * z2 * id3;
+            const double q = beta * id3 + c3 * (lam * id2 + c2 * xi * id1);
+            const double kz = c1 * c2 * c3;
+            const double fxk = fx * ik, fyk = fy * ik;
+            // -A = -d(u,v)/dPc  (the t_c columns)
+            const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
+            const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
+            PUT(kG4Tc + 0, n00, n10);
+            PUT(kG4Tc + 1, n01, n11);
+            PUT(kG4Tc + 2, n02, n12);
+            // w_b: -A (x e_k0 + y e_k1)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const double h0 = x * VC(9 + 6 * kk) + y * VC(12 + 6 * kk);
+                const double h1 = x * VC(10 + 6 * kk) + y * VC(13 + 6 * kk);
+                const double h2 = x * VC(11 + 6 * kk) + y * VC(14 + 6 * kk);
+                PUT(kG4Wb + kk, n00 * h0 + n01 * h1 + n02 * h2, n10 * h0 + n11 * h1 + n12 * h2);
+            }
+            // w_c: -A (dR_c/dw_k Pw)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const double g0 = CC(12 + 9 * kk + 0) * Pw0 + CC(12 + 9 * kk + 1) * Pw1 + CC(12 + 9 * kk + 2) * Pw2;
+                const double g1 = CC(12 + 9 * kk + 3) * Pw0 + CC(12 + 9 * kk + 4) * Pw1 + CC(12 + 9 * kk + 5) * Pw2;
+                const double g2 = CC(12 + 9 * kk + 6) * Pw0 + CC(12 + 9 * kk + 7) * Pw1 + CC(12 + 9 * kk + 8) * Pw2;
+                PUT(kG4Wc + kk, n00 * g0 + n01 * g1 + n02 * g2, n10 * g0 + n11 * g1 + n12 * g2);
+            }
+            // f* and one*
+            PUT(kG4F, -mx, -my);
+            PUT(kG4One, -1.0, -1.0);
+            // xi, lambda, alpha: -du/dk * dk/dparam
+            const double hu = fxk * mx, hv = fyk * my;
+            const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * CC(46);
+            PUT(kG4Xi, hu * kxi, hv * kxi);
+            PUT(kG4Lam, hu * klam, hv * klam);
+            PUT(kG4Al, hu * kal, hv * kal);
+            // residual = observed - projected (multi_calib.h:192-193)
+            PUT(kG4R, ou - (fx * mx + CC(41)), ov - (fy * my + CC(42)));
+        } else if (lane < prev_nv) {
+#pragma unroll
+            for (int c = 0; c < kTcols; ++c) (c < 8 ? fu_lo : fu_hi)[4 * c] = 0.0;
+        }
+        {
+            // prefetch of the next view (see k_eval_gram): observations, and the constant record into the L2
+            const int vn = min(view + 1, vend - 1);
+            const int cn = view + 1 < vend ? __builtin_amdgcn_readlane(m_cnt, vn - vbase) : 0;
+            warm = __builtin_amdgcn_raw_buffer_load_b32(r_vc, lane < 4 ? 64 * lane : (int)0xffffe000u, (int)(8u * (unsigned)kVStride * (unsigned)vn), 0);
+            pf_u = buf_load_f64(r_u, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
+            pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
+        }
+        prev_nv = cnt;
+        wave_lds_fence();
+        TL_STAMP(ts1);
+        double accU[3] = { 0.0, 0.0, 0.0 }, accV[3] = { 0.0, 0.0, 0.0 };
+        if (!(ablate & 1)) gram4_full(aN, aR, aB, accU);
+        wave_lds_fence();
+        TL_STAMP(ts2);
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < kTcols; ++c) (c < 8 ? fu_lo : fu_hi)[4 * c] = fv[c];
+        }
+        wave_lds_fence();
+        TL_STAMP(ts3);
+        if (!(ablate & 1)) gram4_full(aN, aR, aB, accV);
+        TL_STAMP(ts4);
+        asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { camU[q] += accU[q]; camV[q] += accV[q]; }
+        // ---- epilogue: the view's record (same values, same operation order as store_view_record) ------------------
+        if (!(ablate & 2)) {
+            int le = lane;
+            asm volatile("" : "+v"(le));         // lane predicates are rebuilt per view instead of living in SGPR pairs
+            const int b = (le >> 2) & 3, i = le >> 4;
+            const unsigned slot = (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase);
+            const unsigned offW = 8u * (unsigned)kRecW * slot, offE = 8u * ((unsigned)kRecW * (unsigned)P.V + (unsigned)kRecE * slot);
+            const double T0 = accU[0] + accV[0], T1 = accU[1] + accV[1], T2 = accU[2] + accV[2];
+            const double tb0 = quad_tb(T0, rc0, rc1, rc2), tb1 = quad_tb(T1, rc0, rc1, rc2), tb2 = quad_tb(T2, rc0, rc1, rc2);
+            const double tbU2 = quad_tb(accU[2], rc0, rc1, rc2);
+            const bool split1 = b == 3 && i == 0, split2 = (le & 3) == 3 ? b == 0 : (b == 2 ? i == 3 : (b == 3 && i == 0));
+            buf_store_f64(r_rec, o1e, offE, T0);
+            buf_store_f64(r_rec, o1w, offW, b == 1 ? tb0 : T0);
+            buf_store_f64(r_rec, o2, offW, split1 ? accU[1] : (i == 3 ? tb1 : T1));
+            buf_store_f64(r_rec, o3e, offE, tb1);
+            const double a4 = b != 0 ? tb2 : T2, u4 = b != 0 ? tbU2 : accU[2];
+            buf_store_f64(r_rec, o4, offW, split2 ? u4 : a4);
+            buf_store_f64(r_rec, o5, offW, T1 - accU[1]);
+            buf_store_f64(r_rec, o6, offW, a4 - u4);
+        }
+#ifdef TSCM_WAVE_TIMELINE
+        { TL_STAMP(ts5); TL_ADD(0, ts0, ts1); TL_ADD(1, ts1, ts2); TL_ADD(2, ts2, ts3); TL_ADD(3, ts3, ts4); TL_ADD(4, ts4, ts5); }
+#endif
+    }
+    }   // block of <= 64 views
+#ifdef TSCM_WAVE_TIMELINE
+    if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) {
+        g_timeline[4 * chunk] = (long long)__builtin_amdgcn_s_getreg(63492);
+        g_timeline[4 * chunk + 1] = (long long)__builtin_amdgcn_s_getreg(6164);
+        g_timeline[4 * chunk + 2] = tl_t0;
+        g_timeline[4 * chunk + 3] = wall_clock64();
+        for (int k = 0; k < 5; ++k) g_phase[5 * chunk + k] = tl_ph[k];
+    }
+#endif
+    // the camera tile leaves in the 16x16 layout and column numbering of k_eval_gram (both triangles: every entry is
+    // written by the lane that holds it and, mirrored, by the same lane; the doubly held pairs carry the same bits)
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int r = g4_old_col(4 * lb + li), c = g4_old_col(4 * g4_cgroup(lb, q) + lj);
+        lds[16 * r + c] = camU[q]; lds[16 * c + r] = camU[q];
+        lds[256 + 16 * r + c] = camV[q]; lds[256 + 16 * c + r] = camV[q];
+    }
+    __syncthreads();
+    {
+        const int t = threadIdx.x;
+        const size_t st = lds_wave;
+        double *part = S.campart + (size_t)512 * blockIdx.x;
+        part[t] = (lds_all[t] + lds_all[st + t]) + (lds_all[2 * st + t] + lds_all[3 * st + t]);
+        part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
+    }
+}

@@ -434,6 +434,7 @@ __device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, 
 #ifdef TSCM_WAVE_TIMELINE
 constexpr int kTimelineWaves = 8192;
 __device__ long long g_timeline[4 * kTimelineWaves];     // per wave of k_eval_gram: HW_ID, XCC_ID, start, end (10 ns ticks)
+__device__ long long g_phase[5 * kTimelineWaves];        // per wave of k_eval_gram4: shader clocks per phase, summed over its views
 #endif
 #ifndef TSCM_EXP
 #define TSCM_EXP 3     // bit 0: full tiles through gram_full (0 = round 2's paired loop, for A/B runs), bit 1: first MFMA with C = 0
@@ -794,6 +795,8 @@ __device__ __forceinline__ double row16_allmax(double v)
     v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
     return v;
 }
+
+#include "tscm_eval_gram4.h"
 
 // deterministic block reductions (256 threads)
 // Block reductions (256 threads; any multiple of 64 works): DPP butterfly inside each 16-lane row, two xor shuffles across the

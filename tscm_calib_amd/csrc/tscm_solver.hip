@@ -93,6 +93,8 @@ struct tscm_solver {
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
     int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
+    bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
+    size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4 (boards of <= 56 corners)
     // dominant-kernel timing
     int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel (and every n-th exchange) with HIP events
     unsigned ev_count[3] = { 0, 0, 0 }; // occurrences so far, by kind: 0 dominant kernel, 1 exchange of T, 2 exchange of H_stage
@@ -624,6 +626,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
 
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = 4 * sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points);
+    s->lds_eval4 = 4 * sizeof(double) * (size_t)eval_gram4_lds_doubles(p->n_points);
     // reduced solve on the compact system, 4 x 4 tiles, one more tile row for the right-hand side: 16 x 16 threads
     // (<= 4 cameras: at most 13 panels), 25 x 25 threads (<= 24 panels, e.g. 7 cameras with one constant pose: 85
     // columns) or 32 x 32 threads (8 cameras: <= 104 columns, 26 panels)
@@ -732,6 +735,7 @@ static int launch_eval(tscm_solver *s, int cand)
     if (int rc = timed_begin(s, 0, s->stream, &e1)) return rc;
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
     if (s->f32_jacobian) hipLaunchKernelGGL(k_eval_gram_f32, dim3(P.n_chunks / 4), dim3(256), s->lds_eval32, s->stream, P, s->S, cand);
+    else if (P.rp == 58 && !s->gram16) hipLaunchKernelGGL(k_eval_gram4, dim3(P.n_chunks / 4), dim3(256), s->lds_eval4, s->stream, P, s->S, cand);
     else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
     else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
     if (e1) HIP_TRY(hipEventRecord(e1, s->stream));
@@ -946,6 +950,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         s->comm = effective_comm(s, opt.exec_flags);
         s->fuse_reduce = !(opt.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE);
         s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
+        s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
         s->t_epoch = 0;
     }
     if (s0->comm && !s0->comm->group && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
@@ -1431,6 +1436,13 @@ extern "C" int tscm_debug_wave_timeline(long long *out, int max_waves)
     const int n = std::min(max_waves, tscm::kTimelineWaves);
     if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_timeline), sizeof(long long) * 4 * (size_t)n) != hipSuccess) return TSCM_E_HIP;
+    return n;
+}
+extern "C" int tscm_debug_wave_phases(long long *out, int max_waves)
+{
+    const int n = std::min(max_waves, tscm::kTimelineWaves);
+    if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_phase), sizeof(long long) * 5 * (size_t)n) != hipSuccess) return TSCM_E_HIP;
     return n;
 }
 #endif
