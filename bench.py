@@ -163,7 +163,7 @@ def _kernel_src_sha() -> str:
     records it with the traffic measurement."""
     import re
     h = hashlib.sha256()
-    for f in ("tscm_kernels.h", "tscm_math.h", "tscm_fastmath.h", "tscm_eval_f32.h"):
+    for f in ("tscm_kernels.h", "tscm_eval_gram4.h", "tscm_math.h", "tscm_fastmath.h", "tscm_eval_f32.h"):
         with open(os.path.join(ROOT, "tscm_calib_amd", "csrc", f), "r") as fh:
             code = re.sub(r"//[^\n]*", "", fh.read())
             h.update(re.sub(r"\s+", "", code).encode())
@@ -384,11 +384,15 @@ def main():
             # measured ceilings of THIS device, outside the timed region.  fp64 MFMA and fp64 VALU share the DP pipe
             # (no overlap: tools/ubench_fp64.hip), so the kernel's floor is the SUM of its two parts at their own rates
             import ctypes
-            pm, pv = ctypes.c_double(0.0), ctypes.c_double(0.0)
-            lib.check(lib.lib().tscm_device_peak_fp64(local_rank, ctypes.byref(pm), ctypes.byref(pv)))
-            floor_ms = 1e3 * n_local * (FLOP_MFMA_PER_CORNER / (pm.value * 1e12) + FLOP_VALU_PER_CORNER / (pv.value * 1e12))
-            roof.update(peak_measured_mfma_f64=pm.value, peak_measured_valu_f64=pv.value,
-                        measured_floor_ms=floor_ms, frac_of_measured_ceiling=floor_ms / avg_ms if avg_ms > 0 else 0.0)
+            pk = (ctypes.c_double * 3)()
+            lib.check(lib.lib().tscm_device_peak_fp64_ex(local_rank, pk))
+            # the kernel contracts with v_mfma_f64_4x4x4_4b (TSCM_EXEC_GRAM_16X16: with v_mfma_f64_16x16x4): its ceiling
+            pm = pk[0] if (args.exec_flags & 4) else pk[1]
+            pv = pk[2]
+            floor_ms = 1e3 * n_local * (FLOP_MFMA_PER_CORNER / (pm * 1e12) + FLOP_VALU_PER_CORNER / (pv * 1e12))
+            roof.update(peak_measured_mfma_f64=pm, peak_measured_mfma_f64_16x16x4=pk[0], peak_measured_mfma_f64_4x4x4=pk[1],
+                        peak_measured_valu_f64=pv, measured_floor_ms=floor_ms,
+                        frac_of_measured_ceiling=floor_ms / avg_ms if avg_ms > 0 else 0.0)
             pmc = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
             if os.path.exists(pmc) and world == 1:
                 try:

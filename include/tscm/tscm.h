@@ -165,6 +165,10 @@ int tscm_device_synchronize(int device);
 /* Measured fp64 ceilings of the device, every CU busy: v_mfma_f64_16x16x4_f64 and v_fma_f64 throughput in TFLOP/s
  * (a few milliseconds of micro-kernels; benchmark / roofline reporting only, not on any solver path). */
 int tscm_device_peak_fp64(int device, double *mfma_tflops, double *valu_tflops);
+/* ... with the two fp64 matrix instructions apart: peaks[0] = v_mfma_f64_16x16x4_f64 (the instruction of rounds 1-3a: about
+ * half the datasheet rate on gfx950), peaks[1] = v_mfma_f64_4x4x4_4b_f64 (the one the dominant kernel uses since round 3:
+ * the datasheet rate), peaks[2] = v_fma_f64; TFLOP/s. */
+int tscm_device_peak_fp64_ex(int device, double peaks[3]);
 
 void tscm_default_options(tscm_options *opt, int mono);
 

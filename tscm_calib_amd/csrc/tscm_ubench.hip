@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void k_peak_mfma(double *out, int iters, doubl
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// eight independent 4x4 accumulator blocks per wave: v_mfma_f64_4x4x4_4b_f64, the instruction k_eval_gram4 uses
+__global__ __launch_bounds__(256) void k_peak_mfma4(double *out, int iters, double seed)
+{
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = seed;
+    const double a = 1.0 + threadIdx.x * 1e-6, b = 1.0 - threadIdx.x * 1e-6;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 bool time_launches(F launch, int reps, double *ms_per_launch)
 {
@@ -70,6 +87,25 @@ bool time_launches(F launch, int reps, double *ms_per_launch)
 }
 
 }  // namespace
+
+// peaks[0] = v_mfma_f64_16x16x4_f64, peaks[1] = v_mfma_f64_4x4x4_4b_f64, peaks[2] = v_fma_f64, TFLOP/s
+extern "C" int tscm_device_peak_fp64_ex(int device, double peaks[3])
+{
+    if (!peaks) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    if (int rc = tscm_device_peak_fp64(device, &peaks[0], &peaks[2])) return rc;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return tscm_set_error(TSCM_E_HIP, "hipGetDeviceProperties failed");
+    const int blocks = prop.multiProcessorCount * 8;
+    double *out = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&out), sizeof(double) * 256 * (size_t)blocks) != hipSuccess) return tscm_set_error(TSCM_E_NOMEM, "hipMalloc failed");
+    const int iters = 8000, reps = 5;
+    double ms = 0.0;
+    const bool ok = time_launches([&] { hipLaunchKernelGGL(k_peak_mfma4, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0); }, reps, &ms);
+    (void)hipFree(out);
+    if (!ok || ms <= 0.0) return tscm_set_error(TSCM_E_HIP, "fp64 peak measurement failed");
+    peaks[1] = 512.0 * 8.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;       // 4 blocks x 4x4x4x2 flop per instruction, 8 per wave and iteration, 4 waves
+    return 0;
+}
 
 extern "C" int tscm_device_peak_fp64(int device, double *mfma_tflops, double *valu_tflops)
 {
