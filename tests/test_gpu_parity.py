@@ -407,6 +407,23 @@ def test_fused_and_separate_T_reduction_agree_bit_for_bit(hip_device, cfg):
     assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_gram_on_4x4_blocks_and_on_the_16x16_tile_agree_bit_for_bit(hip_device, cfg):
+    """Boards of <= 56 corners run k_eval_gram4 (three v_mfma_f64_4x4x4_4b per four rows, quad-DPP epilogue);
+    tscm_options.exec_flags = TSCM_EXEC_GRAM_16X16 selects k_eval_gram<58> (one v_mfma_f64_16x16x4 tile, the kernel of
+    rounds 1-3a).  Entries of the two instructions' results are the same bits and the epilogues perform the same
+    operations in the same order: the whole solve must be."""
+    p = synth.make_config(cfg)
+    a, b = p.copy().normalised(), p.copy().normalised()
+    with api.Solver(a) as s:
+        sa = s.solve()
+    with api.Solver(b) as s:
+        sb = s.solve(exec_flags=lib.EXEC_GRAM_16X16)
+    assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+    assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
+    assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
 def test_late_handoff_is_a_hard_error(hip_device):
     """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
     counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld
