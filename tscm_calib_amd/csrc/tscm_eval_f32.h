@@ -94,12 +94,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                 const double x = bxy[2 * j], y = bxy[2 * j + 1];
                 const double ou = c0 ? buf_load_f64(r_u, 8u * j, 8u * (unsigned)off) : pf_u, ov = c0 ? buf_load_f64(r_v, 8u * j, 8u * (unsigned)off) : pf_v;
                 // ---- fp64: board -> world -> camera, triple sphere, residual (multi_calib.h:158-193) ----
-                const double Pw0 = x * cst[0] + y * cst[3] + cst[6];
-                const double Pw1 = x * cst[1] + y * cst[4] + cst[7];
-                const double Pw2 = x * cst[2] + y * cst[5] + cst[8];
-                const double X = cc[0] * Pw0 + cc[1] * Pw1 + cc[2] * Pw2 + cc[9];
-                const double Y = cc[3] * Pw0 + cc[4] * Pw1 + cc[5] * Pw2 + cc[10];
-                const double Z = cc[6] * Pw0 + cc[7] * Pw1 + cc[8] * Pw2 + cc[11];
+                const double X = fma(x, cst[0], fma(y, cst[3], cst[6]));
+                const double Y = fma(x, cst[1], fma(y, cst[4], cst[7]));
+                const double Z = fma(x, cst[2], fma(y, cst[5], cst[8]));
                 const double rho2 = X * X + Y * Y;
                 const double s1 = rho2 + Z * Z;
                 const double id1 = fast_rsqrt(s1), d1 = s1 * id1;
@@ -120,7 +117,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                 const float i1 = (float)id1, i2 = (float)id2, i3 = (float)id3, ikf = (float)ik;
                 const float e1 = (float)d1, e2 = (float)d2, e3 = (float)d3;
                 const float mxf = (float)mx, myf = (float)my;
-                const float P0 = (float)Pw0, P1 = (float)Pw1, P2 = (float)Pw2;
+                // Q' = P_c - t_c (minus w x Q in the small-angle branch of the camera rotation): corner_geometry
+                float Q0 = (float)(X - cc[9]), Q1 = (float)(Y - cc[10]), Q2 = (float)(Z - cc[11]);
+                if (cc[24] != 0.0) {
+                    const float w0 = cf[21], w1 = cf[22], w2 = cf[23];
+                    const float s0 = w1 * Q2 - w2 * Q1, s1 = w2 * Q0 - w0 * Q2, s2 = w0 * Q1 - w1 * Q0;
+                    Q0 -= s0; Q1 -= s1; Q2 -= s2;
+                }
                 const float xi = cf[43], lam = cf[44], beta = cf[45];
                 const float c1 = 1.f + xi * Zf * i1;
                 const float c2 = 1.f + lam * z1f * i2;
@@ -143,14 +146,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                     const f2 w = N0 * h0 + N1 * h1 + N2 * h2;
                     fu[(kTcWb + kk) * RP] = w.x; fv[kTcWb + kk] = w.y;
                 }
+                {                                                          // w_c: -A (dR_c/dw_k Pw) = a_k . (Q' x n), both rows at once
+                    const f2 c0 = N2 * Q1 - N1 * Q2, c1 = N0 * Q2 - N2 * Q0, c2 = N1 * Q0 - N0 * Q1;
 #pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {                           // w_c: -A (dR_c/dw_k Pw)
-                    const fptr4 D = cf + 12 + 9 * kk;
-                    const float g0 = D[0] * P0 + D[1] * P1 + D[2] * P2;
-                    const float g1 = D[3] * P0 + D[4] * P1 + D[5] * P2;
-                    const float g2 = D[6] * P0 + D[7] * P1 + D[8] * P2;
-                    const f2 w = N0 * g0 + N1 * g1 + N2 * g2;
-                    fu[(kTcWc + kk) * RP] = w.x; fv[kTcWc + kk] = w.y;
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const f2 w = c0 * cf[12 + 3 * kk] + c1 * cf[13 + 3 * kk] + c2 * cf[14 + 3 * kk];
+                        fu[(kTcWc + kk) * RP] = w.x; fv[kTcWc + kk] = w.y;
+                    }
                 }
                 fu[kTcF * RP] = -mxf;  fv[kTcF] = -myf;
                 fu[kTcOne * RP] = -1.f; fv[kTcOne] = -1.f;

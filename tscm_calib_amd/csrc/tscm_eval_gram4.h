@@ -202,65 +202,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         auto PUT = [&](int c, double u, double v) { (c < 8 ? fu_lo : fu_hi)[4 * c] = u; fv[c] = v; };
         if (valid && !(ablate & 4)) {
             const double x = bxy[2 * lane], y = bxy[2 * lane + 1];
-            const double ou = pf_u, ov = pf_v;
-            // board -> world -> camera (multi_calib.h:158-167)
-            const double Pw0 = x * VC(0) + y * VC(3) + VC(6);
-            const double Pw1 = x * VC(1) + y * VC(4) + VC(7);
-            const double Pw2 = x * VC(2) + y * VC(5) + VC(8);
-            const double X = CC(0) * Pw0 + CC(1) * Pw1 + CC(2) * Pw2 + CC(9);
-            const double Y = CC(3) * Pw0 + CC(4) * Pw1 + CC(5) * Pw2 + CC(10);
-            const double Z = CC(6) * Pw0 + CC(7) * Pw1 + CC(8) * Pw2 + CC(11);
-            const double fx = CC(39), fy = CC(40), xi = CC(43), lam = CC(44), beta = CC(45);
-            // triple sphere (multi_calib.h:170-178)
-            const double rho2 = X * X + Y * Y;
-            double d1, id1, d2, id2, d3, id3;
-            sqrt_and_inverse(rho2 + Z * Z, d1, id1);
-            const double z1 = Z + xi * d1;
-            sqrt_and_inverse(rho2 + z1 * z1, d2, id2);
-            const double z2 = z1 + lam * d2;
-            sqrt_and_inverse(rho2 + z2 * z2, d3, id3);
-            const double k = z2 + beta * d3;
-            const double ik = fast_rcp(k);
-            const double mx = X * ik, my = Y * ik;
-            const double c1 = 1.0 + xi * Z * id1;
-            const double c2 = 1.0 + lam * z1 * id2;
-            const double c3 = 1.0 + beta * z2 * id3;
-            const double q = beta * id3 + c3 * (lam * id2 + c2 * xi * id1);
-            const double kz = c1 * c2 * c3;
-            const double fxk = fx * ik, fyk = fy * ik;
-            // -A = -d(u,v)/dPc  (the t_c columns)
-            const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
-            const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
-            PUT(kG4Tc + 0, n00, n10);
-            PUT(kG4Tc + 1, n01, n11);
-            PUT(kG4Tc + 2, n02, n12);
-            // w_b: -A (x e_k0 + y e_k1)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const double h0 = x * VC(9 + 6 * kk) + y * VC(12 + 6 * kk);
-                const double h1 = x * VC(10 + 6 * kk) + y * VC(13 + 6 * kk);
-                const double h2 = x * VC(11 + 6 * kk) + y * VC(14 + 6 * kk);
-                PUT(kG4Wb + kk, n00 * h0 + n01 * h1 + n02 * h2, n10 * h0 + n11 * h1 + n12 * h2);
-            }
-            // w_c: -A (dR_c/dw_k Pw)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const double g0 = CC(12 + 9 * kk + 0) * Pw0 + CC(12 + 9 * kk + 1) * Pw1 + CC(12 + 9 * kk + 2) * Pw2;
-                const double g1 = CC(12 + 9 * kk + 3) * Pw0 + CC(12 + 9 * kk + 4) * Pw1 + CC(12 + 9 * kk + 5) * Pw2;
-                const double g2 = CC(12 + 9 * kk + 6) * Pw0 + CC(12 + 9 * kk + 7) * Pw1 + CC(12 + 9 * kk + 8) * Pw2;
-                PUT(kG4Wc + kk, n00 * g0 + n01 * g1 + n02 * g2, n10 * g0 + n11 * g1 + n12 * g2);
-            }
-            // f* and one*
-            PUT(kG4F, -mx, -my);
-            PUT(kG4One, -1.0, -1.0);
-            // xi, lambda, alpha: -du/dk * dk/dparam
-            const double hu = fxk * mx, hv = fyk * my;
-            const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * CC(46);
-            PUT(kG4Xi, hu * kxi, hv * kxi);
-            PUT(kG4Lam, hu * klam, hv * klam);
-            PUT(kG4Al, hu * kal, hv * kal);
-            // residual = observed - projected (multi_calib.h:192-193)
-            PUT(kG4R, ou - (fx * mx + CC(41)), ov - (fy * my + CC(42)));
+            // semantic column -> tile column of this kernel
+            constexpr int tcol[15] = { kG4Wb, kG4Wb + 1, kG4Wb + 2, kG4Tc, kG4Tc + 1, kG4Tc + 2, kG4Wc, kG4Wc + 1, kG4Wc + 2,
+                                       kG4F, kG4One, kG4Xi, kG4Lam, kG4Al, kG4R };
+            corner_geometry(x, y, pf_u, pf_v, VC, CC, [&](int gc, double u, double v) { PUT(tcol[gc], u, v); });
         } else if (lane < prev_nv) {
 #pragma unroll
             for (int c = 0; c < kTcols; ++c) (c < 8 ? fu_lo : fu_hi)[4 * c] = 0.0;

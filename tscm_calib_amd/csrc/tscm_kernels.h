@@ -49,8 +49,11 @@ constexpr int kTcols = 15;         // columns of the single MFMA Gram tile (see 
 // register 0 of the lanes kq = 0, 1, 2.
 constexpr int kTcWb = 0, kTcWc = 4, kTcF = 8, kTcOne = 9, kTcXi = 10, kTcLam = 12, kTcAl = 13, kTcR = 14;
 __host__ __device__ constexpr int tc_tc(int j) { return 3 + 4 * j; }
-constexpr int kVConst = 27;        // per-view constants: r1, r2, t_b, R_c dR_b/dw_k [:,0:2]
-constexpr int kCConst = 48;        // per-camera constants: R_c, t_c, dR_c/dw_k, fx fy cx cy xi lambda beta 1/(1-alpha)^2
+constexpr int kVConst = 27;        // per-view constants: R_c r1, R_c r2, R_c t_b + t_c (board point -> camera frame in two FMAs per
+                                   // component), then R_c dR_b/dw_k [:,0:2]
+constexpr int kCConst = 48;        // per-camera constants: [0,9) R_c, [9,12) t_c, [12,21) a_k (dR_c/dw_k = [a_k]x R_c), [21,24) w if the
+                                   // rotation is in the small-angle branch else 0, [24] 1 / 0 for that branch, [39,47) fx fy cx cy xi lambda
+                                   // beta 1/(1-alpha)^2   (camera_rotation_constants, tscm_math.h)
 constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 doubles, then the same 48 values as floats
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
@@ -265,6 +268,39 @@ __device__ __forceinline__ void load_view_const(const DevProblem &P, const DevSt
 //   vconst[view][32]: r1(3) r2(3) t_b(3), then for k=0..2: R_c dR_b/dw_k[:,0] (3), R_c dR_b/dw_k[:,1] (3); 5 pad
 //   cconst[cam] : R_c(9) t_c(3) dR_c/dw_k (27) fx fy cx cy xi lambda beta=alpha/(1-alpha) 1/(1-alpha)^2
 // ---------------------------------------------------------------------------------------------
+// the first nine per-view constants: the board point (x, y, 0) in the camera frame is x m1 + y m2 + t
+__device__ __forceinline__ void view_point_constants(const double Rc[9], const double *tc, const double *bc /* r1, r2 */, const double *tb, double *o)
+{
+    for (int r = 0; r < 3; ++r) {
+        o[r] = Rc[3 * r] * bc[0] + Rc[3 * r + 1] * bc[1] + Rc[3 * r + 2] * bc[2];
+        o[3 + r] = Rc[3 * r] * bc[3] + Rc[3 * r + 1] * bc[4] + Rc[3 * r + 2] * bc[5];
+        o[6 + r] = (Rc[3 * r] * tb[0] + Rc[3 * r + 1] * tb[1] + Rc[3 * r + 2] * tb[2]) + tc[r];
+    }
+}
+
+// the per-camera record of the evaluation target (doubles, then the same values as floats)
+__device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m)
+{
+    double crt[3], Rc[9], a[9], wsm[3];
+    for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
+    const int small = camera_rotation_constants(crt, Rc, a, wsm);
+    double *o = S.cconst[tgt] + kCStride * m;
+    for (int k = 0; k < 9; ++k) o[k] = Rc[k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
+    for (int k = 0; k < 9; ++k) o[12 + k] = a[k];
+    for (int k = 0; k < 3; ++k) o[21 + k] = wsm[k];
+    o[24] = small ? 1.0 : 0.0;
+    for (int k = 25; k < 39; ++k) o[k] = 0.0;
+    const double *I = S.intr[tgt] + 9 * m;
+    for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
+    const double oma = 1.0 - I[6];
+    o[45] = I[6] / oma;
+    o[46] = 1.0 / (oma * oma);
+    o[47] = 0.0;
+    float *of = reinterpret_cast<float *>(o + kCConst);
+    for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
+}
+
 constexpr int kVStride = 48;      // doubles per view record in vconst: 27 doubles (+5 pad), then at byte 256 the same 27 values as
                                   // floats (read by the fp32-Jacobian kernel): 384 bytes
 constexpr int kVFloatOff = 32;    // offset of the float copy, in doubles
@@ -287,30 +323,14 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
         for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);
         double *o = st[t];
-        for (int k = 0; k < 6; ++k) o[k] = bc[k];
-        for (int k = 0; k < 3; ++k) o[6 + k] = rt[3 + k];
+        view_point_constants(Rc, S.cam_rt[tgt] + 6 * m + 3, bc, rt + 3, o);
         for (int k = 0; k < 6; ++k) {           // six 3-vectors d -> R_c d
             const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
             for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
         }
         for (int k = kVConst; k < kVFloatOff; ++k) o[k] = 0.0;
     } else if (i < P.V + P.C) {
-        const int m = i - P.V;
-        double crt[3], Rc[9], dRc[27];
-        for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
-        rotation_and_derivatives(crt, Rc, dRc);
-        double *o = S.cconst[tgt] + kCStride * m;
-        for (int k = 0; k < 9; ++k) o[k] = Rc[k];
-        for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
-        for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
-        const double *I = S.intr[tgt] + 9 * m;
-        for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
-        const double oma = 1.0 - I[6];
-        o[45] = I[6] / oma;
-        o[46] = 1.0 / (oma * oma);
-        o[47] = 0.0;
-        float *of = reinterpret_cast<float *>(o + kCConst);
-        for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
+        write_camera_record(S, tgt, i - P.V);
     }
     __syncthreads();
     // the block's records leave as one contiguous, coalesced stream: vconst[view][32]
@@ -431,6 +451,83 @@ __device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, 
 // dynamic LDS: 16*rp + kCst + 2*n_points doubles (the kCst block is only used by k_eval_gram_f32).
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Geometry of one corner for the Gram kernels: board point (x, y, 0) -> camera frame -> Triple Sphere projection,
+// residual, and the 15 Jacobian entries of the u-row and of the v-row (multi_calib.h:146-195, hand-derived: tscm_math.h).
+// VC(k): the view's constants (kVConst), CC(k): the camera's (kCConst), both wave-uniform (scalar operands);
+// PUT(column, u, v) receives the entries by SEMANTIC column (GCol) -- each kernel has its own tile column order.
+//   * P_c = x m1 + y m2 + t as two FMAs per component (round 3; rounds 1-2: board -> world -> camera, 21 operations);
+//   * camera-rotation columns: n . (a_k x Q') = a_k . (Q' x n) with Q' = P_c - t_c (camera_rotation_constants):
+//     one cross product per row and three dot products (33 operations; 45 with three matrix-vector products).
+// ---------------------------------------------------------------------------------------------
+enum GCol { gcWb0 = 0, gcWb1, gcWb2, gcTc0, gcTc1, gcTc2, gcWc0, gcWc1, gcWc2, gcF, gcOne, gcXi, gcLam, gcAl, gcR };
+
+template <typename FV, typename FC, typename FP>
+__device__ __forceinline__ void corner_geometry(double x, double y, double ou, double ov, FV VC, FC CC, FP PUT)
+{
+    const double X = fma(x, VC(0), fma(y, VC(3), VC(6)));
+    const double Y = fma(x, VC(1), fma(y, VC(4), VC(7)));
+    const double Z = fma(x, VC(2), fma(y, VC(5), VC(8)));
+    const double fx = CC(39), fy = CC(40), xi = CC(43), lam = CC(44), beta = CC(45);
+    // triple sphere (multi_calib.h:170-178)
+    const double rho2 = X * X + Y * Y;
+    double d1, id1, d2, id2, d3, id3;
+    sqrt_and_inverse(rho2 + Z * Z, d1, id1);
+    const double z1 = Z + xi * d1;
+    sqrt_and_inverse(rho2 + z1 * z1, d2, id2);
+    const double z2 = z1 + lam * d2;
+    sqrt_and_inverse(rho2 + z2 * z2, d3, id3);
+    const double k = z2 + beta * d3;
+    const double ik = fast_rcp(k);
+    const double mx = X * ik, my = Y * ik;
+    const double c1 = 1.0 + xi * Z * id1;
+    const double c2 = 1.0 + lam * z1 * id2;
+    const double c3 = 1.0 + beta * z2 * id3;
+    const double q = beta * id3 + c3 * (lam * id2 + c2 * xi * id1);
+    const double kz = c1 * c2 * c3;
+    const double fxk = fx * ik, fyk = fy * ik;
+    // -A = -d(u,v)/dPc  (the t_c columns)
+    const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
+    const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
+    PUT(gcTc0, n00, n10);
+    PUT(gcTc1, n01, n11);
+    PUT(gcTc2, n02, n12);
+    // w_b: -A (x e_k0 + y e_k1),  e = R_c dR_b/dw_k columns
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const double h0 = x * VC(9 + 6 * kk) + y * VC(12 + 6 * kk);
+        const double h1 = x * VC(10 + 6 * kk) + y * VC(13 + 6 * kk);
+        const double h2 = x * VC(11 + 6 * kk) + y * VC(14 + 6 * kk);
+        PUT(gcWb0 + kk, n00 * h0 + n01 * h1 + n02 * h2, n10 * h0 + n11 * h1 + n12 * h2);
+    }
+    // w_c: -A (dR_c/dw_k P_w) = a_k . (Q' x n)
+    {
+        double Q0 = X - CC(9), Q1 = Y - CC(10), Q2 = Z - CC(11);
+        if (CC(24) != 0.0) {                  // small-angle branch of the camera rotation (wave-uniform): Q' = Q - w x Q
+            const double w0 = CC(21), w1 = CC(22), w2 = CC(23);
+            const double s0 = w1 * Q2 - w2 * Q1, s1 = w2 * Q0 - w0 * Q2, s2 = w0 * Q1 - w1 * Q0;
+            Q0 -= s0; Q1 -= s1; Q2 -= s2;
+        }
+        const double cu0 = Q1 * n02 - Q2 * n01, cu1 = Q2 * n00 - Q0 * n02, cu2 = Q0 * n01 - Q1 * n00;
+        const double cv0 = Q1 * n12 - Q2 * n11, cv1 = Q2 * n10 - Q0 * n12, cv2 = Q0 * n11 - Q1 * n10;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+            PUT(gcWc0 + kk, CC(12 + 3 * kk) * cu0 + CC(13 + 3 * kk) * cu1 + CC(14 + 3 * kk) * cu2,
+                            CC(12 + 3 * kk) * cv0 + CC(13 + 3 * kk) * cv1 + CC(14 + 3 * kk) * cv2);
+    }
+    // f* and one*
+    PUT(gcF, -mx, -my);
+    PUT(gcOne, -1.0, -1.0);
+    // xi, lambda, alpha: -du/dk * dk/dparam
+    const double hu = fxk * mx, hv = fyk * my;
+    const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * CC(46);
+    PUT(gcXi, hu * kxi, hv * kxi);
+    PUT(gcLam, hu * klam, hv * klam);
+    PUT(gcAl, hu * kal, hv * kal);
+    // residual = observed - projected (multi_calib.h:192-193)
+    PUT(gcR, ou - (fx * mx + CC(41)), ov - (fy * my + CC(42)));
+}
+
 #ifdef TSCM_WAVE_TIMELINE
 constexpr int kTimelineWaves = 8192;
 __device__ long long g_timeline[4 * kTimelineWaves];     // per wave of k_eval_gram: HW_ID, XCC_ID, start, end (10 ns ticks)
@@ -594,67 +691,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
                 // vmcnt(0) in front of the residual, i.e. a wait for the prefetch issued a few hundred cycles earlier)
                 const bool later_pass = RPC == 0 && c0 != 0;
                 const double ou = later_pass ? buf_load_f64(r_u, 8u * j, 8u * (unsigned)off) : pf_u, ov = later_pass ? buf_load_f64(r_v, 8u * j, 8u * (unsigned)off) : pf_v;
-                // board -> world -> camera (multi_calib.h:158-167)
-                const double Pw0 = x * VC(0) + y * VC(3) + VC(6);
-                const double Pw1 = x * VC(1) + y * VC(4) + VC(7);
-                const double Pw2 = x * VC(2) + y * VC(5) + VC(8);
-                const double X = CC(0) * Pw0 + CC(1) * Pw1 + CC(2) * Pw2 + CC(9);
-                const double Y = CC(3) * Pw0 + CC(4) * Pw1 + CC(5) * Pw2 + CC(10);
-                const double Z = CC(6) * Pw0 + CC(7) * Pw1 + CC(8) * Pw2 + CC(11);
-                const double fx = CC(39), fy = CC(40), xi = CC(43), lam = CC(44), beta = CC(45);
-                // triple sphere (multi_calib.h:170-178)
-                const double rho2 = X * X + Y * Y;
-                double d1, id1, d2, id2, d3, id3;
-                sqrt_and_inverse(rho2 + Z * Z, d1, id1);
-                const double z1 = Z + xi * d1;
-                sqrt_and_inverse(rho2 + z1 * z1, d2, id2);
-                const double z2 = z1 + lam * d2;
-                sqrt_and_inverse(rho2 + z2 * z2, d3, id3);
-                const double k = z2 + beta * d3;
-                const double ik = fast_rcp(k);
-                const double mx = X * ik, my = Y * ik;
-                const double c1 = 1.0 + xi * Z * id1;
-                const double c2 = 1.0 + lam * z1 * id2;
-                const double c3 = 1.0 + beta * z2 * id3;
-                const double q = beta * id3 + c3 * (lam * id2 + c2 * xi * id1);
-                const double kz = c1 * c2 * c3;
-                const double fxk = fx * ik, fyk = fy * ik;
-                // -A = -d(u,v)/dPc  (the t_c columns)
-                const double n00 = -fxk * (1.0 - X * mx * q), n01 = fxk * mx * Y * q, n02 = fxk * mx * kz;
-                const double n10 = fyk * my * X * q, n11 = -fyk * (1.0 - Y * my * q), n12 = fyk * my * kz;
-                fu[tc_tc(0) * RP] = n00; fv[tc_tc(0)] = n10;
-                fu[tc_tc(1) * RP] = n01; fv[tc_tc(1)] = n11;
-                fu[tc_tc(2) * RP] = n02; fv[tc_tc(2)] = n12;
-                // w_b: -A (x e_k0 + y e_k1)
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const double h0 = x * VC(9 + 6 * kk) + y * VC(12 + 6 * kk);
-                    const double h1 = x * VC(10 + 6 * kk) + y * VC(13 + 6 * kk);
-                    const double h2 = x * VC(11 + 6 * kk) + y * VC(14 + 6 * kk);
-                    fu[(kTcWb + kk) * RP] = n00 * h0 + n01 * h1 + n02 * h2;
-                    fv[kTcWb + kk] = n10 * h0 + n11 * h1 + n12 * h2;
-                }
-                // w_c: -A (dR_c/dw_k Pw)
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const double g0 = CC(12 + 9 * kk + 0) * Pw0 + CC(12 + 9 * kk + 1) * Pw1 + CC(12 + 9 * kk + 2) * Pw2;
-                    const double g1 = CC(12 + 9 * kk + 3) * Pw0 + CC(12 + 9 * kk + 4) * Pw1 + CC(12 + 9 * kk + 5) * Pw2;
-                    const double g2 = CC(12 + 9 * kk + 6) * Pw0 + CC(12 + 9 * kk + 7) * Pw1 + CC(12 + 9 * kk + 8) * Pw2;
-                    fu[(kTcWc + kk) * RP] = n00 * g0 + n01 * g1 + n02 * g2;
-                    fv[kTcWc + kk] = n10 * g0 + n11 * g1 + n12 * g2;
-                }
-                // f* and one*
-                fu[kTcF * RP] = -mx;   fv[kTcF] = -my;
-                fu[kTcOne * RP] = -1.0; fv[kTcOne] = -1.0;
-                // xi, lambda, alpha: -du/dk * dk/dparam
-                const double hu = fxk * mx, hv = fyk * my;
-                const double kxi = c3 * c2 * d1, klam = c3 * d2, kal = d3 * CC(46);
-                fu[kTcXi * RP] = hu * kxi;   fv[kTcXi] = hv * kxi;
-                fu[kTcLam * RP] = hu * klam; fv[kTcLam] = hv * klam;
-                fu[kTcAl * RP] = hu * kal;   fv[kTcAl] = hv * kal;
-                // residual = observed - projected (multi_calib.h:192-193)
-                fu[kTcR * RP] = ou - (fx * mx + CC(41));
-                fv[kTcR] = ov - (fy * my + CC(42));
+                // semantic column -> tile column of this kernel
+                constexpr int tcol[15] = { kTcWb, kTcWb + 1, kTcWb + 2, tc_tc(0), tc_tc(1), tc_tc(2), kTcWc, kTcWc + 1, kTcWc + 2,
+                                           kTcF, kTcOne, kTcXi, kTcLam, kTcAl, kTcR };
+                corner_geometry(x, y, ou, ov, VC, CC, [&](int gc, double u, double v) { fu[tcol[gc] * RP] = u; fv[tcol[gc]] = v; });
             } else if (lane < prev_nv) {
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.0;
@@ -2256,25 +2296,6 @@ template <int NTH> struct BsGeom {
     static_assert(kBoards + kMaxCam <= NTH, "lane roles of phase B");
 };
 
-__device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m)
-{
-    double crt[3], Rc[9], dRc[27];
-    for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
-    rotation_and_derivatives(crt, Rc, dRc);
-    double *o = S.cconst[tgt] + kCStride * m;
-    for (int k = 0; k < 9; ++k) o[k] = Rc[k];
-    for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
-    for (int k = 0; k < 27; ++k) o[12 + k] = dRc[k];
-    const double *I = S.intr[tgt] + 9 * m;
-    for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
-    const double oma = 1.0 - I[6];
-    o[45] = I[6] / oma;
-    o[46] = 1.0 / (oma * oma);
-    o[47] = 0.0;
-    float *of = reinterpret_cast<float *>(o + kCConst);
-    for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
-}
-
 template <int NTH>
 __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
 {
@@ -2291,8 +2312,12 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
     double *s_fac = dyn;                                   // [kBsBoards][kFac]   phase B
     double *st_all = dyn;                                  // [kBsTile][kVFloatOff + 1]  phase C
     __shared__ double s_q[kBsBoards][6], s_new[kBsBoards][6];
-    __shared__ double s_rc[kMaxCam][9];
-    __shared__ double s_yh[16 * kMaxCam];
+    __shared__ double s_yh[16 * kMaxCam];                  // phase A
+    // candidate R_c (9) and t_c (3), phases B and C: in the space of s_yh, which phase A is done with.  The workgroup's
+    // LDS (static + dynamic) has to stay under 32 KB: config 1's 1250 workgroups are then resident at once, five per CU;
+    // 768 bytes more (s_rc on its own, round 3) made it four per CU, a second round of workgroups and 22 us for 17.8
+    double (*s_rc)[12] = reinterpret_cast<double (*)[12]>(s_yh);
+    static_assert(12 * kMaxCam <= 16 * kMaxCam, "s_rc aliases s_yh");
     __shared__ double sm[16];
     __shared__ int s_view[kBsTile];
     const int t = threadIdx.x;
@@ -2312,6 +2337,10 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
     for (int j = 0; j < 7; ++j) facv[j] = S.fac[(size_t)kFac * b0 + min(t + kBsThreads * j, nbl * kFac - 1)];
     for (int i = t; i < P.n_pad; i += kBsThreads) s_yh[i] = S.yhat[i];
     if (t < kBsBoards * 6) (&s_q[0][0])[t] = 0.0;
+    // the candidate's per-camera records (rotation, left-Jacobian vectors, intrinsics: write_camera_record): one camera
+    // per workgroup, by the first lane of the second wave while the loads requested above are in flight -- a serial
+    // chain of a few hundred operations that cost workgroup 0 4.6 us when it did all cameras after its board solves
+    if (t == 64) for (int m = blockIdx.x; m < P.C; m += gridDim.x) write_camera_record(S, cur ^ 1, m);
     // ---- phase A -----------------------------------------------------------------------------------------------------
     {
         const int grp = t >> 4, a = t & 15;
@@ -2411,7 +2440,8 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
         for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[cur ^ 1][6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);
         for (int k = 0; k < 9; ++k) s_rc[m][k] = Rc[k];
-        if (blockIdx.x == 0) write_camera_record(S, cur ^ 1, m);
+        for (int k = 0; k < 3; ++k) s_rc[m][9 + k] = S.cam_rt[cur ^ 1][6 * m + 3 + k];
+
     }
     {
         double red[2] = { mb, ss }, mdummy = 0.0;
@@ -2432,8 +2462,7 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
             for (int k = 0; k < 6; ++k) rt[k] = s_new[bl][k];
             board_constants(rt, bc);
             double *o = st_all + (size_t)t * (kVFloatOff + 1);
-            for (int k = 0; k < 6; ++k) o[k] = bc[k];
-            for (int k = 0; k < 3; ++k) o[6 + k] = rt[3 + k];
+            view_point_constants(s_rc[m], s_rc[m] + 9, bc, rt + 3, o);
             for (int k = 0; k < 6; ++k) {           // six 3-vectors d -> R_c d
                 const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
                 for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = s_rc[m][3 * r] * d0 + s_rc[m][3 * r + 1] * d1 + s_rc[m][3 * r + 2] * d2;

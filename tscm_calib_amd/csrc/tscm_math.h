@@ -103,6 +103,37 @@ TSCM_HD void camera_constants(const double rt[6], double out[kCamConst])
     rotation_and_derivatives(rt, out, out + 9);
 }
 
+// The camera rotation in the form the Gram kernels consume since round 3: R (row-major), the three vectors a_k with
+// dR/dw_k = [a_k]x R  (the columns of the rotation's left Jacobian; a_k = vee(dR_k R^T), taken from the same dR the
+// rounds before used), so that  dR/dw_k P_w = a_k x (R P_w) = a_k x Q,  Q = P_c - t_c:  the camera-rotation columns
+// of a corner are  n . (a_k x Q) = a_k . (Q x n)  -- one cross product per Jacobian row and three dot products, against
+// three matrix-vector products with 27 constants.  Small-angle branch of ceres::AngleAxisRotatePoint (theta^2 <=
+// DBL_EPSILON: R p = p + w x p, dR/dw_k = [e_k]x): a_k = e_k and the kernels use Q' = Q - w x Q  (= P_w up to
+// O(|w|^2) ~ 1e-16 relative); wsm = w there and 0 otherwise.  Returns 1 in the small-angle branch.
+TSCM_HD int camera_rotation_constants(const double w[3], double R[9], double a[9], double wsm[3])
+{
+    double dR[27];
+    rotation_and_derivatives(w, R, dR);
+    const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (theta2 > DBL_EPSILON) {
+        for (int k = 0; k < 3; ++k) {
+            const double *D = dR + 9 * k;
+            double A[9];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) A[3 * r + c] = D[3 * r] * R[3 * c] + D[3 * r + 1] * R[3 * c + 1] + D[3 * r + 2] * R[3 * c + 2];
+            a[3 * k + 0] = 0.5 * (A[7] - A[5]);
+            a[3 * k + 1] = 0.5 * (A[2] - A[6]);
+            a[3 * k + 2] = 0.5 * (A[3] - A[1]);
+        }
+        wsm[0] = wsm[1] = wsm[2] = 0.0;
+        return 0;
+    }
+    for (int i = 0; i < 9; ++i) a[i] = 0.0;
+    a[0] = a[4] = a[8] = 1.0;
+    wsm[0] = w[0]; wsm[1] = w[1]; wsm[2] = w[2];
+    return 1;
+}
+
 // Everything a corner needs that is uniform over one (camera, board) view.
 struct ViewConst {
     double r1[3], r2[3], tb[3];     // board: R_b columns 0,1 and translation
