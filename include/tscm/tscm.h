@@ -148,8 +148,8 @@ typedef struct tscm_summary {
                                    /*   ended on a tolerance test)                     */
     tscm_iteration iterations[TSCM_MAX_ITERATIONS + 1];
     char message[128];
-    double seconds_solve;          /* minimiser loop only (device work + host polling) */
-    double seconds_total;          /* incl. parameter upload/download                  */
+    double seconds_solve;          /* minimiser loop on the device: first to last kernel */
+    double seconds_total;          /* wall time of the call (tscm_solve_*: incl. upload/download) */
     double rmse;                   /* sqrt(2*final_cost/N)                             */
 } tscm_summary;
 

@@ -156,6 +156,7 @@ struct CtrlHead {
     double se_min, se_cur, se_ref, se_cand, se_acc_ref, se_acc_cand;
     double initial_cost;
     Options opt;
+    long long t_begin, t_end;           // s_memrealtime (100 MHz) in k_begin_solve / k_end_solve: device time of the solve
 };
 
 struct Ctrl : CtrlHead {
@@ -2630,6 +2631,36 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
     ControlPre pre;
     control_prefetch(P, S, init, pre);
     control_step(P, S, init, pre, sm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// first and last launch of a solve.  What the host did with five stream operations in front of a solve (control block
+// H2D, counter memset, three D2D copies of the start point, a stream synchronisation) and four synchronous copies
+// behind it cost 0.25 ms per solve -- as much as two LM iterations of config 4.
+// ---------------------------------------------------------------------------------------------
+// the control block as the host set it up (kernel argument), the arrival counter of the fused T reduction at zero and,
+// with `reset`, the registered start point in buffer 0
+__global__ __launch_bounds__(256) void k_begin_solve(DevState S, CtrlHead head, int C, int B, const double *init_cam,
+                                                     const double *init_intr, const double *init_board, int reset)
+{
+    const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
+    if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; *S.t_count = 0; }
+    if (!reset) return;
+    for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = init_cam[i];
+    for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = init_intr[i];
+    for (int i = i0; i < 6 * B; i += n) S.board_rt[0][i] = init_board[i];
+}
+
+// the accepted point lives in buffer `cur`: it becomes buffer 0 (what the caller downloads and the next resident solve
+// starts from)
+__global__ __launch_bounds__(256) void k_end_solve(DevState S, int C, int B)
+{
+    const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
+    if (i0 == 0) S.ctrl->t_end = wall_clock64();
+    if (S.ctrl->cur == 0) return;
+    for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = S.cam_rt[1][i];
+    for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = S.intr[1][i];
+    for (int i = i0; i < 6 * B; i += n) S.board_rt[0][i] = S.board_rt[1][i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include "tscm_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -627,6 +628,10 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = 4 * sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points);
     s->lds_eval4 = 4 * sizeof(double) * (size_t)eval_gram4_lds_doubles(p->n_points);
+#ifdef TSCM_G4_LDS_PAD      // occupancy experiments (tools/wave_timeline.py): fewer workgroups per CU, same kernel
+    s->lds_eval4 += TSCM_G4_LDS_PAD;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval4));
+#endif
     // reduced solve on the compact system, 4 x 4 tiles, one more tile row for the right-hand side: 16 x 16 threads
     // (<= 4 cameras: at most 13 panels), 25 x 25 threads (<= 24 panels, e.g. 7 cameras with one constant pose: 85
     // columns) or 32 x 32 threads (8 cameras: <= 104 columns, 26 panels)
@@ -708,9 +713,9 @@ extern "C" int tscm_solver_upload_params(tscm_solver *s, const double *cam_rt, c
 // HIP-event brackets on the solver's stream: every `timing`-th occurrence of a kind (0 = the dominant kernel, 1 = the
 // exchange of T, 2 = the exchange of H_stage) is timed; an event pair holds the stream for a few microseconds, so the
 // sampling keeps the measurement out of the result
-static int timed_begin(tscm_solver *s, int kind, hipStream_t stream, hipEvent_t *e1)
+static int timed_pair(tscm_solver *s, int kind, hipEvent_t *e0, hipEvent_t *e1)
 {
-    *e1 = nullptr;
+    *e0 = *e1 = nullptr;
     if (!(s->timing > 0 && (s->ev_count[kind]++ % (unsigned)s->timing) == 0)) return 0;
     if (s->ev_used == s->ev.size()) {
         hipEvent_t a, b;
@@ -719,26 +724,43 @@ static int timed_begin(tscm_solver *s, int kind, hipStream_t stream, hipEvent_t 
         s->ev_kind.push_back(0);
     }
     s->ev_kind[s->ev_used] = kind;
-    const hipEvent_t e0 = s->ev[s->ev_used].first;
+    *e0 = s->ev[s->ev_used].first;
     *e1 = s->ev[s->ev_used].second;
     ++s->ev_used;
-    HIP_TRY(hipEventRecord(e0, stream));
     return 0;
 }
 
-// one launch of the dominant kernel, optionally bracketed by HIP events on the solver's stream
+static int timed_begin(tscm_solver *s, int kind, hipStream_t stream, hipEvent_t *e1)
+{
+    hipEvent_t e0 = nullptr;
+    if (int rc = timed_pair(s, kind, &e0, e1)) return rc;
+    if (e0) HIP_TRY(hipEventRecord(e0, stream));
+    return 0;
+}
+
+// one launch of the dominant kernel.  A timed launch carries its event pair IN the dispatch (hipExtLaunchKernelGGL:
+// the events take the start and end time stamps of this kernel's packet on the solver's stream) -- two hipEventRecord
+// around it are two more packets with a drain each, 8.5 us per timed launch at config 4 and 3 % of the driver's
+// 20-step run
+template <typename K>
+static void launch_eval_kernel(K kernel, dim3 grid, size_t lds, tscm_solver *s, hipEvent_t e0, hipEvent_t e1, int cand)
+{
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, dim3(256), (std::uint32_t)lds, s->stream, e0, e1, 0, s->P, s->S, cand);
+    else hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s->stream, s->P, s->S, cand);
+}
+
 static int launch_eval(tscm_solver *s, int cand)
 {
     const DevProblem &P = s->P;
     if (P.n_chunks == 0) return 0;
-    hipEvent_t e1 = nullptr;
-    if (int rc = timed_begin(s, 0, s->stream, &e1)) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (int rc = timed_pair(s, 0, &e0, &e1)) return rc;
+    const dim3 grid(P.n_chunks / 4);
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
-    if (s->f32_jacobian) hipLaunchKernelGGL(k_eval_gram_f32, dim3(P.n_chunks / 4), dim3(256), s->lds_eval32, s->stream, P, s->S, cand);
-    else if (P.rp == 58 && !s->gram16) hipLaunchKernelGGL(k_eval_gram4, dim3(P.n_chunks / 4), dim3(256), s->lds_eval4, s->stream, P, s->S, cand);
-    else if (P.rp == 58) hipLaunchKernelGGL(k_eval_gram<58>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
-    else hipLaunchKernelGGL(k_eval_gram<0>, dim3(P.n_chunks / 4), dim3(256), s->lds_eval, s->stream, P, s->S, cand);
-    if (e1) HIP_TRY(hipEventRecord(e1, s->stream));
+    if (s->f32_jacobian) launch_eval_kernel(k_eval_gram_f32, grid, s->lds_eval32, s, e0, e1, cand);
+    else if (P.rp == 58 && !s->gram16) launch_eval_kernel(k_eval_gram4, grid, s->lds_eval4, s, e0, e1, cand);
+    else if (P.rp == 58) launch_eval_kernel(k_eval_gram<58>, grid, s->lds_eval, s, e0, e1, cand);
+    else launch_eval_kernel(k_eval_gram<0>, grid, s->lds_eval, s, e0, e1, cand);
     return 0;
 }
 
@@ -969,35 +991,28 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         if (s->f32_jacobian && s->lds_eval32 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
     }
 
-    // control block (identical on every rank)
-    for (tscm_solver *s : run.m) {
-        DevState &S = s->S;
-        Ctrl *h = s->h_ctrl;
-        std::memset(h, 0, sizeof(Ctrl));
-        h->radius = opt.initial_trust_region_radius;
-        h->decrease_factor = 2.0;
-        h->opt.max_num_iterations = opt.max_num_iterations;
-        h->opt.function_tolerance = opt.function_tolerance;
-        h->opt.gradient_tolerance = opt.gradient_tolerance;
-        h->opt.parameter_tolerance = opt.parameter_tolerance;
-        h->opt.initial_radius = opt.initial_trust_region_radius;
-        h->opt.max_radius = opt.max_trust_region_radius;
-        h->opt.min_radius = opt.min_trust_region_radius;
-        h->opt.min_relative_decrease = opt.min_relative_decrease;
-        h->opt.min_lm_diagonal = opt.min_lm_diagonal;
-        h->opt.max_lm_diagonal = opt.max_lm_diagonal;
-        h->opt.max_invalid = opt.max_num_consecutive_invalid_steps;
-        h->opt.jacobi_scaling = opt.jacobi_scaling;
-        HIP_TRY(hipMemcpyAsync(S.ctrl, h, sizeof(CtrlHead), hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipMemsetAsync(S.t_count, 0, sizeof(int), s->stream));        // arrival counter of the fused T reduction: every solve starts from zero
-        if (reset) {
-            HIP_TRY(hipMemcpyAsync(S.cam_rt[0], s->d_init_cam, sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice, s->stream));
-            HIP_TRY(hipMemcpyAsync(S.intr[0], s->d_init_intr, sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice, s->stream));
-            if (s->B) HIP_TRY(hipMemcpyAsync(S.board_rt[0], s->d_init_board, sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice, s->stream));
-        }
-    }
-    HIP_TRY(hipStreamSynchronize(s0->stream));
+    // control block (identical on every rank), counter of the fused T reduction, start point: one launch (k_begin_solve)
     const double t0 = wall();
+    for (tscm_solver *s : run.m) {
+        CtrlHead h;
+        std::memset(&h, 0, sizeof(h));
+        h.radius = opt.initial_trust_region_radius;
+        h.decrease_factor = 2.0;
+        h.opt.max_num_iterations = opt.max_num_iterations;
+        h.opt.function_tolerance = opt.function_tolerance;
+        h.opt.gradient_tolerance = opt.gradient_tolerance;
+        h.opt.parameter_tolerance = opt.parameter_tolerance;
+        h.opt.initial_radius = opt.initial_trust_region_radius;
+        h.opt.max_radius = opt.max_trust_region_radius;
+        h.opt.min_radius = opt.min_trust_region_radius;
+        h.opt.min_relative_decrease = opt.min_relative_decrease;
+        h.opt.min_lm_diagonal = opt.min_lm_diagonal;
+        h.opt.max_lm_diagonal = opt.max_lm_diagonal;
+        h.opt.max_invalid = opt.max_num_consecutive_invalid_steps;
+        h.opt.jacobi_scaling = opt.jacobi_scaling;
+        const int nb = reset ? std::min(256, (6 * std::max(s->B, s->C) + 255) / 256 + 1) : 1;
+        hipLaunchKernelGGL(k_begin_solve, dim3(nb), dim3(256), 0, s->stream, s->S, h, s->C, s->B, s->d_init_cam, s->d_init_intr, s->d_init_board, reset ? 1 : 0);
+    }
 
     int rc;
     if ((rc = enqueue_eval(run, /*cand=*/0, /*init=*/1, /*have_backsub=*/0))) return rc;
@@ -1005,31 +1020,32 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     bool done = false;
     for (int it = 1; it <= opt.max_num_iterations && !done; ++it) {
         if ((rc = enqueue_iteration(run))) return rc;
-        if (it % check_every == 0 || it == opt.max_num_iterations) {
+        if (it % check_every == 0 && it < opt.max_num_iterations) {
             // every rank takes the same decisions from the same all-reduced bits: polling one member is enough
             HIP_TRY(hipMemcpyAsync(s0->h_ctrl, s0->S.ctrl, 64, hipMemcpyDeviceToHost, s0->stream));
             if ((rc = sync_stream(s0))) return rc;
             done = s0->h_ctrl->done != 0;
         }
     }
+    // the accepted point into buffer 0 (k_end_solve), the control block and the iteration log to the host: enqueued
+    // behind the last iteration, ONE synchronisation for the whole solve
+    const size_t ctrl_bytes = offsetof(Ctrl, log) + sizeof(IterLog) * (size_t)std::min(opt.max_num_iterations + 1, kMaxLog);
+    for (tscm_solver *s : run.m) {
+        const int nb = std::min(256, (6 * std::max(s->B, s->C) + 255) / 256 + 1);
+        hipLaunchKernelGGL(k_end_solve, dim3(nb), dim3(256), 0, s->stream, s->S, s->C, s->B);
+        HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->S.ctrl, ctrl_bytes, hipMemcpyDeviceToHost, s->stream));
+    }
     if ((rc = sync_stream(s0))) return rc;
+    for (tscm_solver *s : run.m) if (s->stream != s0->stream) HIP_TRY(hipStreamSynchronize(s->stream));
     const double t1 = wall();
     HIP_TRY(hipGetLastError());
     for (size_t r = 0; r < run.m.size(); ++r) {
         tscm_solver *s = run.m[r];
-        DevState &S = s->S;
         Ctrl *h = s->h_ctrl;
         tscm_summary *sum = &sums[r];
-        HIP_TRY(hipMemcpy(h, S.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
         if ((rc = collect_timing(s))) return rc;
         if (h->fault) return fail(TSCM_E_HIP, "a device-side hand-off (Schur-complement tiles -> reduced solve) did not arrive within its time bound: the solve was stopped");
         if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
-        // the accepted point lives in buffer `cur`; make it buffer 0 for the next resident solve
-        if (h->cur != 0) {
-            HIP_TRY(hipMemcpy(S.cam_rt[0], S.cam_rt[1], sizeof(double) * 6 * s->C, hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemcpy(S.intr[0], S.intr[1], sizeof(double) * 9 * s->C, hipMemcpyDeviceToDevice));
-            if (s->B) HIP_TRY(hipMemcpy(S.board_rt[0], S.board_rt[1], sizeof(double) * 6 * s->B, hipMemcpyDeviceToDevice));
-        }
         sum->termination_type = h->term_type;
         sum->num_iterations = std::min(h->n_log, TSCM_MAX_ITERATIONS + 1);
         sum->num_successful_steps = h->num_successful;
@@ -1046,8 +1062,8 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
             o.step_norm = l.step_norm; o.relative_decrease = l.relative_decrease; o.trust_region_radius = l.radius;
         }
         std::snprintf(sum->message, sizeof(sum->message), "%s", reason_message(h->term_reason));
-        sum->seconds_solve = t1 - t0;
-        sum->seconds_total = t1 - t0;
+        sum->seconds_solve = 1e-8 * (double)(h->t_end - h->t_begin);      // on the device: first to last kernel of the solve
+        sum->seconds_total = t1 - t0;                                     // wall time of the call
         sum->rmse = s->N_total ? std::sqrt(2.0 * h->x_cost / (double)s->N_total) : 0.0;     // cost and N of the WHOLE job
     }
     return 0;
