@@ -104,6 +104,7 @@ __device__ __forceinline__ double quad_tb(double x, double c0, double c1, double
 
 __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S, int cand)
 {
+    KTL(0);
 #ifdef TSCM_ABLATE
     constexpr int ablate = TSCM_ABLATE;      // profiling builds only (make ABLATE=n): 1 no MFMA phases, 2 no epilogue, 4 no geometry
 #else

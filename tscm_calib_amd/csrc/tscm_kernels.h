@@ -57,7 +57,7 @@ constexpr int kCConst = 48;        // per-camera constants: [0,9) R_c, [9,12) t_
 constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 doubles, then the same 48 values as floats
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
-constexpr int kCamG1 = 16;         // first-level fan-in of the per-camera tile reduction
+constexpr int kCamSl = 16;         // the per-camera tile reduction runs in slices of 32 of the 512 raw entries: C * kCamSl workgroups
 constexpr int kSmallBids = 10;     // camera-pair blocks of a rig of <= 4 cameras: their partial-tile ranges travel as kernel arguments
 constexpr int kMaxCamLds = 8;      // n_pad = 16*C <= 128: reduced system solved in registers/LDS (k_solve_reduced)
 constexpr int kMaxCam = 32;        // larger rigs: k_solve_reduced_big factors the system in global memory (n_pad <= 512)
@@ -196,6 +196,7 @@ struct DevProblem {
     // compact [cam_pre[q], cam_pre[q + 1]) = padded cam_col0[q] + 0, 1, ...  (cam_pre[q] = n_act from q = C on).
     // Kernel arguments: the solver computes its operand addresses without a dependent table load.
     int cam_pre[9], cam_col0[8];
+    int cam_wg[9];                     // cam_chunk_ptr by value for rigs of <= kMaxCamLds cameras (k_reduce_control: no index load in front of the tiles)
     // frame sharding (tscm_solver_create_sharded): this rank / number of ranks; 0 / 1 on a single GPU
     int rank, world;
     // T is stored compact: one 16x16 tile per camera-pair block (mi <= mj) that ANY rank contributes to, numbered in
@@ -533,6 +534,30 @@ __device__ __forceinline__ void corner_geometry(double x, double y, double ou, d
 constexpr int kTimelineWaves = 8192;
 __device__ long long g_timeline[4 * kTimelineWaves];     // per wave of k_eval_gram: HW_ID, XCC_ID, start, end (10 ns ticks)
 __device__ long long g_phase[5 * kTimelineWaves];        // per wave of k_eval_gram4: shader clocks per phase, summed over its views
+// per workgroup of the six kernels of an LM iteration (iteration 5): start, end of its thread 0 in 10 ns ticks
+// (tscm_debug_kernel_timeline, tools/kernel_timeline.py: launch gaps, dispatch ramps and tails between the kernels)
+constexpr int kKtlKernels = 6, kKtlGroups = 2048;
+__device__ long long g_ktl[2 * kKtlKernels * kKtlGroups];
+struct KtlScope {
+    long long t0; int id; bool on;
+    __device__ KtlScope(int id_, const Ctrl *c) : t0(wall_clock64()), id(id_), on(c->iteration == 5) {}
+    __device__ ~KtlScope()
+    {
+        if (on && threadIdx.x == 0 && blockIdx.x < kKtlGroups) {
+            g_ktl[2 * (id * kKtlGroups + blockIdx.x)] = t0;
+            g_ktl[2 * (id * kKtlGroups + blockIdx.x) + 1] = wall_clock64();
+        }
+    }
+};
+#define KTL(id) KtlScope ktl_scope(id, S.ctrl)
+__device__ long long g_ktlx[32];         // stamps inside the workgroup that runs the control step (thread 0): kept in LDS
+__shared__ long long s_ktlx[32];         // and written out at the end (a global store in front of a barrier is waited for)
+#define KTLX(i, on) do { if ((on) && threadIdx.x == 0) s_ktlx[i] = wall_clock64(); } while (0)
+#define KTLX_FLUSH() do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 32; ++q_) g_ktlx[q_] = s_ktlx[q_]; } while (0)
+#else
+#define KTL(id)
+#define KTLX(i, on)
+#define KTLX_FLUSH()
 #endif
 #ifndef TSCM_EXP
 #define TSCM_EXP 3     // bit 0: full tiles through gram_full (0 = round 2's paired loop, for A/B runs), bit 1: first MFMA with C = 0
@@ -791,28 +816,39 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
 
 #include "tscm_eval_f32.h"
 
-// per-camera raw tile (GU | GV) reduction, level 1: one block per (camera, group)
-__device__ void cam_reduce1_block(const DevProblem &P, const DevState &S, int blk)
+// per-camera raw tile (GU | GV) reduction: one block per (camera, slice of 32 of the 512 raw entries).  Eight threads per
+// entry take every eighth workgroup tile -- up to 32 loads per thread requested at once -- and are combined through LDS
+// in a fixed order: campart2[cam][512] holds the finished sums (round 3; before: 16 groups of tiles per camera here and
+// a second level in k_finalize_eval, 16 more dependent loads per thread in a kernel that is nothing but a latency chain)
+__device__ void cam_reduce_block(const DevProblem &P, const DevState &S, int blk, double *sm /* 256 doubles */)
 {
-    const int cam = blk / kCamG1, g = blk % kCamG1;
-    const int cb = P.cam_chunk_ptr[cam], ce = P.cam_chunk_ptr[cam + 1];
-    const int n = ce - cb;
-    const int per = (n + kCamG1 - 1) / kCamG1;
-    const int b = cb + g * per, e = min(ce, b + per);
-    const int t = threadIdx.x;
-    // both halves (u-tile, v-tile) in one loop: eight loads in flight per trip
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    const double *src = S.campart + t;
-    int c = b;
-    for (; c + 3 < e; c += 4) {
-        a0 += src[(size_t)512 * c];           b0 += src[(size_t)512 * c + 256];
-        a1 += src[(size_t)512 * (c + 1)];     b1 += src[(size_t)512 * (c + 1) + 256];
-        a2 += src[(size_t)512 * (c + 2)];     b2 += src[(size_t)512 * (c + 2) + 256];
-        a3 += src[(size_t)512 * (c + 3)];     b3 += src[(size_t)512 * (c + 3) + 256];
+    const int cam = blk / kCamSl, sl = blk % kCamSl;
+    int cb, ce;
+    if (P.C <= kMaxCamLds) {
+        cb = P.cam_wg[0]; ce = P.cam_wg[1];
+#pragma unroll
+        for (int q = 1; q < kMaxCamLds; ++q) { cb = cam >= q ? P.cam_wg[q] : cb; ce = cam >= q ? P.cam_wg[q + 1] : ce; }
+    } else {
+        cb = P.cam_chunk_ptr[cam]; ce = P.cam_chunk_ptr[cam + 1];
     }
-    for (; c < e; ++c) { a0 += src[(size_t)512 * c]; b0 += src[(size_t)512 * c + 256]; }
-    S.campart2[(size_t)512 * blk + t] = (a0 + a1) + (a2 + a3);
-    S.campart2[(size_t)512 * blk + 256 + t] = (b0 + b1) + (b2 + b3);
+    const int t = threadIdx.x, o = t & 31, ph = t >> 5;
+    const double *src = S.campart + 32 * sl + o;
+    double acc = 0.0;
+    for (int base = cb + ph; base < ce; base += 256) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int c = base + 8 * u; v[u] = src[(size_t)512 * min(c, ce - 1)]; v[u] = c < ce ? v[u] : 0.0; }
+#pragma unroll
+        for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) v[u] += v[u + w];
+        acc += v[0];
+    }
+    sm[t] = acc;
+    __syncthreads();
+    if (t < 32)
+        S.campart2[(size_t)512 * cam + 32 * sl + t] = ((sm[t] + sm[32 + t]) + (sm[64 + t] + sm[96 + t])) + ((sm[128 + t] + sm[160 + t]) + (sm[192 + t] + sm[224 + t]));
+    __syncthreads();
 }
 
 // All-reduce over the 16 lanes of a DPP row without the LDS crossbar: a butterfly of quad_perm [1,0,3,2], quad_perm
@@ -900,10 +936,24 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
         const int q0 = P.bv_ptr[b], q1 = P.bv_ptr[b + 1];
         if (q1 > q0 && !P.board_const[b]) {         // constant pose blocks are not part of the reduced program
             double g[6] = { 0, 0, 0, 0, 0, 0 }, dg[6] = { 0, 0, 0, 0, 0, 0 };
-            for (int q = q0; q < q1; ++q) {
-                const double *W = rec_w(S.rec[tgt], q);
-                for (int i = 0; i < 6; ++i) g[i] += W[6 * kFR + i];
-                if (init) {                     // diag(E^T E) is only needed for the Jacobi scaling
+            // the gradient columns of up to four views per trip, requested together (a load inside a loop of unknown
+            // length is one memory round trip per view); same order of additions
+            for (int qb = q0; qb < q1; qb += 4) {
+                double w[4][6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double *W = rec_w(S.rec[tgt], min(qb + u, q1 - 1));
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) w[u][i] = W[6 * kFR + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) g[i] += qb + u < q1 ? w[u][i] : 0.0;
+            }
+            if (init) {                         // diag(E^T E) is only needed for the Jacobi scaling
+                for (int q = q0; q < q1; ++q) {
+                    const double *W = rec_w(S.rec[tgt], q);
                     const double *E = rec_e(S.rec[tgt], P.V, q), *Rc = S.cconst[tgt] + kCStride * P.slot_cam[q];
                     for (int i = 0; i < 3; ++i) { dg[i] += E[6 * i + i]; dg[3 + i] += tb_tb(W, Rc, i, i); }
                 }
@@ -925,111 +975,149 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
 }
 
 // one launch for the two independent post-evaluation reductions:
-//   blocks [0, C*kCamG1)            level-1 sums of the per-workgroup camera tiles
-//   blocks [C*kCamG1, +ceil(B/256)) per-board gradient / norm statistics (+ Jacobi scaling at iteration 0)
+//   blocks [0, C*kCamSl)            sums of the per-workgroup camera tiles
+//   blocks [C*kCamSl, +ceil(B/256)) per-board gradient / norm statistics (+ Jacobi scaling at iteration 0)
 __global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, int cand, int init)
 {
+    KTL(1);
     if (S.ctrl->done) return;
     __shared__ double sm[256];
-    const int nc = P.C * kCamG1;
-    if ((int)blockIdx.x < nc) cam_reduce1_block(P, S, blockIdx.x);
+    const int nc = P.C * kCamSl;
+    if ((int)blockIdx.x < nc) cam_reduce_block(P, S, blockIdx.x, sm);
     else board_stats_block(P, S, cand, init, blockIdx.x - nc, sm);
 }
 
-// level-2 camera reduction (raw u/v tiles -> [F|r]^T[F|r]) into H_stage + reduction of the per-block scalar partials.
-// grid (C + 1) x 256.  H_stage = C camera tiles, then kScal scalars: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b
+// H_stage = C camera tiles ([F|r]^T[F|r] from the raw u/v sums), then kScal scalars: [0] model_b [1] stepsq_b [2] xsq_b [3] gsq_b
 // [4] e-block factorisation failures on this rank, then one slot per rank with that rank's board gradient max-norm
 // (zero in the other ranks' slots): ONE sum all-reduce carries sums, the failure flag and the maximum.
 // What the control step reads from memory that does NOT depend on the evaluation being finalised: the LM state and the
-// target point's camera-side parameters.  Loaded at the head of the kernel (by every workgroup: whichever arrives last
-// runs the step), so that the step itself only waits for the staged tiles.
-struct ControlPre { CtrlHead c; double x[2]; };
+// target point's camera-side parameters, requested together with the first loads of the workgroup that runs the step.
+struct ControlPre { CtrlHead c; double x[2]; bool free_param[2]; };
 __device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre)
 {
     pre.c = *S.ctrl;
+    // (both parameter buffers and the camera flags are requested without waiting for `cur`: one round trip, not two)
+    double x0[2], x1[2];
+    int act[2], cst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = threadIdx.x + 256 * j;
+        const int m = min(p >> 4, P.C - 1), a = p & 15;
+        const int ia = a < 6 ? 6 * m + a : 9 * m + min(a - 6, 8);
+        x0[j] = a < 6 ? S.cam_rt[0][ia] : S.intr[0][ia];
+        x1[j] = a < 6 ? S.cam_rt[1][ia] : S.intr[1][ia];
+        act[j] = P.cam_active[m]; cst[j] = P.cam_const[m];
+    }
     const int tgt = init ? pre.c.cur : (pre.c.cur ^ 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int p = threadIdx.x + 256 * j;
-        const int m = p >> 4, a = p & 15;
-        pre.x[j] = (p < 16 * P.C && a < 15) ? (a < 6 ? S.cam_rt[tgt][6 * m + a] : S.intr[tgt][9 * m + (a - 6)]) : 0.0;
+        const int a = p & 15;
+        const bool in = p < 16 * P.C && a < 15;
+        pre.x[j] = in ? (tgt ? x1[j] : x0[j]) : 0.0;
+        pre.free_param[j] = in & (act[j] != 0) & !((a < 6) & (cst[j] != 0));
     }
 }
-__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm);
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy);
 
-// fused_control: -1 = none (multi-GPU: the all-reduce sits between this kernel and k_control);
-// 0 / 1 = the last block to arrive also runs the LM control step with init = fused_control
-// (release/acquire hand-off at agent scope, arrival counter reset for the next launch).
-__global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S, int have_backsub, int fused_control)
+// raw (GU | GV) tile of one camera (G: 512 doubles in LDS) -> H layout: 14x14 [F | r]^T [F | r] in a 16x16 slot
+__device__ __forceinline__ double camera_tile_entry(const double *G, int t)
 {
-    ControlPre pre;
-    if (fused_control >= 0) control_prefetch(P, S, fused_control, pre);
-    if (S.ctrl->done) return;
+    const int a = t >> 4, b = t & 15;
+    double v = 0.0;
+    if (a < 14 && b < 14) {
+        const int ta = f_tile(a), tb = f_tile(b), m = f_mask(a) & f_mask(b);
+        if (m & 1) v += G[ta * 16 + tb];
+        if (m & 2) v += G[256 + ta * 16 + tb];
+    }
+    return v;
+}
+
+// the per-workgroup scalar partials of the back-substitution and of the board statistics -> the kScal + world scalars
+// that follow the camera tiles in H_stage, written to `sc` (global or LDS; 256 threads; sm: block_reduce256 scratch).
+// Every load is unconditional (clamped index, value masked): a load under `if (i < n)` is a branch with its own wait,
+// and the eight + four of them in the ragged ends were twelve memory round trips in a row (5 us of the control
+// workgroup's 10, tools/kernel_timeline.py).
+__device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, const DevState &S, int have_backsub, int lin_fail, double *sc, double *sm)
+{
+    const int t = threadIdx.x;
+    double mb = 0.0, ss = 0.0;
+    if (have_backsub) {
+        const d2 *bp = reinterpret_cast<const d2 *>(S.bs_part);
+        const int n = S.n_bs_blocks;
+        d2 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = d2{ 0.0, 0.0 };
+        for (int i = t; i < n; i += 8 * 256) {
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = bp[min(i + 256 * u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += i + 256 * u < n ? v[u] : d2{ 0.0, 0.0 };
+        }
+        const d2 r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        mb = r[0]; ss = r[1];
+    }
+    double gm = 0.0, gs = 0.0, xs = 0.0;
+    {
+        const int n = S.n_st_blocks;
+        double g4[4] = { 0, 0, 0, 0 }, s4[4] = { 0, 0, 0, 0 }, x4[4] = { 0, 0, 0, 0 };
+        for (int i = t; i < n; i += 4 * 256) {
+            double q[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + 3 * (size_t)min(i + 256 * u, n - 1); q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const bool in = i + 256 * u < n; g4[u] = fmax(g4[u], in ? q[u][0] : 0.0); s4[u] += in ? q[u][1] : 0.0; x4[u] += in ? q[u][2] : 0.0; }
+        }
+        gm = fmax(fmax(g4[0], g4[1]), fmax(g4[2], g4[3])); gs = (s4[0] + s4[1]) + (s4[2] + s4[3]); xs = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+    }
+    double red[4] = { mb, ss, gs, xs };
+    block_reduce256<4>(red, gm, sm);
+    mb = red[0]; ss = red[1]; gs = red[2]; xs = red[3];
+    if (t == 0) {
+        sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = lin_fail ? 1.0 : 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
+        for (int r = 0; r < P.world; ++r) sc[kScal + r] = r == P.rank ? gm : 0.0;
+    }
+}
+
+// camera tiles (raw u/v sums -> [F|r]^T[F|r]) into H_stage + reduction of the per-block scalar partials, for the paths
+// with something between the evaluation and the control step (all-reduce: k_control follows) or without a control step
+// (tscm_eval_normal_equations).  grid (C + 1) x 256, or C x 256 for the camera tiles alone.
+__global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S, int have_backsub)
+{
+    KTL(2);
+    const int done = S.ctrl->done, lin_fail = S.ctrl->lin_fail;
+    if (done) return;
     __shared__ double sm[256];
     __shared__ double G[512];
-    __shared__ int s_last;
     const int t = threadIdx.x;
     if ((int)blockIdx.x < P.C) {
         const int cam = blockIdx.x;
-        for (int half = 0; half < 2; ++half) {
-            double a = 0.0;
-            for (int g = 0; g < kCamG1; ++g) a += S.campart2[(size_t)512 * (cam * kCamG1 + g) + 256 * half + t];
-            G[256 * half + t] = a;
-        }
+        G[t] = S.campart2[(size_t)512 * cam + t];
+        G[256 + t] = S.campart2[(size_t)512 * cam + 256 + t];
         __syncthreads();
-        // raw (GU | GV) tile -> H layout: 14x14 [F | r]^T [F | r] in a 16x16 slot
-        const int a = t >> 4, b = t & 15;
-        double v = 0.0;
-        if (a < 14 && b < 14) {
-            const int ta = f_tile(a), tb = f_tile(b), m = f_mask(a) & f_mask(b);
-            if (m & 1) v += G[ta * 16 + tb];
-            if (m & 2) v += G[256 + ta * 16 + tb];
-        }
-        S.H_stage[256 * cam + t] = v;
+        S.H_stage[256 * cam + t] = camera_tile_entry(G, t);
     } else {
-        // the per-workgroup partials of the back-substitution (thousands of them): eight independent 16-byte loads in
-        // flight per thread -- as a plain loop every trip was a memory round trip (5 trips at config 4, 20 at config 5)
-        double mb = 0.0, ss = 0.0;
-        if (have_backsub) {
-            const d2 *bp = reinterpret_cast<const d2 *>(S.bs_part);
-            const int n = S.n_bs_blocks;
-            d2 a[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = d2{ 0.0, 0.0 };
-            int i = t;
-            for (; i + 7 * 256 < n; i += 8 * 256) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += bp[i + 256 * u];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (i + 256 * u < n) a[u] += bp[i + 256 * u];
-            const d2 r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-            mb = r[0]; ss = r[1];
-        }
-        double gm = 0.0, gs = 0.0, xs = 0.0;
-        {
-            const int n = S.n_st_blocks;
-            double g4[4] = { 0, 0, 0, 0 }, s4[4] = { 0, 0, 0, 0 }, x4[4] = { 0, 0, 0, 0 };
-            int i = t;
-            for (; i + 3 * 256 < n; i += 4 * 256) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const double *q = S.st_part + 3 * (size_t)(i + 256 * u); g4[u] = fmax(g4[u], q[0]); s4[u] += q[1]; x4[u] += q[2]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (i + 256 * u < n) { const double *q = S.st_part + 3 * (size_t)(i + 256 * u); g4[u] = fmax(g4[u], q[0]); s4[u] += q[1]; x4[u] += q[2]; }
-            gm = fmax(fmax(g4[0], g4[1]), fmax(g4[2], g4[3])); gs = (s4[0] + s4[1]) + (s4[2] + s4[3]); xs = (x4[0] + x4[1]) + (x4[2] + x4[3]);
-        }
-        double red[4] = { mb, ss, gs, xs };
-        block_reduce256<4>(red, gm, sm);
-        mb = red[0]; ss = red[1]; gs = red[2]; xs = red[3];
-        if (t == 0) {
-            double *sc = S.H_stage + 256 * P.C;
-            sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = S.ctrl->lin_fail ? 1.0 : 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
-            for (int r = 0; r < P.world; ++r) sc[kScal + r] = r == P.rank ? gm : 0.0;
-        }
+        reduce_scalar_partials(P, S, have_backsub, lin_fail, S.H_stage + 256 * P.C, sm);
     }
-    if (fused_control < 0) return;
-    // ---- last block to arrive runs the control step (cdna guide G16: release -> counter -> acquire) ----
+}
+
+// One GPU: everything between the evaluation and the next Schur complement in ONE launch (round 3; before:
+// k_reduce_stats, k_finalize_eval with a second reduction level, the control step in its last workgroup -- 6.6 + 16.4 us
+// of an iteration of 131, every dependent load of these small kernels a cold round trip of 1-2 us).  The workgroups
+// are k_reduce_stats' (camera-tile slices, board statistics); whichever arrives last (release -> counter -> acquire at
+// agent scope, cdna guide G16) requests in ONE batch what is left -- the 512 finished sums per camera, the scalar
+// partials, the LM state, the target point's camera parameters -- forms H_stage and runs the control step.
+__global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S, int cand, int init, int have_backsub)
+{
+    KTL(1);
+    if (S.ctrl->done) return;
+    __shared__ double sm[256];
+    __shared__ int s_last;
+    const int t = threadIdx.x;
+    const int nc = P.C * kCamSl;
+    if ((int)blockIdx.x < nc) cam_reduce_block(P, S, blockIdx.x, sm);
+    else board_stats_block(P, S, cand, init, blockIdx.x - nc, sm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
@@ -1040,12 +1128,41 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
     }
     __syncthreads();
     if (!s_last) return;
+    KTLX(0, true);
     if (t == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(&S.ctrl->fin_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    control_step(P, S, fused_control, pre, sm);
+    KTLX(1, true);
+    // ---- the last workgroup: one batch of loads, H in LDS and in both global places, the control step on the LDS copy
+    __shared__ double Hl[256 * kMaxCamLds + kScal + 8];
+    __shared__ double Gall[512 * kMaxCamLds];
+    ControlPre pre;
+    control_prefetch(P, S, init, pre);
+    double gu[kMaxCamLds], gv[kMaxCamLds];
+#pragma unroll
+    for (int m = 0; m < kMaxCamLds; ++m) {
+        const int cam = min(m, P.C - 1);
+        gu[m] = S.campart2[(size_t)512 * cam + t];
+        gv[m] = S.campart2[(size_t)512 * cam + 256 + t];
+    }
+    double *scl = Hl + 256 * P.C;
+    reduce_scalar_partials(P, S, have_backsub, pre.c.lin_fail, scl, sm);
+    KTLX(2, true);
+    // (all cameras' raw tiles in LDS at once: one barrier, not two per camera)
+#pragma unroll
+    for (int m = 0; m < kMaxCamLds; ++m) if (m < P.C) { Gall[512 * m + t] = gu[m]; Gall[512 * m + 256 + t] = gv[m]; }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kMaxCamLds; ++m) if (m < P.C) Hl[256 * m + t] = camera_tile_entry(Gall + 512 * m, t);
+    __syncthreads();
+    KTLX(3, true);
+    // (no global store up to here: a barrier behind one waits for its acknowledgement, a microsecond.  The control
+    // step writes H -- and H_stage, for whoever reads the staged copy -- behind its own last barrier.)
+    control_step(P, S, init, pre, sm, Hl, scl, S.H_stage);
+    KTLX(8, true);
+    KTLX_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1229,6 +1346,7 @@ struct RawTc {
 template <int NV>
 __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0)
 {
+    KTL(3);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
     const int4 desc = P.bc_desc[chunk0 + blockIdx.x];
@@ -1645,6 +1763,7 @@ constexpr long long kHandoffTimeoutTicks = 50 * 1000 * 1000;          // 0.5 s
 template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
 __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S, int epoch, int withhold)
 {
+    KTL(4);
     constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
     if constexpr (FUSED) {
         static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
@@ -2300,6 +2419,7 @@ template <int NTH> struct BsGeom {
 template <int NTH>
 __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
 {
+    KTL(5);
     constexpr int kBsBoards = BsGeom<NTH>::kBoards, kBsThreads = NTH, kLoads = BsGeom<NTH>::kLoads;
     // head: control block and slot range in one round trip
     const int b0 = blockIdx.x * kBsBoards;
@@ -2501,7 +2621,9 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
 // one thread.  `init` = IterationZero; otherwise the tail of one loop iteration followed by
 // FinalizeIterationAndCheckIfMinimizerCanContinue.
 // ---------------------------------------------------------------------------------------------
-__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm)
+// H: the (all-reduced) camera tiles, sc: the scalars behind them -- H_stage in global memory, or the LDS copy of the
+// workgroup that formed them (k_reduce_control: stage_copy = H_stage, which then receives a copy as well)
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy)
 {
     // The LM state is read ONCE (wide loads, one memory round trip -- by control_prefetch, at the head of the kernel),
     // advanced in registers and written back once: as individual fields in global memory the ~40 dependent loads and
@@ -2512,11 +2634,6 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
     const int t = threadIdx.x;
-    // publish the staged (all-reduced) camera tiles as the target system's H
-#pragma unroll 8
-    for (int i = t; i < 256 * P.C; i += 256) S.H[tgt][i] = S.H_stage[i];
-    const double *H = S.H_stage;
-    const double *sc = S.H_stage + 256 * P.C;
     // camera-side norms |x - Plus(x, -g)|_inf, its 2-norm, |x|^2 and the cost, one thread per parameter
     double gmax_c = 0.0, gsq_c = 0.0, xsq_c = 0.0, cost = 0.0;
 #pragma unroll
@@ -2524,7 +2641,7 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
         const int p = t + 256 * j;
         if (p >= 16 * P.C) break;
         const int m = p >> 4, a = p & 15;
-        if (a < 15 && P.cam_active[m] && !(a < 6 && P.cam_const[m])) {
+        if (pre.free_param[j]) {
             const double x = pre.x[j];
             const double g = a < kFA ? H[256 * m + a * 16 + kFR] : 0.0;   // b, c: zero gradient
             const double d = x - (x + (-g));
@@ -2537,7 +2654,14 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
         }
         if (init && a == 15) S.s_c[p] = 1.0;
     }
+    KTLX(4, true);
     { double red[3] = { gsq_c, xsq_c, cost }; block_reduce256<3>(red, gmax_c, sm); gsq_c = red[0]; xsq_c = red[1]; cost = red[2]; }
+    KTLX(5, true);
+    // publish the staged (all-reduced) camera tiles as the target system's H -- behind the last barrier of this step: a
+    // barrier with global stores in flight waits for their acknowledgement
+#pragma unroll 8
+    for (int i = t; i < 256 * P.C; i += 256) { const double h = H[i]; S.H[tgt][i] = h; if (stage_copy) stage_copy[i] = h; }
+    if (stage_copy && t < kScal + P.world) stage_copy[256 * P.C + t] = sc[t];
     if (t != 0) return;
     auto commit = [&]() { c.fin_count = 0; static_cast<CtrlHead &>(g) = c; };
     double gmax_b = 0.0;
@@ -2546,6 +2670,7 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
     if (sc[4] > 0.0) c.lin_fail = 1;          // an e-block factorisation failed on some rank: every rank rejects the step
     const double gnorm_t = sqrt(gsq_c + sc[3]);
     const double xnorm_t = sqrt(xsq_c + sc[2]);
+    KTLX(6, true);
 
     IterLog it;
     it.pad = 0;
@@ -2630,7 +2755,7 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
     __shared__ double sm[256];
     ControlPre pre;
     control_prefetch(P, S, init, pre);
-    control_step(P, S, init, pre, sm);
+    control_step(P, S, init, pre, sm, S.H_stage, S.H_stage + 256 * P.C, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

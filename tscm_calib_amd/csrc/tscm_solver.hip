@@ -497,6 +497,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.chunk_ve, chunk_ve))) return rc;
     if ((rc = dev_upload(s, &P.chunk_cam, chunk_cam))) return rc;
     if ((rc = dev_upload(s, &P.cam_chunk_ptr, cam_chunk_ptr))) return rc;
+    for (int q = 0; q <= kMaxCamLds; ++q) P.cam_wg[q] = cam_chunk_ptr[std::min(q, C)];
     if ((rc = dev_upload(s, &P.bv_ptr, bv_ptr))) return rc;
     if ((rc = dev_upload(s, &P.view_slot, view_slot))) return rc;
     if ((rc = dev_upload(s, &P.slot_cam, slot_cam))) return rc;
@@ -603,7 +604,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.vconst, (size_t)kVStride * V))) return rc;
     for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(s, &S.cconst[k], (size_t)kCStride * C))) return rc;
     if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)(P.n_chunks / 4)))) return rc;
-    if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C * kCamG1))) return rc;
+    if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C))) return rc;
     if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal + world))) return rc;
     if ((rc = dev_alloc(s, &S.s_b, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.s_c, (size_t)s->n_pad))) return rc;
@@ -621,7 +622,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.ctrl, 1))) return rc;
     HIP_TRY(hipMemset(S.T, 0, sizeof(double) * 256 * (size_t)n_bids));
     HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal + world)));
-    HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 512 * (size_t)C * kCamG1));
+    HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 512 * (size_t)C));
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
@@ -844,16 +845,22 @@ static int exchange(LmRun &run, bool t_buffer)
 static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
 {
     const bool sep = run.separate_control();
+    const bool fused = !sep && run.m[0]->P.C <= kMaxCamLds;     // (rigs of more than 8 cameras: k_control as a launch of its own)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
         // the constants of a candidate point were written by k_backsub_prep; the initial point needs them here
         if (!have_backsub) hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
         if (int rc = launch_eval(s, cand)) return rc;
-        hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1 + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
-        hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub, sep ? -1 : init);
+        if (fused) {
+            // one GPU: reductions, statistics and the control step in one launch
+            hipLaunchKernelGGL(k_reduce_control, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init, have_backsub);
+            continue;
+        }
+        hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
+        hipLaunchKernelGGL(k_finalize_eval, dim3(P.C + 1), dim3(256), 0, s->stream, P, S, have_backsub);
     }
-    if (!sep) return 0;                   // single GPU: the control step is fused into k_finalize_eval
+    if (fused) return 0;
     if (int rc = exchange(run, /*t_buffer=*/false)) return rc;
     for (tscm_solver *s : run.m) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, init);
     return 0;
@@ -1242,8 +1249,8 @@ extern "C" int tscm_eval_normal_equations(const tscm_problem *p, int device, dou
     const DevProblem &P = s->P;
     DevState &S = s->S;
     if ((rc = launch_eval(s, 0))) return rc;
-    hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamG1), dim3(256), 0, s->stream, P, S, 0, 0);   // camera blocks only
-    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C), dim3(256), 0, s->stream, P, S, 0, -1);        // camera blocks only
+    hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamSl), dim3(256), 0, s->stream, P, S, 0, 0);   // camera blocks only
+    hipLaunchKernelGGL(k_finalize_eval, dim3(P.C), dim3(256), 0, s->stream, P, S, 0);            // camera blocks only
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipGetLastError());
     std::vector<double> rec((size_t)kRec * s->V), H(256 * (size_t)s->C), cc((size_t)kCStride * s->C);
@@ -1453,6 +1460,19 @@ extern "C" int tscm_debug_wave_timeline(long long *out, int max_waves)
     if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_timeline), sizeof(long long) * 4 * (size_t)n) != hipSuccess) return TSCM_E_HIP;
     return n;
+}
+extern "C" int tscm_debug_kernel_timeline(long long *out, int max_groups)
+{
+    if (max_groups < tscm::kKtlGroups) return TSCM_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_ktl), sizeof(long long) * 2 * tscm::kKtlKernels * tscm::kKtlGroups) != hipSuccess) return TSCM_E_HIP;
+    return tscm::kKtlKernels;
+}
+extern "C" int tscm_debug_control_stamps(long long *out)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_ktlx), sizeof(long long) * 32) != hipSuccess) return TSCM_E_HIP;
+    return 32;
 }
 extern "C" int tscm_debug_wave_phases(long long *out, int max_waves)
 {
