@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 
 # (the library takes at most TSCM_MAX_ITERATIONS = 255 iterations per solve)
 ITERS_PER_SOLVE = min(255, max(1, int(os.environ.get("TSCM_BENCH_ITERS_PER_SOLVE", "50"))))
+PREHEAT_MS = float(os.environ.get("TSCM_BENCH_PREHEAT_MS", "60"))
 # algorithmic work of one k_eval_gram launch (DESIGN.md "roofline accounting")
 FLOP_MFMA_PER_CORNER = 836           # Gram contraction 2P(P+1)+4P with P=19
 FLOP_VALU_PER_CORNER = 600           # hand-structured residual + analytic Jacobian
@@ -345,6 +346,11 @@ def main():
     if args.exec_flags:
         extra["exec_flags"] = args.exec_flags
     natural = solver.solve_resident(reset=True, **extra)
+    # the hot path itself for PREHEAT_MS before the W warmup steps (untimed): the fp64 ceilings above leave the device
+    # at sustained clocks, this keeps it there through the host-side work in between
+    t_pre = time.perf_counter()
+    while not stub and (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS:
+        run_iterations(solver, ITERS_PER_SOLVE, **extra)
     if args.warmup > 0:
         run_iterations(solver, args.warmup, **extra)
     # HIP events around every stride-th launch of the dominant kernel (each pair holds the stream for ~6 us) -- and,

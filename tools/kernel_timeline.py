@@ -16,7 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tscm_calib_amd import api, lib, synth  # noqa: E402
 
-NAMES = ["k_eval_gram4", "k_reduce_stats", "k_finalize_eval", "k_schur_gram", "k_solve_reduced", "k_backsub_prep"]
+NAMES = ["k_eval_gram4", "k_reduce_control", "(k_finalize_eval: comm path only)", "k_schur_gram", "k_solve_reduced", "k_backsub_prep"]
 ORDER = [3, 4, 5, 0, 1, 2]          # launch order inside an LM iteration
 GROUPS = 2048
 
@@ -51,13 +51,21 @@ def main():
         print(f"{NAMES[k]:18s} {len(rows):5d} {gap:6.2f} {(s1 - s0) / 100.0:6.2f} {(e0 - s0) / 100.0:9.2f} {(e1 - s0) / 100.0:8.2f} "
               f"{statistics.median((rows[:, 1] - rows[:, 0]).tolist()) / 100.0:9.2f} {(e1 - (prev_end if prev_end is not None else s0)) / 100.0:7.2f}")
         prev_end = e1
+    nc = p.n_cameras * 16
+    rc = t[1]
+    cam, brd = rc[:nc][rc[:nc, 1] > 0], rc[nc:][rc[nc:, 1] > 0]
+    if len(cam) and len(brd):
+        k0 = rc[rc[:, 1] > 0][:, 0].min()
+        print(f"k_reduce_control: camera-tile workgroups ({len(cam)}) end {np.median(cam[:, 1] - k0) / 100.0:.2f} us after the first start "
+              f"(max {(cam[:, 1].max() - k0) / 100.0:.2f}), board-statistics workgroups ({len(brd)}) {np.median(brd[:, 1] - k0) / 100.0:.2f} "
+              f"(max {(brd[:, 1].max() - k0) / 100.0:.2f}); median durations {np.median(cam[:, 1] - cam[:, 0]) / 100.0:.2f} / {np.median(brd[:, 1] - brd[:, 0]) / 100.0:.2f}")
     if xs.any():
         k0 = t[1][t[1][:, 1] > 0][:, 0].min()
         lab = {0: "last arrival known", 1: "acquired", 2: "scalars reduced", 3: "H_stage written", 4: "control: norms", 5: "control: reduced",
                6: "control: scalars read", 8: "control done"}
         print("workgroup of the control step, us after the first start of its kernel: " +
               ", ".join(f"{lab[i]} {(xs[i] - k0) / 100.0:.2f}" for i in sorted(lab) if xs[i] > 0))
-    print(f"iteration (first start of k_schur_gram -> last end of k_finalize_eval): {(prev_end - t_first) / 100.0:.1f} us")
+    print(f"iteration (first start of k_schur_gram -> last end of k_reduce_control): {(prev_end - t_first) / 100.0:.1f} us")
     print("gap: last end of the kernel before -> first start; ramp: first -> last workgroup start; kernel: last end before -> last end")
 
 

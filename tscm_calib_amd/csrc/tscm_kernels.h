@@ -148,7 +148,7 @@ struct CtrlHead {
     // ---- header (polled by the host) ----
     int done, term_type, term_reason, iteration;
     int cur, lin_fail, num_successful, num_unsuccessful;
-    int num_invalid, n_log, lm_iterations, fin_count;   // fin_count: arrival counter of k_finalize_eval
+    int num_invalid, n_log, lm_iterations, fin_count;   // fin_count: arrival counter of k_reduce_control
     int fault, pad0;                    // fault: a device-side hand-off timed out (sticky; the host turns it into TSCM_E_HIP)
     double radius, decrease_factor;
     double x_cost, x_norm, gmax, gnorm;
@@ -816,6 +816,20 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
 
 #include "tscm_eval_f32.h"
 
+// Device-side hand-offs (many producer workgroups -> the workgroup that consumes their results in the SAME launch).
+// The textbook form -- plain stores, release fence, counter; counter, acquire fence, plain loads -- makes every producer
+// issue a `buffer_wbl2` (the agent-scope release fence writes its XCD's L2 back).  Measured with tools/kernel_timeline.py:
+// with the fences the producers of k_reduce_control ended 4.9 us (143 workgroups, config 4) and 16 us (441, config 5)
+// after the kernel's first start, whatever they computed.  Here the handed-over values are written THROUGH instead
+// (agent-scope stores: `global_store ... sc1`), a producer waits for their completion (`s_waitcnt vmcnt(0)`, then the
+// workgroup barrier) and only then counts itself in; the consumer reads them with agent-scope loads (`sc1`: not from its
+// own XCD's L2).  No L2 write-back anywhere: 4.0 / 6-8 us, the iteration 130.1 -> 127.9 us (config 4), 393.8 -> 381.2
+// (config 5), same bits.  Everything else a kernel writes stays an ordinary store and reaches the next kernel through
+// the kernel boundary as before.  (Counting the arrivals in two levels, sixteen workgroups per counter, was slower:
+// contention on the single counter is not what the producers wait for.)
+__device__ __forceinline__ void handoff_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double handoff_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // per-camera raw tile (GU | GV) reduction: one block per (camera, slice of 32 of the 512 raw entries).  Eight threads per
 // entry take every eighth workgroup tile -- up to 32 loads per thread requested at once -- and are combined through LDS
 // in a fixed order: campart2[cam][512] holds the finished sums (round 3; before: 16 groups of tiles per camera here and
@@ -847,7 +861,7 @@ __device__ void cam_reduce_block(const DevProblem &P, const DevState &S, int blk
     sm[t] = acc;
     __syncthreads();
     if (t < 32)
-        S.campart2[(size_t)512 * cam + 32 * sl + t] = ((sm[t] + sm[32 + t]) + (sm[64 + t] + sm[96 + t])) + ((sm[128 + t] + sm[160 + t]) + (sm[192 + t] + sm[224 + t]));
+        handoff_store(&S.campart2[(size_t)512 * cam + 32 * sl + t], ((sm[t] + sm[32 + t]) + (sm[64 + t] + sm[96 + t])) + ((sm[128 + t] + sm[160 + t]) + (sm[192 + t] + sm[224 + t])));
     __syncthreads();
 }
 
@@ -971,7 +985,7 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
     double red[2] = { gsq, xsq }, m = gmax;
     block_reduce256<2>(red, m, sm);
     const double s1 = red[0], s2 = red[1];
-    if (threadIdx.x == 0) { S.st_part[3 * blk] = m; S.st_part[3 * blk + 1] = s1; S.st_part[3 * blk + 2] = s2; }
+    if (threadIdx.x == 0) { handoff_store(&S.st_part[3 * blk], m); handoff_store(&S.st_part[3 * blk + 1], s1); handoff_store(&S.st_part[3 * blk + 2], s2); }
 }
 
 // one launch for the two independent post-evaluation reductions:
@@ -1065,7 +1079,7 @@ __device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, cons
         for (int i = t; i < n; i += 4 * 256) {
             double q[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + 3 * (size_t)min(i + 256 * u, n - 1); q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2]; }
+            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + 3 * (size_t)min(i + 256 * u, n - 1); q[u][0] = handoff_load(src); q[u][1] = handoff_load(src + 1); q[u][2] = handoff_load(src + 2); }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const bool in = i + 256 * u < n; g4[u] = fmax(g4[u], in ? q[u][0] : 0.0); s4[u] += in ? q[u][1] : 0.0; x4[u] += in ? q[u][2] : 0.0; }
         }
@@ -1093,8 +1107,8 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
     const int t = threadIdx.x;
     if ((int)blockIdx.x < P.C) {
         const int cam = blockIdx.x;
-        G[t] = S.campart2[(size_t)512 * cam + t];
-        G[256 + t] = S.campart2[(size_t)512 * cam + 256 + t];
+        G[t] = handoff_load(&S.campart2[(size_t)512 * cam + t]);
+        G[256 + t] = handoff_load(&S.campart2[(size_t)512 * cam + 256 + t]);
         __syncthreads();
         S.H_stage[256 * cam + t] = camera_tile_entry(G, t);
     } else {
@@ -1118,21 +1132,18 @@ __global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S
     const int nc = P.C * kCamSl;
     if ((int)blockIdx.x < nc) cam_reduce_block(P, S, blockIdx.x, sm);
     else board_stats_block(P, S, cand, init, blockIdx.x - nc, sm);
+    // hand-off without an L2 write-back (handoff_store): the written-through results are complete, then the count
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = __hip_atomic_fetch_add(&S.ctrl->fin_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
     KTLX(0, true);
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(&S.ctrl->fin_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) __hip_atomic_store(&S.ctrl->fin_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv: whatever else this workgroup reads from now on is current)
     __syncthreads();
     KTLX(1, true);
     // ---- the last workgroup: one batch of loads, H in LDS and in both global places, the control step on the LDS copy
@@ -1144,8 +1155,8 @@ __global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S
 #pragma unroll
     for (int m = 0; m < kMaxCamLds; ++m) {
         const int cam = min(m, P.C - 1);
-        gu[m] = S.campart2[(size_t)512 * cam + t];
-        gv[m] = S.campart2[(size_t)512 * cam + 256 + t];
+        gu[m] = handoff_load(&S.campart2[(size_t)512 * cam + t]);
+        gv[m] = handoff_load(&S.campart2[(size_t)512 * cam + 256 + t]);
     }
     double *scl = Hl + 256 * P.C;
     reduce_scalar_partials(P, S, have_backsub, pre.c.lin_fail, scl, sm);
@@ -1561,7 +1572,7 @@ __device__ __forceinline__ void t_reduce_block(const DevState &S, int bid, int p
         for (int w = kTSlices / 2; w >= 1; w >>= 1)
 #pragma unroll
             for (int q = 0; q < w; ++q) v[q] += v[q + w];
-        S.T[(size_t)256 * bid + entry] = v[0];
+        handoff_store(&S.T[(size_t)256 * bid + entry], v[0]);      // (written through: the fused launch hands T over inside the launch)
     }
 }
 // grid (n_bids * 256 / kTEntries) x 1024: block (bid, part) sums kTEntries entries of the partial tiles that belong to
@@ -1776,11 +1787,8 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
             t_reduce_block<kFusedEntries>(S, bid, part, cb, ce, red);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0 && !(withhold && blockIdx.x == 1)) {      // (withhold: fault injection, TSCM_EXEC_TEST_WITHHOLD_HANDOFF)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(S.t_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (threadIdx.x == 0 && !(withhold && blockIdx.x == 1))        // (withhold: fault injection, TSCM_EXEC_TEST_WITHHOLD_HANDOFF)
+                __hip_atomic_fetch_add(S.t_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (no release fence: handoff_store)
             return;
         }
     }
@@ -1864,7 +1872,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
 #pragma unroll
     for (int r = 0; r < TS; ++r)
 #pragma unroll
-        for (int c = 0; c < TS; ++c) { const int ot = off[kMapT + r * TS + c]; tt[r][c] = ot >= 0 ? S.T[ot] : 0.0; }
+        for (int c = 0; c < TS; ++c) { const int ot = off[kMapT + r * TS + c]; tt[r][c] = ot >= 0 ? (FUSED ? handoff_load(&S.T[ot]) : S.T[ot]) : 0.0; }
     PHASE_STAMP(ts0b);
     if (tid == 0) s_fail = ctrl_fail;
     double a[TS][TS];
@@ -2769,7 +2777,8 @@ __global__ __launch_bounds__(256) void k_begin_solve(DevState S, CtrlHead head, 
                                                      const double *init_intr, const double *init_board, int reset)
 {
     const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
-    if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; *S.t_count = 0; }
+    if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
+    if (i0 == 0) *S.t_count = 0;          // every solve starts with the arrival counter of the fused T reduction at zero
     if (!reset) return;
     for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = init_cam[i];
     for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = init_intr[i];
