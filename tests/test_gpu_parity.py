@@ -424,6 +424,22 @@ def test_gram_on_4x4_blocks_and_on_the_16x16_tile_agree_bit_for_bit(hip_device, 
     assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_backsub_inside_the_solve_launch_and_as_a_launch_of_its_own_agree_bit_for_bit(hip_device, cfg):
+    """One GPU, <= 4 cameras: the back-substitution workgroups ride in the reduced solve's launch, load their operands
+    and wait for the camera step (y_flag); tscm_options.exec_flags = TSCM_EXEC_SEPARATE_BACKSUB launches k_backsub_prep
+    on its own.  Same arithmetic either way: the solves must agree bit for bit."""
+    p = synth.make_config(cfg)
+    a, b = p.copy().normalised(), p.copy().normalised()
+    with api.Solver(a) as s:
+        sa = s.solve()
+    with api.Solver(b) as s:
+        sb = s.solve(exec_flags=lib.EXEC_SEPARATE_BACKSUB)
+    assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+    assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
+    assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
 def test_late_handoff_is_a_hard_error(hip_device):
     """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
     counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld

@@ -92,9 +92,12 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigne
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
+#ifndef TSCM_STORE_AUX
+#define TSCM_STORE_AUX 0      // cache policy of the record stores (experiment: 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#endif
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v), r, (int)voff, (int)soff, TSCM_STORE_AUX);
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -107,7 +110,7 @@ __device__ __forceinline__ d2 buf_load_2f64(__amdgpu_buffer_rsrc_t r, unsigned v
 __device__ __forceinline__ void buf_store_2f64(__amdgpu_buffer_rsrc_t r, unsigned voff, double a, double b)
 {
     const d2 v = { a, b };
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, (int)voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, (int)voff, 0, TSCM_STORE_AUX);
 }
 
 // Wave priority rule of k_eval_gram (see there; s_setprio takes an immediate, p is wave-uniform)
@@ -221,6 +224,7 @@ struct DevState {
     double *fac;                       // [B][kFac] e-block factors
     double *pairpart, *T;
     int *t_count;                      // arrival counter of the fused T reduction + reduced solve (k_solve_reduced<..., true>)
+    int *y_flag;                       // 2 * epoch + lin_fail once the camera step of that fused launch is written (backsub_body<.., true> waits for it)
     double *yhat;
     double *Abig;                      // compact reduced system + rhs row in 16x16 blocks, rigs of more than kMaxCamLds cameras only
     double *bs_part, *st_part;
@@ -280,6 +284,20 @@ __device__ __forceinline__ void view_point_constants(const double Rc[9], const d
     }
 }
 
+// Device-side hand-offs (many producer workgroups -> the workgroup that consumes their results in the SAME launch).
+// The textbook form -- plain stores, release fence, counter; counter, acquire fence, plain loads -- makes every producer
+// issue a `buffer_wbl2` (the agent-scope release fence writes its XCD's L2 back).  Measured with tools/kernel_timeline.py:
+// with the fences the producers of k_reduce_control ended 4.9 us (143 workgroups, config 4) and 16 us (441, config 5)
+// after the kernel's first start, whatever they computed.  Here the handed-over values are written THROUGH instead
+// (agent-scope stores: `global_store ... sc1`), a producer waits for their completion (`s_waitcnt vmcnt(0)`, then the
+// workgroup barrier) and only then counts itself in; the consumer reads them with agent-scope loads (`sc1`: not from its
+// own XCD's L2).  No L2 write-back anywhere: 4.0 / 6-8 us, the iteration 130.1 -> 127.9 us (config 4), 393.8 -> 381.2
+// (config 5), same bits.  Everything else a kernel writes stays an ordinary store and reaches the next kernel through
+// the kernel boundary as before.  (Counting the arrivals in two levels, sixteen workgroups per counter, was slower:
+// contention on the single counter is not what the producers wait for.)
+__device__ __forceinline__ void handoff_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double handoff_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // the per-camera record of the evaluation target (doubles, then the same values as floats)
 __device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m)
 {
@@ -293,7 +311,8 @@ __device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, 
     for (int k = 0; k < 3; ++k) o[21 + k] = wsm[k];
     o[24] = small ? 1.0 : 0.0;
     for (int k = 25; k < 39; ++k) o[k] = 0.0;
-    const double *I = S.intr[tgt] + 9 * m;
+    double I[7];
+    for (int k = 0; k < 7; ++k) I[k] = S.intr[tgt][9 * m + k];
     for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
     const double oma = 1.0 - I[6];
     o[45] = I[6] / oma;
@@ -539,13 +558,13 @@ __device__ long long g_phase[5 * kTimelineWaves];        // per wave of k_eval_g
 constexpr int kKtlKernels = 6, kKtlGroups = 2048;
 __device__ long long g_ktl[2 * kKtlKernels * kKtlGroups];
 struct KtlScope {
-    long long t0; int id; bool on;
-    __device__ KtlScope(int id_, const Ctrl *c) : t0(wall_clock64()), id(id_), on(c->iteration == 5) {}
+    long long t0; int id; bool on; int blk;
+    __device__ KtlScope(int id_, const Ctrl *c) : t0(wall_clock64()), id(id_), on(c->iteration == 5), blk((int)blockIdx.x) {}
     __device__ ~KtlScope()
     {
-        if (on && threadIdx.x == 0 && blockIdx.x < kKtlGroups) {
-            g_ktl[2 * (id * kKtlGroups + blockIdx.x)] = t0;
-            g_ktl[2 * (id * kKtlGroups + blockIdx.x) + 1] = wall_clock64();
+        if (on && threadIdx.x == 0 && blk < kKtlGroups) {
+            g_ktl[2 * (id * kKtlGroups + blk)] = t0;
+            g_ktl[2 * (id * kKtlGroups + blk) + 1] = wall_clock64();
         }
     }
 };
@@ -815,20 +834,6 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
 }
 
 #include "tscm_eval_f32.h"
-
-// Device-side hand-offs (many producer workgroups -> the workgroup that consumes their results in the SAME launch).
-// The textbook form -- plain stores, release fence, counter; counter, acquire fence, plain loads -- makes every producer
-// issue a `buffer_wbl2` (the agent-scope release fence writes its XCD's L2 back).  Measured with tools/kernel_timeline.py:
-// with the fences the producers of k_reduce_control ended 4.9 us (143 workgroups, config 4) and 16 us (441, config 5)
-// after the kernel's first start, whatever they computed.  Here the handed-over values are written THROUGH instead
-// (agent-scope stores: `global_store ... sc1`), a producer waits for their completion (`s_waitcnt vmcnt(0)`, then the
-// workgroup barrier) and only then counts itself in; the consumer reads them with agent-scope loads (`sc1`: not from its
-// own XCD's L2).  No L2 write-back anywhere: 4.0 / 6-8 us, the iteration 130.1 -> 127.9 us (config 4), 393.8 -> 381.2
-// (config 5), same bits.  Everything else a kernel writes stays an ordinary store and reaches the next kernel through
-// the kernel boundary as before.  (Counting the arrivals in two levels, sixteen workgroups per counter, was slower:
-// contention on the single counter is not what the producers wait for.)
-__device__ __forceinline__ void handoff_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double handoff_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // per-camera raw tile (GU | GV) reduction: one block per (camera, slice of 32 of the 512 raw entries).  Eight threads per
 // entry take every eighth workgroup tile -- up to 32 loads per thread requested at once -- and are combined through LDS
@@ -1629,8 +1634,11 @@ __device__ __forceinline__ void tail_prefetch(const DevProblem &P, const DevStat
     }
 }
 // yv: solution by padded column (LDS); s_sc, s_yh, s_act: LDS arrays of n_pad entries.  Every thread of the workgroup calls it.
+// publish_epoch > 0: workgroups of this launch wait for the step (backsub_body<.., true>): yhat and the candidate camera
+// parameters are written through, and once they are complete thread 0 sets y_flag = 2 * epoch + fail
 __device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const DevState &S, int cur, int fail, const TailOperands &o,
-                                                      const double *yv, const double *s_sc, double *s_yh, const unsigned char *s_act, double *sred)
+                                                      const double *yv, const double *s_sc, double *s_yh, const unsigned char *s_act, double *sred,
+                                                      int publish_epoch = 0)
 {
     const int n = P.n_pad, i = threadIdx.x;
     const int m = i >> 4, ai = i & 15;
@@ -1638,18 +1646,23 @@ __device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const
     if (i < n) {
         const bool act = s_act[i] && !fail;
         yh = act ? s_sc[i] * yv[i] : 0.0;
-        S.yhat[i] = yh;
+        handoff_store(&S.yhat[i], yh);
         s_yh[i] = yh;
         if (ai < kFA) {
             const double x = o.x;
             const double xn = x + (-yh);
-            if (ai < 6) S.cam_rt[cur ^ 1][6 * m + ai] = xn; else S.intr[cur ^ 1][9 * m + (ai - 6)] = xn;
+            if (ai < 6) handoff_store(&S.cam_rt[cur ^ 1][6 * m + ai], xn); else handoff_store(&S.intr[cur ^ 1][9 * m + (ai - 6)], xn);
             const double d = x - xn; stepsq = d * d;
         } else if (ai < 15) {
-            S.intr[cur ^ 1][9 * m + (ai - 6)] = o.x;   // b, c are inert
+            handoff_store(&S.intr[cur ^ 1][9 * m + (ai - 6)], o.x);   // b, c are inert
         }
     }
+    if (publish_epoch > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (publish_epoch > 0 && i == 0) __hip_atomic_store(S.y_flag, 2 * publish_epoch + (fail ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the candidate's per-camera records for the next evaluation: the waiting workgroups are busy now, this one is not.
+    // (Plain loads: this workgroup wrote the parameters itself, through its own L2, and never had them in its L1.)
+    if (publish_epoch > 0 && i >= 64 && i < 64 + P.C) write_camera_record(S, cur ^ 1, i - 64);
     // model_cam = yhat^T g_c - 1/2 yhat^T H_cc yhat   (block diagonal H_cc)
     if (i < n && ai < kFA && yh != 0.0) {
         double hy = 0.0;
@@ -1771,13 +1784,28 @@ constexpr long long kHandoffTimeoutTicks = 50 * 1000 * 1000;          // 0.5 s
 // epoch: 1, 2, ... = the number of fused launches of this solve so far, this one included (the host resets the
 // counter to zero in front of every solve).  The arrival counter is MONOTONIC: a launch waits for epoch * producers,
 // so late arrivals of a launch that was given up on can never be mistaken for this launch's.
+template <int NTH, bool WAIT>
+__device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState &S, int with_floats, const int blk, const int nblk, const int epoch, const int t_need);
+
+// n_prod: workgroups 1 .. n_prod are the T reduction (FUSED); n_bs > 0: workgroups behind them are the back-substitution
+// of this step (backsub_body<256, true>): their loads are in flight and their registers full while the solver works
 template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
-__global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevProblem P, DevState S, int epoch, int withhold)
+__global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve_reduced(DevProblem P, DevState S, int epoch, int withhold, int n_prod, int n_bs, int with_floats)
 {
-    KTL(4);
     constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
     if constexpr (FUSED) {
         static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
+        if ((int)blockIdx.x > n_prod) {
+#ifdef TSCM_WAVE_TIMELINE
+            KtlScope ktl_bs(5, S.ctrl);
+            ktl_bs.blk = (int)blockIdx.x - 1 - n_prod;
+#endif
+            backsub_body<256, true>(P, S, with_floats, (int)blockIdx.x - 1 - n_prod, n_bs, epoch, epoch * n_prod);
+            return;
+        }
+    }
+    KTL(4);
+    if constexpr (FUSED) {
         if (blockIdx.x > 0) {
             constexpr int kParts = 256 / kFusedEntries;
             const int bid = ((int)blockIdx.x - 1) / kParts, part = ((int)blockIdx.x - 1) % kParts;
@@ -1851,7 +1879,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
         // everything that does not depend on T is in flight; now the tiles of the other workgroups
         __shared__ int s_late;
         if (tid == 0) {
-            const int need = epoch * ((int)gridDim.x - 1);
+            const int need = epoch * n_prod;
             const long long t_start = wall_clock64();
             int late = 0;
             while (__hip_atomic_load(S.t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
@@ -1863,6 +1891,8 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
                 // not a failed linear solve (that would merely shrink the trust region and go on): the stream's work stops here
                 S.ctrl->fault = 1; S.ctrl->term_type = 2; S.ctrl->done = 1;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // (the workgroups waiting for the camera step are let go: they see ctrl->done)
+                if (n_bs > 0) __hip_atomic_store(S.y_flag, 2 * epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_late = late;
         }
@@ -2105,7 +2135,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_reduced(DevPro
     }
     __syncthreads();
     PHASE_STAMP(ts3);
-    reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred);
+    reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred, FUSED && n_bs > 0 ? epoch : 0);
 #ifdef TSCM_PHASE_PROFILE
     if (tid == 0) printf("solve_reduced: ctrl %lld operands %lld  factor %lld (%lld shader clocks)  backsub %lld  tail %lld [10 ns]\n", ts0b - ts0, ts1 - ts0b, ts2 - ts1, cy2 - cy1, ts3 - ts2, wall_clock64() - ts3);
 #endif
@@ -2424,16 +2454,21 @@ template <int NTH> struct BsGeom {
     static_assert(kBoards + kMaxCam <= NTH, "lane roles of phase B");
 };
 
-template <int NTH>
-__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
+// WAIT: the workgroup runs inside the reduced solve's launch (k_solve_reduced<..., true>, one GPU).  Everything that does
+// not depend on the camera step -- the first round of W records, the factor records, the boards' poses -- is requested
+// at once; then thread 0 waits for the solver's flag (y_flag = 2 * epoch + lin_fail, monotonic like the T counter and
+// with the same time bound) while the solver workgroup works, alone on the chip otherwise.  What the solver wrote is
+// written through (handoff_store) and read behind an acquire fence.
+template <int NTH, bool WAIT>
+__device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState &S, int with_floats, const int blk, const int nblk, const int epoch, const int t_need)
 {
-    KTL(5);
     constexpr int kBsBoards = BsGeom<NTH>::kBoards, kBsThreads = NTH, kLoads = BsGeom<NTH>::kLoads;
     // head: control block and slot range in one round trip
-    const int b0 = blockIdx.x * kBsBoards;
+    const int b0 = blk * kBsBoards;
     const int nbl = min(kBsBoards, P.B - b0);
     const int s0 = P.bv_ptr[b0], s1 = P.bv_ptr[b0 + nbl];                // the views of these boards: slots [s0, s1)
-    const int ctrl_done = S.ctrl->done, cur = S.ctrl->cur, fail = S.ctrl->lin_fail;
+    const int ctrl_done = S.ctrl->done, cur = S.ctrl->cur;
+    int fail = WAIT ? 0 : S.ctrl->lin_fail;
     if (ctrl_done) return;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     double *s_w = dyn;                                     // [kBsRound][kRecW]   phase A
@@ -2464,12 +2499,12 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
     double facv[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) facv[j] = S.fac[(size_t)kFac * b0 + min(t + kBsThreads * j, nbl * kFac - 1)];
-    for (int i = t; i < P.n_pad; i += kBsThreads) s_yh[i] = S.yhat[i];
+    if constexpr (!WAIT) { for (int i = t; i < P.n_pad; i += kBsThreads) s_yh[i] = S.yhat[i]; }
     if (t < kBsBoards * 6) (&s_q[0][0])[t] = 0.0;
     // the candidate's per-camera records (rotation, left-Jacobian vectors, intrinsics: write_camera_record): one camera
     // per workgroup, by the first lane of the second wave while the loads requested above are in flight -- a serial
     // chain of a few hundred operations that cost workgroup 0 4.6 us when it did all cameras after its board solves
-    if (t == 64) for (int m = blockIdx.x; m < P.C; m += gridDim.x) write_camera_record(S, cur ^ 1, m);
+    if constexpr (!WAIT) { if (t == 64) for (int m = blk; m < P.C; m += nblk) write_camera_record(S, cur ^ 1, m); }
     // ---- phase A -----------------------------------------------------------------------------------------------------
     {
         const int grp = t >> 4, a = t & 15;
@@ -2482,6 +2517,30 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
 #pragma unroll
             for (int j = 0; j < kLoads; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
             camv = P.slot_cam[min(s0 + (t & 31), max(s1 - 1, 0))];
+        }
+        if constexpr (WAIT) {
+            __shared__ int s_flag;
+            if (t == 0) {
+                const long long t_start = wall_clock64();
+                int f;
+                while (((f = __hip_atomic_load(S.y_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) < epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t_start > kHandoffTimeoutTicks) { f = -1; break; }
+                }
+                if (f < 0) {             // the solver never reported: a device fault (see k_solve_reduced), not a failed step
+                    __hip_atomic_store(&S.ctrl->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S.ctrl->term_type, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_flag = f;
+            }
+            __syncthreads();
+            // (no acquire fence: it is a `buffer_inv` per wave, 2,500 of them at config 4, served one after the other
+            // by the XCDs' L2s -- 20 us.  The few values of the solver that this workgroup reads are read through.)
+            if (s_flag < 0 || __hip_atomic_load(&S.ctrl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            fail = s_flag & 1;
+            for (int i = t; i < P.n_pad; i += kBsThreads) s_yh[i] = handoff_load(&S.yhat[i]);
+            // (the candidate's per-camera records are written by the solver workgroup once it has published the step)
         }
         for (int rbase = s0; rbase < s1; rbase += kBsRound) {
             const int rend = min(s1, rbase + kBsRound);
@@ -2566,16 +2625,19 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
     } else if (t >= kBsBoards && t < kBsBoards + P.C) {
         const int m = t - kBsBoards;
         double crt[3], Rc[9], dRc[27];
-        for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[cur ^ 1][6 * m + k];
+        double crt6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) crt6[k] = WAIT ? handoff_load(&S.cam_rt[cur ^ 1][6 * m + k]) : S.cam_rt[cur ^ 1][6 * m + k];
+        for (int k = 0; k < 3; ++k) crt[k] = crt6[k];
         rotation_and_derivatives(crt, Rc, dRc);
         for (int k = 0; k < 9; ++k) s_rc[m][k] = Rc[k];
-        for (int k = 0; k < 3; ++k) s_rc[m][9 + k] = S.cam_rt[cur ^ 1][6 * m + 3 + k];
+        for (int k = 0; k < 3; ++k) s_rc[m][9 + k] = crt6[3 + k];
 
     }
     {
         double red[2] = { mb, ss }, mdummy = 0.0;
         block_reduce256<2>(red, mdummy, sm);       // (contains the barriers that publish s_new / s_rc and retire s_fac)
-        if (t == 0) { S.bs_part[2 * blockIdx.x] = red[0]; S.bs_part[2 * blockIdx.x + 1] = red[1]; }
+        if (t == 0) { S.bs_part[2 * blk] = red[0]; S.bs_part[2 * blk + 1] = red[1]; }
     }
     PHASE_STAMP(ts2);
     // ---- phase C: one lane per view of these boards, tiles of kBsTile views ------------------------------------------
@@ -2619,9 +2681,16 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
         __syncthreads();
     }
 #ifdef TSCM_PHASE_PROFILE
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200))
-        printf("backsub_prep wg %d: W.yhat %lld  board solve %lld  view constants %lld [10 ns]\n", (int)blockIdx.x, ts1 - ts0, ts2 - ts1, wall_clock64() - ts2);
+    if (threadIdx.x == 0 && (blk == 0 || blk == 200))
+        printf("backsub_prep wg %d: W.yhat %lld  board solve %lld  view constants %lld [10 ns]\n", blk, ts1 - ts0, ts2 - ts1, wall_clock64() - ts2);
 #endif
+}
+
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
+{
+    KTL(5);
+    backsub_body<NTH, false>(P, S, with_floats, (int)blockIdx.x, (int)gridDim.x, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2778,7 +2847,7 @@ __global__ __launch_bounds__(256) void k_begin_solve(DevState S, CtrlHead head, 
 {
     const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
     if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
-    if (i0 == 0) *S.t_count = 0;          // every solve starts with the arrival counter of the fused T reduction at zero
+    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
     if (!reset) return;
     for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = init_cam[i];
     for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = init_intr[i];

@@ -89,6 +89,7 @@ struct tscm_solver {
     int bs_threads = 128;               // geometry of k_backsub_prep: 128 threads / 16 boards or 256 / 32
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
     bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
+    bool fuse_backsub = true;           // this solve: k_backsub_prep rides in it too (TSCM_EXEC_SEPARATE_BACKSUB clears it)
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0;                   // this solve: TSCM_EXEC_TEST_WITHHOLD_HANDOFF
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
@@ -519,6 +520,9 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         s->lds_gram = 0;
         // groups of 16 boards while they all fit the chip at once (5 workgroups per CU), groups of 32 beyond that
         s->bs_threads = (B + 15) / 16 > 5 * std::max(1, prop.multiProcessorCount) * 3 / 2 ? 256 : 128;
+        // ... and groups of 32 (256 threads, the reduced solve's workgroup shape) wherever the back-substitution can ride
+        // in the reduced solve's launch (one GPU, <= 4 cameras: k_solve_reduced<4, 16, 64, true>)
+        if (16 * C <= 64 && n_bids > 0 && n_bids <= kSmallBids) s->bs_threads = 256;
         s->lds_bs = sizeof(double) * (size_t)(s->bs_threads == 256 ? BsGeom<256>::kLds : BsGeom<128>::kLds);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
@@ -613,6 +617,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &S.T, 256 * (size_t)n_bids))) return rc;
     if ((rc = dev_alloc(s, &S.t_count, 1))) return rc;
     HIP_TRY(hipMemset(S.t_count, 0, sizeof(int)));
+    if ((rc = dev_alloc(s, &S.y_flag, 1))) return rc;
+    HIP_TRY(hipMemset(S.y_flag, 0, sizeof(int)));
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
     S.n_bs_blocks = (B + 15) / 16;                  // (upper bound for the allocation; set to the geometry's group count below)
     S.n_st_blocks = (B + 255) / 256;
@@ -886,10 +892,19 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        if (fused_reduce(s)) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + P.n_bids * (256 / kFusedEntries)), dim3(256), s->lds_solve, s->stream, P, S, ++s->t_epoch, s->withhold);
-        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S, 0, 0);
-        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S, 0, 0);
-        else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S, 0, 0);
+        const int wf = s->f32_jacobian ? 1 : 0;
+        if (fused_reduce(s)) {
+            // one GPU, <= 4 cameras: T reduction, reduced solve and (unless TSCM_EXEC_SEPARATE_BACKSUB) the back-substitution
+            // workgroups, which wait for the camera step with their operands loaded, in ONE launch
+            const int n_prod = P.n_bids * (256 / kFusedEntries);
+            const int n_bs = s->fuse_backsub && s->bs_threads == 256 ? S.n_bs_blocks : 0;
+            hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_solve, n_bs ? s->lds_bs : (size_t)0), s->stream,
+                               P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+            if (n_bs) continue;
+        }
+        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
+        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
+        else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
         else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
         if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
         if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
@@ -978,6 +993,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     for (tscm_solver *s : run.m) {
         s->comm = effective_comm(s, opt.exec_flags);
         s->fuse_reduce = !(opt.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE);
+        s->fuse_backsub = !(opt.exec_flags & TSCM_EXEC_SEPARATE_BACKSUB);
         s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
         s->t_epoch = 0;
