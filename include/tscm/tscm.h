@@ -118,6 +118,8 @@ enum {
                                            /* rounds 1-3a) instead of three v_mfma_f64_4x4x4_4b per four rows (A/B runs)   */
     TSCM_EXEC_SEPARATE_BACKSUB = 8,        /* keep the back-substitution a launch of its own instead of workgroups that   */
                                            /* wait for the camera step inside the reduced solve's launch (one GPU)        */
+    TSCM_EXEC_SEPARATE_CONTROL = 16,       /* take the LM control step in the reductions' launch (k_reduce_control) instead  */
+                                           /* of in the head of the next Schur-complement kernel (one GPU)                    */
     TSCM_EXEC_TEST_WITHHOLD_HANDOFF = 0x100 /* TEST ONLY: one producer of the fused hand-off never reports in; the solve */
                                            /* must end with TSCM_E_HIP within the hand-off's time bound                 */
 };

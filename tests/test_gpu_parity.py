@@ -440,6 +440,28 @@ def test_backsub_inside_the_solve_launch_and_as_a_launch_of_its_own_agree_bit_fo
     assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_control_step_in_the_schur_kernels_head_and_in_the_reductions_launch_agree_bit_for_bit(hip_device, cfg):
+    """One GPU, <= 4 cameras, one Schur kernel per iteration: every workgroup of k_schur_gram takes the control step of
+    the evaluation in front of it in its head (same inputs, same bits; workgroup 0 writes), and k_control_tail takes the
+    last one of the solve.  tscm_options.exec_flags = TSCM_EXEC_SEPARATE_CONTROL keeps it in k_reduce_control's last
+    workgroup.  Same decisions, same log, same bits -- with the termination tests on (natural solve) and with 30
+    forced iterations (rejected steps included)."""
+    forced = dict(max_num_iterations=30, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
+                  min_trust_region_radius=0.0)
+    for opts in (dict(), forced):
+        p = synth.make_config(cfg)
+        a, b = p.copy().normalised(), p.copy().normalised()
+        with api.Solver(a) as s:
+            sa = s.solve(**opts)
+        with api.Solver(b) as s:
+            sb = s.solve(exec_flags=lib.EXEC_SEPARATE_CONTROL, **opts)
+        assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+        assert sa["iterations"] == sb["iterations"]
+        assert sa["final_cost"] == sb["final_cost"] and sa["lm_iterations"] == sb["lm_iterations"]
+        assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
 def test_late_handoff_is_a_hard_error(hip_device):
     """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
     counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld

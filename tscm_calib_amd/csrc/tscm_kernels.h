@@ -93,7 +93,7 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigne
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
 #ifndef TSCM_STORE_AUX
-#define TSCM_STORE_AUX 0      // cache policy of the record stores (experiment: 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#define TSCM_STORE_AUX 16     // cache policy of the record stores: sc1 (written through: 0.7 us off the Gram kernel, nothing on the consumers; nt = 2 costs the consumers more than it saves)
 #endif
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
 {
@@ -224,6 +224,8 @@ struct DevState {
     double *fac;                       // [B][kFac] e-block factors
     double *pairpart, *T;
     int *t_count;                      // arrival counter of the fused T reduction + reduced solve (k_solve_reduced<..., true>)
+    int *fac_fail;                     // set by an e-block factorisation that failed (k_schur_gram / k_schur_factor); read and cleared by the reduced
+                                       // solve (outside the control block: the control step may rewrite that block while the factorisations run)
     int *y_flag;                       // 2 * epoch + lin_fail once the camera step of that fused launch is written (backsub_body<.., true> waits for it)
     double *yhat;
     double *Abig;                      // compact reduced system + rhs row in 16x16 blocks, rigs of more than kMaxCamLds cameras only
@@ -1012,9 +1014,21 @@ __global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, 
 // What the control step reads from memory that does NOT depend on the evaluation being finalised: the LM state and the
 // target point's camera-side parameters, requested together with the first loads of the workgroup that runs the step.
 struct ControlPre { CtrlHead c; double x[2]; bool free_param[2]; };
+// what the kernel that runs the control step in its head goes on with (LDS, written by thread 0)
+struct CtlOut { int cur, done; double radius, dmin, dmax; };
 __device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre)
 {
-    pre.c = *S.ctrl;
+    // (the LM state through the scalar cache: wave-uniform, and when 500 workgroups take the step at once -- k_schur_gram's
+    // head -- 2,000 waves x 22 vector loads of the same six cache lines queue up at one L2 channel)
+    {
+        static_assert(sizeof(CtrlHead) % 8 == 0, "copied in 8-byte words");
+        typedef const unsigned long long __attribute__((address_space(4))) *cq4;
+        const cq4 src = (cq4)(const void *)S.ctrl;
+        unsigned long long w[sizeof(CtrlHead) / 8];
+#pragma unroll
+        for (unsigned q = 0; q < sizeof(CtrlHead) / 8; ++q) w[q] = src[q];
+        __builtin_memcpy(&pre.c, w, sizeof(CtrlHead));
+    }
     // (both parameter buffers and the camera flags are requested without waiting for `cur`: one round trip, not two)
     double x0[2], x1[2];
     int act[2], cst[2];
@@ -1037,7 +1051,8 @@ __device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevS
         pre.free_param[j] = in & (act[j] != 0) & !((a < 6) & (cst[j] != 0));
     }
 }
-__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy);
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy,
+                             bool writer = true, CtlOut *out = nullptr);
 
 // raw (GU | GV) tile of one camera (G: 512 doubles in LDS) -> H layout: 14x14 [F | r]^T [F | r] in a 16x16 slot
 __device__ __forceinline__ double camera_tile_entry(const double *G, int t)
@@ -1057,6 +1072,8 @@ __device__ __forceinline__ double camera_tile_entry(const double *G, int t)
 // Every load is unconditional (clamped index, value masked): a load under `if (i < n)` is a branch with its own wait,
 // and the eight + four of them in the ragged ends were twelve memory round trips in a row (5 us of the control
 // workgroup's 10, tools/kernel_timeline.py).
+// THROUGH: the board statistics were handed over inside this launch (handoff_store): read them the same way
+template <bool THROUGH>
 __device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, const DevState &S, int have_backsub, int lin_fail, double *sc, double *sm)
 {
     const int t = threadIdx.x;
@@ -1084,7 +1101,7 @@ __device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, cons
         for (int i = t; i < n; i += 4 * 256) {
             double q[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + 3 * (size_t)min(i + 256 * u, n - 1); q[u][0] = handoff_load(src); q[u][1] = handoff_load(src + 1); q[u][2] = handoff_load(src + 2); }
+            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + 3 * (size_t)min(i + 256 * u, n - 1); q[u][0] = THROUGH ? handoff_load(src) : src[0]; q[u][1] = THROUGH ? handoff_load(src + 1) : src[1]; q[u][2] = THROUGH ? handoff_load(src + 2) : src[2]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const bool in = i + 256 * u < n; g4[u] = fmax(g4[u], in ? q[u][0] : 0.0); s4[u] += in ? q[u][1] : 0.0; x4[u] += in ? q[u][2] : 0.0; }
         }
@@ -1112,13 +1129,69 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
     const int t = threadIdx.x;
     if ((int)blockIdx.x < P.C) {
         const int cam = blockIdx.x;
-        G[t] = handoff_load(&S.campart2[(size_t)512 * cam + t]);
-        G[256 + t] = handoff_load(&S.campart2[(size_t)512 * cam + 256 + t]);
+        G[t] = S.campart2[(size_t)512 * cam + t];
+        G[256 + t] = S.campart2[(size_t)512 * cam + 256 + t];
         __syncthreads();
         S.H_stage[256 * cam + t] = camera_tile_entry(G, t);
     } else {
-        reduce_scalar_partials(P, S, have_backsub, lin_fail, S.H_stage + 256 * P.C, sm);
+        reduce_scalar_partials<false>(P, S, have_backsub, lin_fail, S.H_stage + 256 * P.C, sm);
     }
+}
+
+// What is left of an evaluation once the camera-tile sums (campart2) and the scalar partials are complete: one batch of
+// loads -- the 512 finished sums per camera, the partials, the LM state, the target point's camera parameters -- H in
+// LDS, the control step on that copy.  Called by the last workgroup of k_reduce_control (writer), by k_control_tail,
+// and by EVERY workgroup of k_schur_gram in its head (one of them the writer): the step is cheap, deterministic and
+// needs no hand-off when everybody takes it.  Hl: 256 C + kScal + 8 doubles, Gall: 512 C, sm: 256 (LDS; C <= 8).
+// THROUGH: the sums were handed over inside this launch (k_reduce_control); otherwise they come through a kernel boundary
+// and plain loads let the L2s serve the 500 workgroups of k_schur_gram that all read the same 36 KB
+template <bool THROUGH>
+__device__ __forceinline__ void finish_evaluation(const DevProblem &P, const DevState &S, int init, int have_backsub, bool writer,
+                                                  double *Hl, double *Gall, double *sm, CtlOut *out)
+{
+    const int t = threadIdx.x;
+    ControlPre pre;
+    control_prefetch(P, S, init, pre);
+    double gu[kMaxCamLds], gv[kMaxCamLds];
+#pragma unroll
+    for (int m = 0; m < kMaxCamLds; ++m) {
+        const int cam = min(m, P.C - 1);
+        gu[m] = THROUGH ? handoff_load(&S.campart2[(size_t)512 * cam + t]) : S.campart2[(size_t)512 * cam + t];
+        gv[m] = THROUGH ? handoff_load(&S.campart2[(size_t)512 * cam + 256 + t]) : S.campart2[(size_t)512 * cam + 256 + t];
+    }
+    double *scl = Hl + 256 * P.C;
+    reduce_scalar_partials<THROUGH>(P, S, have_backsub, pre.c.lin_fail, scl, sm);
+    KTLX(2, true);
+    // (all cameras' raw tiles in LDS at once: one barrier, not two per camera)
+#pragma unroll
+    for (int m = 0; m < kMaxCamLds; ++m) if (m < P.C) { Gall[512 * m + t] = gu[m]; Gall[512 * m + 256 + t] = gv[m]; }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kMaxCamLds; ++m) if (m < P.C) Hl[256 * m + t] = camera_tile_entry(Gall + 512 * m, t);
+    __syncthreads();
+    KTLX(3, true);
+    // (no global store up to here: a barrier behind one waits for its acknowledgement, a microsecond.  The control
+    // step writes H -- and H_stage, for whoever reads the staged copy -- behind its own last barrier.)
+    control_step(P, S, init, pre, sm, Hl, scl, S.H_stage, writer, out);
+}
+
+// The same step for a workgroup that only needs its OUTCOME (every workgroup of k_schur_gram but the extra one that
+// writes): of H only the gradient column and the cost entry of each camera enter the step -- 15 entries per camera, two
+// loads per thread straight from the finished sums instead of 16 KB through LDS and two barriers.  Hl: 256 C + kScal + 8.
+__device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int have_backsub, double *Hl, double *sm, CtlOut *out)
+{
+    const int t = threadIdx.x;
+    ControlPre pre;
+    control_prefetch(P, S, 0, pre);
+    // thread (camera m, a): H[m][a][kFR] for a < 14 (a = kFR = 13: the cost entry)
+    const int m = min(t >> 4, P.C - 1), a = t & 15;
+    const int fa = min(a, 13), ta = f_tile(fa), tb = f_tile(kFR), mk = f_mask(fa) & f_mask(kFR);
+    const double gu = S.campart2[(size_t)512 * m + ta * 16 + tb], gv = S.campart2[(size_t)512 * m + 256 + ta * 16 + tb];
+    double *scl = Hl + 256 * P.C;
+    reduce_scalar_partials<false>(P, S, have_backsub, pre.c.lin_fail, scl, sm);
+    if (t < 16 * P.C && a < 14) Hl[256 * m + a * 16 + kFR] = ((mk & 1) ? gu : 0.0) + ((mk & 2) ? gv : 0.0);
+    __syncthreads();
+    control_step(P, S, 0, pre, sm, Hl, scl, nullptr, /*writer=*/false, out);
 }
 
 // One GPU: everything between the evaluation and the next Schur complement in ONE launch (round 3; before:
@@ -1133,6 +1206,8 @@ __global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S
     if (S.ctrl->done) return;
     __shared__ double sm[256];
     __shared__ int s_last;
+    __shared__ double Hl[256 * kMaxCamLds + kScal + 8];
+    __shared__ double Gall[512 * kMaxCamLds];
     const int t = threadIdx.x;
     const int nc = P.C * kCamSl;
     if ((int)blockIdx.x < nc) cam_reduce_block(P, S, blockIdx.x, sm);
@@ -1151,34 +1226,20 @@ __global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv: whatever else this workgroup reads from now on is current)
     __syncthreads();
     KTLX(1, true);
-    // ---- the last workgroup: one batch of loads, H in LDS and in both global places, the control step on the LDS copy
-    __shared__ double Hl[256 * kMaxCamLds + kScal + 8];
-    __shared__ double Gall[512 * kMaxCamLds];
-    ControlPre pre;
-    control_prefetch(P, S, init, pre);
-    double gu[kMaxCamLds], gv[kMaxCamLds];
-#pragma unroll
-    for (int m = 0; m < kMaxCamLds; ++m) {
-        const int cam = min(m, P.C - 1);
-        gu[m] = handoff_load(&S.campart2[(size_t)512 * cam + t]);
-        gv[m] = handoff_load(&S.campart2[(size_t)512 * cam + 256 + t]);
-    }
-    double *scl = Hl + 256 * P.C;
-    reduce_scalar_partials(P, S, have_backsub, pre.c.lin_fail, scl, sm);
-    KTLX(2, true);
-    // (all cameras' raw tiles in LDS at once: one barrier, not two per camera)
-#pragma unroll
-    for (int m = 0; m < kMaxCamLds; ++m) if (m < P.C) { Gall[512 * m + t] = gu[m]; Gall[512 * m + 256 + t] = gv[m]; }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < kMaxCamLds; ++m) if (m < P.C) Hl[256 * m + t] = camera_tile_entry(Gall + 512 * m, t);
-    __syncthreads();
-    KTLX(3, true);
-    // (no global store up to here: a barrier behind one waits for its acknowledgement, a microsecond.  The control
-    // step writes H -- and H_stage, for whoever reads the staged copy -- behind its own last barrier.)
-    control_step(P, S, init, pre, sm, Hl, scl, S.H_stage);
+    finish_evaluation<true>(P, S, init, have_backsub, /*writer=*/true, Hl, Gall, sm, nullptr);
     KTLX(8, true);
     KTLX_FLUSH();
+}
+
+// The control step of an evaluation whose reductions are complete, as a launch of its own: behind the LAST evaluation
+// of a solve when the steps in between are taken in the head of k_schur_gram (enqueue_eval / flush_pending_control).
+__global__ __launch_bounds__(256) void k_control_tail(DevProblem P, DevState S, int have_backsub)
+{
+    if (S.ctrl->done) return;
+    __shared__ double sm[256];
+    __shared__ double Hl[256 * kMaxCamLds + kScal + 8];
+    __shared__ double Gall[512 * kMaxCamLds];
+    finish_evaluation<false>(P, S, 0, have_backsub, true, Hl, Gall, sm, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1277,7 +1338,7 @@ __device__ __forceinline__ void factor_board(const DevProblem &P, const DevState
             g[i] += W[6 * kFR + i];
         }
     }
-    if (!factor_core(M, g, sb, radius, dmin, dmax, S.fac + (size_t)kFac * b, P.board_const[b] != 0)) S.ctrl->lin_fail = 1;
+    if (!factor_core(M, g, sb, radius, dmin, dmax, S.fac + (size_t)kFac * b, P.board_const[b] != 0)) *S.fac_fail = 1;
 }
 
 // stand-alone factorisation of the boards seen by more than three cameras (their Gram products go through
@@ -1359,17 +1420,19 @@ struct RawTc {
     __device__ __forceinline__ double operator[](int i) const { return r[3 * (i / 6 - kWcolTc) + (i % 6 - 3)]; }
 };
 
+// ctl = 1 (one GPU, <= 4 cameras, this the only Schur kernel of the iteration): the evaluation in front of this launch
+// has not been followed by its control step yet -- EVERY workgroup takes it here, in its head (finish_evaluation, LDS
+// borrowed from the factor records), on the same inputs and to the same bits; workgroup 0 writes the results.  No
+// launch, no hand-off and no single workgroup that the whole chip waits for: what k_reduce_control's last workgroup
+// did in 10 us with 255 CUs idle happens here while nothing else could run anyway.
 template <int NV>
-__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0)
+__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl)
 {
     KTL(3);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
-    const int4 desc = P.bc_desc[chunk0 + blockIdx.x];
-    const int ctrl_done = S.ctrl->done, cur = S.ctrl->cur;
-    const double radius = S.ctrl->radius, dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
-    if (ctrl_done) return;
-    PHASE_STAMP(ts0);
+    const bool extra = ctl && blockIdx.x == gridDim.x - 1;        // the workgroup that writes the control step's results, and nothing else
+    const int4 desc = P.bc_desc[chunk0 + (extra ? 0 : (int)blockIdx.x)];
     constexpr int NT = NV * (NV + 1) / 2;
     // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
     // 3 x 3 block t_b x t_c of W (9 NV): the t_b x t_b block is built from those in phase 0b with each view's R_c
@@ -1377,6 +1440,29 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     __shared__ double sumE[kChunkBoards][NE];
     __shared__ __attribute__((aligned(16))) double facl[kChunkBoards][kFac];
     __shared__ double tiles[4][NT][256];
+    int ctrl_done, cur;
+    double radius, dmin, dmax;
+    if (ctl) {
+        static_assert(kChunkBoards * kFac >= 256 * 4 + kScal + 8 + 512 * 4 + 256, "finish_evaluation's LDS (C <= 4) fits the factor records' space");
+        __shared__ CtlOut s_ctl;
+        double *scratch = &facl[0][0];
+        if (S.ctrl->done) return;
+        if (extra) {
+            finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + 256 * 4 + kScal + 8, scratch + 256 * 4 + kScal + 8 + 512 * 4, nullptr);
+            return;
+        }
+        control_outcome(P, S, 1, scratch, scratch + 256 * 4 + kScal + 8, &s_ctl);
+        __syncthreads();
+        // (wave-uniform by construction -- and the compiler has to know: `cur` selects the buffer descriptors)
+        ctrl_done = __builtin_amdgcn_readfirstlane(s_ctl.done); cur = __builtin_amdgcn_readfirstlane(s_ctl.cur);
+        radius = s_ctl.radius; dmin = s_ctl.dmin; dmax = s_ctl.dmax;
+        __syncthreads();
+    } else {
+        ctrl_done = S.ctrl->done; cur = S.ctrl->cur;
+        radius = S.ctrl->radius; dmin = S.ctrl->opt.min_lm_diagonal; dmax = S.ctrl->opt.max_lm_diagonal;
+    }
+    if (ctrl_done) return;
+    PHASE_STAMP(ts0);
     const int chunk = chunk0 + blockIdx.x;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1460,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
             }
             g[i] = sumE[tid][18 + i];
         }
-        if (!factor_core(M, g, sb, radius, dmin, dmax, facl[tid], board_is_const)) S.ctrl->lin_fail = 1;
+        if (!factor_core(M, g, sb, radius, dmin, dmax, facl[tid], board_is_const)) *S.fac_fail = 1;
     }
     __syncthreads();
     PHASE_STAMP(ts2);
@@ -1671,7 +1757,7 @@ __device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const
         model = yh * (o.hg - 0.5 * hy);
     }
     { double red[2] = { model, stepsq }, mdummy = 0.0; block_reduce256<2>(red, mdummy, sred); model = red[0]; stepsq = red[1]; }
-    if (i == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; }
+    if (i == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; *S.fac_fail = 0; }
 }
 
 // compact index of the reduced system -> padded column (-1 past the last free column), from kernel arguments only
@@ -1860,7 +1946,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
-    const int ctrl_fail = S.ctrl->lin_fail;
+    const int ctrl_fail = S.ctrl->lin_fail | *S.fac_fail;       // (fac_fail is cleared in the tail, by the one workgroup that solves)
     for (int i = tid; i < NPD; i += NT) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; yv[i] = 0.0; }
     if (ctrl_done) return;
     const double *H = S.H[cur];
@@ -2207,7 +2293,7 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
     double *A = S.Abig;               // packed lower triangle of 16x16 blocks (big_idx), block row NP: the rhs row + scratch
     for (int i = tid; i < n; i += kBigNT) { s_sc[i] = S.s_c[i]; s_act[i] = P.col_active[i]; yv[i] = 0.0; }
     for (int i = tid; i < N; i += kBigNT) s_map[i] = i < na ? P.act_map[i] : -1;
-    if (tid == 0) s_fail = S.ctrl->lin_fail;
+    if (tid == 0) s_fail = S.ctrl->lin_fail | *S.fac_fail;
     __syncthreads();
     // ---- build the lower triangle and the rhs row; the first panel goes straight to LDS -------------
     // wave w owns rows w, w + 16, ...; 16 rows are in flight per trip (one memory round trip per 16 x 64 entries),
@@ -2700,17 +2786,22 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
 // ---------------------------------------------------------------------------------------------
 // H: the (all-reduced) camera tiles, sc: the scalars behind them -- H_stage in global memory, or the LDS copy of the
 // workgroup that formed them (k_reduce_control: stage_copy = H_stage, which then receives a copy as well)
-__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy)
+// writer = false: the step is taken redundantly (k_schur_gram: every workgroup runs it in its head, on the same inputs,
+// to the same bits -- no hand-off, no kernel of its own); only the writer touches global memory.  out: the new state for
+// the calling workgroup.
+__device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy,
+                             bool writer, CtlOut *out)
 {
     // The LM state is read ONCE (wide loads, one memory round trip -- by control_prefetch, at the head of the kernel),
     // advanced in registers and written back once: as individual fields in global memory the ~40 dependent loads and
     // stores of this function cost about half a microsecond each on the single thread that executes it.
     Ctrl &g = *S.ctrl;
     CtrlHead c = pre.c;
+    const int t = threadIdx.x;
+    if (out && t == 0) { out->cur = c.cur; out->done = c.done; out->radius = c.radius; out->dmin = c.opt.min_lm_diagonal; out->dmax = c.opt.max_lm_diagonal; }
     if (c.done) return;
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
-    const int t = threadIdx.x;
     // camera-side norms |x - Plus(x, -g)|_inf, its 2-norm, |x|^2 and the cost, one thread per parameter
     double gmax_c = 0.0, gsq_c = 0.0, xsq_c = 0.0, cost = 0.0;
 #pragma unroll
@@ -2725,22 +2816,28 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
             gmax_c = fmax(gmax_c, fabs(d)); gsq_c += d * d; xsq_c += x * x;
         }
         if (a == 15) cost += 0.5 * H[256 * m + kFR * 16 + kFR];
-        if (init && a < 15) {
+        if (init && writer && a < 15) {
             const double hii = (a < kFA) ? H[256 * m + a * 16 + a] : 0.0;
             S.s_c[p] = o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0;
         }
-        if (init && a == 15) S.s_c[p] = 1.0;
+        if (init && writer && a == 15) S.s_c[p] = 1.0;
     }
     KTLX(4, true);
     { double red[3] = { gsq_c, xsq_c, cost }; block_reduce256<3>(red, gmax_c, sm); gsq_c = red[0]; xsq_c = red[1]; cost = red[2]; }
     KTLX(5, true);
     // publish the staged (all-reduced) camera tiles as the target system's H -- behind the last barrier of this step: a
     // barrier with global stores in flight waits for their acknowledgement
+    if (writer) {
 #pragma unroll 8
-    for (int i = t; i < 256 * P.C; i += 256) { const double h = H[i]; S.H[tgt][i] = h; if (stage_copy) stage_copy[i] = h; }
-    if (stage_copy && t < kScal + P.world) stage_copy[256 * P.C + t] = sc[t];
+        for (int i = t; i < 256 * P.C; i += 256) { const double h = H[i]; S.H[tgt][i] = h; if (stage_copy) stage_copy[i] = h; }
+        if (stage_copy && t < kScal + P.world) stage_copy[256 * P.C + t] = sc[t];
+    }
     if (t != 0) return;
-    auto commit = [&]() { c.fin_count = 0; static_cast<CtrlHead &>(g) = c; };
+    auto commit = [&]() {
+        c.fin_count = 0;
+        if (writer) static_cast<CtrlHead &>(g) = c;
+        if (out) { out->cur = c.cur; out->done = c.done; out->radius = c.radius; }
+    };
     double gmax_b = 0.0;
     for (int r = 0; r < P.world; ++r) gmax_b = fmax(gmax_b, sc[kScal + r]);
     const double gmax_t = fmax(gmax_c, gmax_b);
@@ -2819,7 +2916,7 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (it.step_is_successful) ++c.num_successful; else ++c.num_unsuccessful;
     it.radius = c.radius;
-    if (c.n_log < kMaxLog) g.log[c.n_log] = it;
+    if (writer && c.n_log < kMaxLog) g.log[c.n_log] = it;
     ++c.n_log;
     if (it.iteration >= o.max_num_iterations) { c.done = 1; c.term_type = 1; c.term_reason = kMaxIter; commit(); return; }
     if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) { c.done = 1; c.term_type = 0; c.term_reason = kGradTol; commit(); return; }
@@ -2847,7 +2944,7 @@ __global__ __launch_bounds__(256) void k_begin_solve(DevState S, CtrlHead head, 
 {
     const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
     if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
-    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
+    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
     if (!reset) return;
     for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = init_cam[i];
     for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = init_intr[i];

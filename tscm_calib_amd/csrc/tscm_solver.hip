@@ -90,6 +90,8 @@ struct tscm_solver {
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
     bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
     bool fuse_backsub = true;           // this solve: k_backsub_prep rides in it too (TSCM_EXEC_SEPARATE_BACKSUB clears it)
+    bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
+    bool eval_pending = false;          // ... and an evaluation is waiting for it
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0;                   // this solve: TSCM_EXEC_TEST_WITHHOLD_HANDOFF
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
@@ -619,6 +621,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     HIP_TRY(hipMemset(S.t_count, 0, sizeof(int)));
     if ((rc = dev_alloc(s, &S.y_flag, 1))) return rc;
     HIP_TRY(hipMemset(S.y_flag, 0, sizeof(int)));
+    if ((rc = dev_alloc(s, &S.fac_fail, 1))) return rc;
+    HIP_TRY(hipMemset(S.fac_fail, 0, sizeof(int)));
     if ((rc = dev_alloc(s, &S.yhat, (size_t)s->n_pad))) return rc;
     S.n_bs_blocks = (B + 15) / 16;                  // (upper bound for the allocation; set to the geometry's group count below)
     S.n_st_blocks = (B + 255) / 256;
@@ -858,6 +862,13 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
         // the constants of a candidate point were written by k_backsub_prep; the initial point needs them here
         if (!have_backsub) hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
         if (int rc = launch_eval(s, cand)) return rc;
+        if (fused && s->ctl_in_schur && cand && !init) {
+            // ... or the reductions alone: the next k_schur_gram takes the control step in its head (flush_pending_control
+            // behind the last evaluation of the solve)
+            hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
+            s->eval_pending = true;
+            continue;
+        }
         if (fused) {
             // one GPU: reductions, statistics and the control step in one launch
             hipLaunchKernelGGL(k_reduce_control, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init, have_backsub);
@@ -881,10 +892,12 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
+        const int ctl = s->eval_pending ? 1 : 0;          // (ctl_in_schur: exactly one of the three variants below is launched)
+        s->eval_pending = false;
         if (P.n_slow) hipLaunchKernelGGL(k_schur_factor, dim3((P.n_slow + 255) / 256), dim3(256), 0, s->stream, P, S);
-        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1]);
-        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2]);
-        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3]), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3]);
+        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + ctl), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl);
+        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + ctl), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl);
+        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + ctl), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
@@ -994,6 +1007,12 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         s->comm = effective_comm(s, opt.exec_flags);
         s->fuse_reduce = !(opt.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE);
         s->fuse_backsub = !(opt.exec_flags & TSCM_EXEC_SEPARATE_BACKSUB);
+        {
+            // one GPU, <= 4 cameras (finish_evaluation's LDS fits k_schur_gram's), exactly one Schur kernel per iteration
+            const int n_variants = (s->nv_chunks[1] ? 1 : 0) + (s->nv_chunks[2] ? 1 : 0) + (s->nv_chunks[3] ? 1 : 0);
+            s->ctl_in_schur = !s->comm && s->P.C <= 4 && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 && !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
+            s->eval_pending = false;
+        }
         s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
         s->t_epoch = 0;
@@ -1050,6 +1069,9 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
             done = s0->h_ctrl->done != 0;
         }
     }
+    // the last evaluation's control step, if the steps were taken in k_schur_gram's head
+    for (tscm_solver *s : run.m)
+        if (s->eval_pending) { hipLaunchKernelGGL(k_control_tail, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 1); s->eval_pending = false; }
     // the accepted point into buffer 0 (k_end_solve), the control block and the iteration log to the host: enqueued
     // behind the last iteration, ONE synchronisation for the whole solve
     const size_t ctrl_bytes = offsetof(Ctrl, log) + sizeof(IterLog) * (size_t)std::min(opt.max_num_iterations + 1, kMaxLog);

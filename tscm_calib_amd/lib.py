@@ -22,6 +22,7 @@ EXEC_SEPARATE_T_REDUCE = 1
 EXEC_KEEP_SINGLE_RANK_COMM = 2
 EXEC_GRAM_16X16 = 4
 EXEC_SEPARATE_BACKSUB = 8
+EXEC_SEPARATE_CONTROL = 16
 EXEC_TEST_WITHHOLD_HANDOFF = 0x100
 
 E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
