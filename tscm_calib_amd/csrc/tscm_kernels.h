@@ -93,7 +93,9 @@ __device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t r, unsigne
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
 #ifndef TSCM_STORE_AUX
-#define TSCM_STORE_AUX 16     // cache policy of the record stores: sc1 (written through: 0.7 us off the Gram kernel, nothing on the consumers; nt = 2 costs the consumers more than it saves)
+#define TSCM_STORE_AUX 0      // cache policy of the record stores.  sc1 (16: written through) takes 0.7 us off the Gram kernel and nothing off
+                              // the iteration, and WRITE_SIZE goes from 33.6 to 59.7 MB per launch (partial lines are no longer merged in the
+                              // L2); nt (2) costs the consumers more than it saves the producer: both measured, neither kept
 #endif
 __device__ __forceinline__ void buf_store_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v)
 {
