@@ -23,9 +23,16 @@ without WORLD_SIZE spawns N fresh child processes BEFORE anything touches the GP
 ncclUniqueId, the barriers and the max-over-ranks travel over a TCP side channel (tscm_calib_amd/rendezvous.py), so
 the only HIP runtime and RCCL in the process are the ones libtscm_hip.so links.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_eval_gram, timed
-with HIP events on the solver's own stream; `cpu_baseline` is the CPU oracle (a plain-C
-port of the reference's Ceres path) on the full workload, 1 thread like the reference, plus an all-cores figure.
+Before anything is timed (all of it untimed, none of it skipping work inside the timed region): the device's fp64
+ceilings are measured (three dense kernels, ~70 ms: they are part of the roofline block anyway and leave the device
+at sustained clocks), the natural solve runs, and the hot path itself is run for TSCM_BENCH_PREHEAT_MS (60 ms) -- then
+the W warmup steps of the contract, the barrier, and exactly K timed steps.  With 5 warmup steps alone the first
+timed steps ran on a device still ramping from idle (dominant kernel 62 us instead of 55-57).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel k_eval_gram4, timed with HIP events on the
+solver's own stream (the event pair rides in the kernel's dispatch: hipExtLaunchKernelGGL); `cpu_baseline` is the CPU
+oracle (a plain-C port of the reference's Ceres path) on the full workload, 1 thread like the reference, plus an
+all-cores figure.
 """
 import argparse
 import hashlib
