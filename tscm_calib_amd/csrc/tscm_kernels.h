@@ -1422,7 +1422,8 @@ struct RawTc {
     __device__ __forceinline__ double operator[](int i) const { return r[3 * (i / 6 - kWcolTc) + (i % 6 - 3)]; }
 };
 
-// ctl = 1 (one GPU, <= 4 cameras, this the only Schur kernel of the iteration): the evaluation in front of this launch
+// ctl = 1 (one GPU, <= 4 cameras) or 2 (communicator: the tiles are all-reduced in H_stage); this the only Schur kernel
+// of the iteration: the evaluation in front of this launch
 // has not been followed by its control step yet -- EVERY workgroup takes it here, in its head (finish_evaluation, LDS
 // borrowed from the factor records), on the same inputs and to the same bits; workgroup 0 writes the results.  No
 // launch, no hand-off and no single workgroup that the whole chip waits for: what k_reduce_control's last workgroup
@@ -1433,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     KTL(3);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
-    const bool extra = ctl && blockIdx.x == gridDim.x - 1;        // the workgroup that writes the control step's results, and nothing else
+    const bool extra = ctl != 0 && blockIdx.x == gridDim.x - 1;        // the workgroup that writes the control step's results, and nothing else
     const int4 desc = P.bc_desc[chunk0 + (extra ? 0 : (int)blockIdx.x)];
     constexpr int NT = NV * (NV + 1) / 2;
     // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
@@ -1449,11 +1450,19 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
         __shared__ CtlOut s_ctl;
         double *scratch = &facl[0][0];
         if (S.ctrl->done) return;
-        if (extra) {
-            finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + 256 * 4 + kScal + 8, scratch + 256 * 4 + kScal + 8 + 512 * 4, nullptr);
-            return;
+        if (ctl == 2) {
+            // communicator path: H_stage holds the all-reduced tiles and scalars -- k_control's work, by every workgroup
+            ControlPre pre;
+            control_prefetch(P, S, 0, pre);
+            control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, extra ? nullptr : &s_ctl);
+            if (extra) return;
+        } else {
+            if (extra) {
+                finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + 256 * 4 + kScal + 8, scratch + 256 * 4 + kScal + 8 + 512 * 4, nullptr);
+                return;
+            }
+            control_outcome(P, S, 1, scratch, scratch + 256 * 4 + kScal + 8, &s_ctl);
         }
-        control_outcome(P, S, 1, scratch, scratch + 256 * 4 + kScal + 8, &s_ctl);
         __syncthreads();
         // (wave-uniform by construction -- and the compiler has to know: `cur` selects the buffer descriptors)
         ctrl_done = __builtin_amdgcn_readfirstlane(s_ctl.done); cur = __builtin_amdgcn_readfirstlane(s_ctl.cur);

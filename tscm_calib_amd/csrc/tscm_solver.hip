@@ -91,7 +91,7 @@ struct tscm_solver {
     bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
     bool fuse_backsub = true;           // this solve: k_backsub_prep rides in it too (TSCM_EXEC_SEPARATE_BACKSUB clears it)
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
-    bool eval_pending = false;          // ... and an evaluation is waiting for it
+    int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator)
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0;                   // this solve: TSCM_EXEC_TEST_WITHHOLD_HANDOFF
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
@@ -866,7 +866,7 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
             // ... or the reductions alone: the next k_schur_gram takes the control step in its head (flush_pending_control
             // behind the last evaluation of the solve)
             hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
-            s->eval_pending = true;
+            s->eval_pending = 1;
             continue;
         }
         if (fused) {
@@ -879,7 +879,11 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
     }
     if (fused) return 0;
     if (int rc = exchange(run, /*t_buffer=*/false)) return rc;
-    for (tscm_solver *s : run.m) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, init);
+    for (tscm_solver *s : run.m) {
+        // behind the all-reduce: k_control -- or, for a candidate's evaluation, the head of the next k_schur_gram
+        if (sep && s->ctl_in_schur && cand && !init) s->eval_pending = 2;
+        else hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, init);
+    }
     return 0;
 }
 
@@ -892,12 +896,12 @@ static int enqueue_iteration(LmRun &run)
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
-        const int ctl = s->eval_pending ? 1 : 0;          // (ctl_in_schur: exactly one of the three variants below is launched)
-        s->eval_pending = false;
+        const int ctl = s->eval_pending;                  // (ctl_in_schur: exactly one of the three variants below is launched)
+        s->eval_pending = 0;
         if (P.n_slow) hipLaunchKernelGGL(k_schur_factor, dim3((P.n_slow + 255) / 256), dim3(256), 0, s->stream, P, S);
-        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + ctl), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl);
-        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + ctl), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl);
-        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + ctl), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl);
+        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl);
+        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl);
+        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
@@ -914,6 +918,13 @@ static int enqueue_iteration(LmRun &run)
             hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_solve, n_bs ? s->lds_bs : (size_t)0), s->stream,
                                P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
             if (n_bs) continue;
+        }
+        else if (s->solve_variant == 0 && s->fuse_backsub && s->bs_threads == 256 && S.n_bs_blocks) {
+            // T was reduced (and all-reduced) by launches of its own: no producers, but the back-substitution workgroups
+            // still ride in the solve's launch
+            hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + S.n_bs_blocks), dim3(256), std::max(s->lds_solve, s->lds_bs), s->stream,
+                               P, S, ++s->t_epoch, 0, 0, S.n_bs_blocks, wf);
+            continue;
         }
         else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
         else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
@@ -1010,8 +1021,8 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         {
             // one GPU, <= 4 cameras (finish_evaluation's LDS fits k_schur_gram's), exactly one Schur kernel per iteration
             const int n_variants = (s->nv_chunks[1] ? 1 : 0) + (s->nv_chunks[2] ? 1 : 0) + (s->nv_chunks[3] ? 1 : 0);
-            s->ctl_in_schur = !s->comm && s->P.C <= 4 && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 && !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
-            s->eval_pending = false;
+            s->ctl_in_schur = (s->comm || s->P.C <= 4) && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 && !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
+            s->eval_pending = 0;
         }
         s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
@@ -1071,7 +1082,11 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     }
     // the last evaluation's control step, if the steps were taken in k_schur_gram's head
     for (tscm_solver *s : run.m)
-        if (s->eval_pending) { hipLaunchKernelGGL(k_control_tail, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 1); s->eval_pending = false; }
+        if (s->eval_pending) {
+            if (s->eval_pending == 2) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 0);
+            else hipLaunchKernelGGL(k_control_tail, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 1);
+            s->eval_pending = 0;
+        }
     // the accepted point into buffer 0 (k_end_solve), the control block and the iteration log to the host: enqueued
     // behind the last iteration, ONE synchronisation for the whole solve
     const size_t ctrl_bytes = offsetof(Ctrl, log) + sizeof(IterLog) * (size_t)std::min(opt.max_num_iterations + 1, kMaxLog);
