@@ -1422,7 +1422,7 @@ struct RawTc {
     __device__ __forceinline__ double operator[](int i) const { return r[3 * (i / 6 - kWcolTc) + (i % 6 - 3)]; }
 };
 
-// ctl = 1 (one GPU, <= 4 cameras) or 2 (communicator: the tiles are all-reduced in H_stage); this the only Schur kernel
+// ctl = 1 (one GPU, <= 8 cameras) or 2 (communicator: the tiles are all-reduced in H_stage); this the only Schur kernel
 // of the iteration: the evaluation in front of this launch
 // has not been followed by its control step yet -- EVERY workgroup takes it here, in its head (finish_evaluation, LDS
 // borrowed from the factor records), on the same inputs and to the same bits; workgroup 0 writes the results.  No
@@ -1440,15 +1440,20 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
     // 3 x 3 block t_b x t_c of W (9 NV): the t_b x t_b block is built from those in phase 0b with each view's R_c
     constexpr int NE = 24 + 9 * NV, NJ = (NE + 15) / 16;
-    __shared__ double sumE[kChunkBoards][NE];
-    __shared__ __attribute__((aligned(16))) double facl[kChunkBoards][kFac];
-    __shared__ double tiles[4][NT][256];
+    // (one block, so that the control step in the head can borrow all of it: facl first, 16-byte aligned)
+    struct __attribute__((aligned(16))) Lds { double facl[kChunkBoards][kFac]; double sumE[kChunkBoards][NE]; double tiles[4][NT][256]; };
+    __shared__ Lds lds_blk;
+    double (&sumE)[kChunkBoards][NE] = lds_blk.sumE;
+    double (&facl)[kChunkBoards][kFac] = lds_blk.facl;
+    double (&tiles)[4][NT][256] = lds_blk.tiles;
     int ctrl_done, cur;
     double radius, dmin, dmax;
     if (ctl) {
-        static_assert(kChunkBoards * kFac >= 256 * 4 + kScal + 8 + 512 * 4 + 256, "finish_evaluation's LDS (C <= 4) fits the factor records' space");
+        constexpr int kHl = 256 * kMaxCamLds + kScal + 8, kGall = 512 * kMaxCamLds;
+        static_assert(sizeof(Lds) / sizeof(double) >= kHl + kGall + 256, "finish_evaluation's LDS (C <= 8) fits the kernel's block");
+        static_assert(kChunkBoards * kFac >= kHl + 256, "control_outcome's LDS fits the factor records' space");
         __shared__ CtlOut s_ctl;
-        double *scratch = &facl[0][0];
+        double *scratch = reinterpret_cast<double *>(&lds_blk);
         if (S.ctrl->done) return;
         if (ctl == 2) {
             // communicator path: H_stage holds the all-reduced tiles and scalars -- k_control's work, by every workgroup
@@ -1458,10 +1463,10 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
             if (extra) return;
         } else {
             if (extra) {
-                finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + 256 * 4 + kScal + 8, scratch + 256 * 4 + kScal + 8 + 512 * 4, nullptr);
+                finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + kHl, scratch + kHl + kGall, nullptr);
                 return;
             }
-            control_outcome(P, S, 1, scratch, scratch + 256 * 4 + kScal + 8, &s_ctl);
+            control_outcome(P, S, 1, scratch, scratch + kHl, &s_ctl);
         }
         __syncthreads();
         // (wave-uniform by construction -- and the compiler has to know: `cur` selects the buffer descriptors)

@@ -91,6 +91,7 @@ struct tscm_solver {
     bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
     bool fuse_backsub = true;           // this solve: k_backsub_prep rides in it too (TSCM_EXEC_SEPARATE_BACKSUB clears it)
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
+    int schur_one_round = 0;            // largest grid of k_schur_gram whose workgroups are all resident at once (2 per CU)
     int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator)
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0;                   // this solve: TSCM_EXEC_TEST_WITHHOLD_HANDOFF
@@ -418,6 +419,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         // get equal numbers of workgroups: two per CU on big problems (a multiple of the CU count), never more than
         // kChunkBoards boards each, at least 16 (four waves of one group of four).
         const int target_bchunks = 2 * std::max(1, prop.multiProcessorCount);
+        s->schur_one_round = target_bchunks;
         const int per_bchunk = std::min<int>(kChunkBoards, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
         size_t i = 0;
         while (i < order_b.size()) {
@@ -1019,9 +1021,13 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         s->fuse_reduce = !(opt.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE);
         s->fuse_backsub = !(opt.exec_flags & TSCM_EXEC_SEPARATE_BACKSUB);
         {
-            // one GPU, <= 4 cameras (finish_evaluation's LDS fits k_schur_gram's), exactly one Schur kernel per iteration
+            // one GPU with <= 8 cameras (finish_evaluation's LDS fits k_schur_gram's) or a communicator; exactly one Schur kernel per iteration
             const int n_variants = (s->nv_chunks[1] ? 1 : 0) + (s->nv_chunks[2] ? 1 : 0) + (s->nv_chunks[3] ? 1 : 0);
-            s->ctl_in_schur = (s->comm || s->P.C <= 4) && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 && !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
+            // ... whose workgroups are resident at once: the step costs every workgroup 4.5 us, and a grid of several
+            // rounds (config 5: 1256 workgroups, 2.5 rounds) pays that per round -- measured: 391 against 383 us
+            const int n_chunks = s->nv_chunks[1] + s->nv_chunks[2] + s->nv_chunks[3];
+            s->ctl_in_schur = (s->comm || s->P.C <= kMaxCamLds) && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 && n_chunks <= s->schur_one_round &&
+                              !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
             s->eval_pending = 0;
         }
         s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
