@@ -1,3 +1,4 @@
+# usage (GPU box): bash tools/round_end_bench_lines.sh -- the default and the driver-command bench lines (with CPU baseline) into gpurun_out/
 cd $GRAFT_REPO_ROOT
 o=gpurun_out
 python3 bench.py > $o/r03f_bench.json 2> $o/r03f_bench.err

@@ -1,3 +1,6 @@
+# usage (GPU box, via gpurun): bash tools/round_end_pass.sh  -- kernel stats + medians, bench lines, PMC passes, config 5, kernel / wave timelines
+# of the release build into gpurun_out/r03f_*; then, here: python tools/record_pmc.py gpurun_out/pmc_r03f_fetch gpurun_out/pmc_r03f_write 4 gpurun_out/pmc_r03f_sq{1,2,3}
+# and bash tools/round_end_bench_lines.sh on the box (bench lines that carry roofline.traffic of the recorded sources)
 cd $GRAFT_REPO_ROOT
 d=tscm_calib_amd/csrc
 o=gpurun_out
