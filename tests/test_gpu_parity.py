@@ -462,6 +462,24 @@ def test_control_step_in_the_schur_kernels_head_and_in_the_reductions_launch_agr
         assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+def test_every_fusion_switched_off_gives_the_same_bits(hip_device):
+    """exec_flags = SEPARATE_T_REDUCE | SEPARATE_BACKSUB | SEPARATE_CONTROL: the six-launch iteration of the start of
+    round 3 (k_schur_gram, k_T_reduce, k_solve_reduced, k_backsub_prep, Gram kernel, k_reduce_control) against the
+    four-launch one -- 30 forced iterations of config 3 with rejected steps, and the natural solve."""
+    forced = dict(max_num_iterations=30, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
+                  min_trust_region_radius=0.0)
+    off = lib.EXEC_SEPARATE_T_REDUCE | lib.EXEC_SEPARATE_BACKSUB | lib.EXEC_SEPARATE_CONTROL
+    for opts in (dict(), forced):
+        p = synth.make_config(3)
+        a, b = p.copy().normalised(), p.copy().normalised()
+        with api.Solver(a) as s:
+            sa = s.solve(**opts)
+        with api.Solver(b) as s:
+            sb = s.solve(exec_flags=off, **opts)
+        assert sa["iterations"] == sb["iterations"] and sa["message"] == sb["message"]
+        assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
 def test_late_handoff_is_a_hard_error(hip_device):
     """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
     counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld
