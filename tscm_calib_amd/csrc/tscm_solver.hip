@@ -1095,7 +1095,8 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         }
     // the accepted point into buffer 0 (k_end_solve), the control block and the iteration log to the host: enqueued
     // behind the last iteration, ONE synchronisation for the whole solve
-    const size_t ctrl_bytes = offsetof(Ctrl, log) + sizeof(IterLog) * (size_t)std::min(opt.max_num_iterations + 1, kMaxLog);
+    static_assert(sizeof(Ctrl) == sizeof(CtrlHead) + sizeof(IterLog) * kMaxLog, "the log follows the head without padding");
+    const size_t ctrl_bytes = sizeof(CtrlHead) + sizeof(IterLog) * (size_t)std::min(opt.max_num_iterations + 1, kMaxLog);
     for (tscm_solver *s : run.m) {
         const int nb = std::min(256, (6 * std::max(s->B, s->C) + 255) / 256 + 1);
         hipLaunchKernelGGL(k_end_solve, dim3(nb), dim3(256), 0, s->stream, s->S, s->C, s->B);
