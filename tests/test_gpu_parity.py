@@ -480,6 +480,22 @@ def test_every_fusion_switched_off_gives_the_same_bits(hip_device):
         assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+def test_repeated_solves_are_the_same_bits_every_time(hip_device):
+    """The hand-offs inside the launches (T tiles -> reduced solve, camera step -> waiting back-substitution workgroups)
+    order data by completion, not by fences: a lost ordering would show as a solve that differs from the others.  100
+    resident solves of 25 forced iterations of config 3 (rejected steps included) must give one and the same log."""
+    p = synth.make_config(3).normalised()
+    opts = dict(max_num_iterations=25, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
+                min_trust_region_radius=0.0, check_every=255)
+    with api.Solver(p) as s:
+        s.upload_params()
+        logs = set()
+        for _ in range(100):
+            r = s.solve_resident(reset=True, **opts)
+            logs.add((r["final_cost"], tuple((it["cost"], it["step_is_successful"], it["trust_region_radius"]) for it in r["iterations"])))
+    assert len(logs) == 1
+
+
 def test_late_handoff_is_a_hard_error(hip_device):
     """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
     counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld
