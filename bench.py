@@ -418,6 +418,12 @@ def main():
                     # the PMC passes are separate runs: their figure only describes THIS kernel if the sources are unchanged
                     if rec.get("kernel_src_sha") == _kernel_src_sha():
                         roof["traffic"] = rec.get("hbm_bytes_per_launch")
+                        # what the total consists of: reads (2 x FETCH_SIZE) against the algorithmic INPUT bytes above, and
+                        # the kernel's own output -- 102 doubles of Schur records per view (+ 4 KB of camera tile per workgroup)
+                        roof["traffic_read"] = rec.get("read_bytes_corrected")
+                        roof["traffic_written"] = (rec.get("hbm_bytes_per_launch") - rec.get("read_bytes_corrected")
+                                                   if rec.get("hbm_bytes_per_launch") and rec.get("read_bytes_corrected") else None)
+                        roof["alg_output_record_bytes_per_launch"] = 8.0 * 102 * full.n_views
                         roof["traffic_source"] = "profiles/pmc_eval_gram.json (same kernel sources)"
                     else:
                         roof["traffic_source"] = "none: profiles/pmc_eval_gram.json was measured on other kernel sources"
