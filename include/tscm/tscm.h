@@ -23,8 +23,10 @@
 extern "C" {
 #endif
 
-#define TSCM_ABI_VERSION 3   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
-                             /*    zero-initialised structs keep their meaning)                                  */
+#define TSCM_ABI_VERSION 4   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
+                             /*    zero-initialised structs keep their meaning); 4: unknown exec_flags bits are  */
+                             /*    refused, TSCM_EXEC_DENSE_REDUCED_ORDER, the fault injection of the tests is   */
+                             /*    an entry point of its own (tscm_solver_debug_withhold_handoff), no option     */
 
 enum {
     TSCM_OK = 0,
@@ -107,8 +109,9 @@ typedef struct tscm_options {
                                          /* not change the mathematics (TSCM_EXEC_*)   */
 } tscm_options;
 
-/* tscm_options.exec_flags.  The results are the same bits with or without the first two; they select code paths that
- * a one-GPU box would otherwise never run (the tests use them), the third one is fault injection. */
+/* tscm_options.exec_flags.  They select code paths for A/B runs and for tests that a one-GPU box would otherwise never
+ * run; none of them changes the mathematics, all but the last two give the same bits.  Bits outside TSCM_EXEC_ALL are
+ * refused with TSCM_E_INVALID (a caller built against an options struct without the field passes garbage here). */
 enum {
     TSCM_EXEC_SEPARATE_T_REDUCE = 1,       /* keep the Schur-complement tile reduction a launch of its own instead of   */
                                            /* riding in the reduced solve's launch (what every communicator run does)   */
@@ -120,8 +123,11 @@ enum {
                                            /* wait for the camera step inside the reduced solve's launch (one GPU)        */
     TSCM_EXEC_SEPARATE_CONTROL = 16,       /* take the LM control step in the reductions' launch (k_reduce_control) instead  */
                                            /* of in the head of the next Schur-complement kernel (one GPU)                    */
-    TSCM_EXEC_TEST_WITHHOLD_HANDOFF = 0x100 /* TEST ONLY: one producer of the fused hand-off never reports in; the solve */
-                                           /* must end with TSCM_E_HIP within the hand-off's time bound                 */
+    TSCM_EXEC_DENSE_REDUCED_ORDER = 32,    /* k_solve_nd (rigs of 5-8 cameras) factors the reduced camera system as ONE dense  */
+                                           /* block instead of along the camera-pair graph (same solution to rounding)       */
+    TSCM_EXEC_GRAPH_REDUCED_ORDER = 64,    /* rigs of up to 4 cameras: k_solve_nd along the camera-pair graph instead of the  */
+                                           /* dense k_solve_reduced (which is faster there: tests and A/B runs)               */
+    TSCM_EXEC_ALL = 127
 };
 
 /* ceres::IterationSummary subset */
@@ -190,6 +196,10 @@ void tscm_default_options(tscm_options *opt, int mono);
  */
 int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
 int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU, see below */
+/* TESTS ONLY: in the next solve of `s` one producer of the device-side hand-off (Schur-complement tiles -> reduced solve)
+ * never reports in; that solve must end with TSCM_E_HIP within the hand-off's time bound, the caller's parameters
+ * untouched, and the solver must solve again afterwards. */
+int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on);
 int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *summary);
 /* Same as _solve but parameters start from / are left in device memory (used by the
  * benchmark to time the minimiser loop with inputs resident in HBM). reset=1 reloads

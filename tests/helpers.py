@@ -84,6 +84,37 @@ def mixed_visibility_rig(seed=5, n_frames=24, n_cameras=4, noise_px=0.05, **boar
     return p.normalised()
 
 
+def rig_with_pairs(n_cameras, pairs, frames_per_pair=6, seed=11, noise_px=0.05) -> Problem:
+    """Rig whose camera-pair graph is exactly `pairs` (list of (a, b)): frame f is seen by the two cameras of pair
+    f % len(pairs).  Observations are exact projections of the ground truth plus noise (image bounds ignored, like
+    mixed_visibility_rig): chains, complete graphs, stars -- the shapes the reduced solver's elimination plan is built for."""
+    C = n_cameras
+    B = frames_per_pair * len(pairs)
+    base = synth.make_problem(C, max(2, (2 * B + C - 1) // C), seed, noise_px=0.0)
+    assert base.n_boards >= B
+    rng = np.random.default_rng(seed)
+    intr, cam, brd = base.meta["gt_intr"], base.meta["gt_cam_rt"], base.meta["gt_board_rt"][:B]
+    npts = base.n_points
+    P3 = np.concatenate([base.board_xy, np.zeros((npts, 1))], axis=1)
+    vc, vb, u, v = [], [], [], []
+    for b in range(B):
+        Rb = synth.rodrigues(brd[b, :3])
+        Pw = P3 @ Rb.T + brd[b, 3:]
+        for m in sorted(pairs[b % len(pairs)]):
+            Pc = Pw @ synth.rodrigues(cam[m, :3]).T + cam[m, 3:]
+            uu, vv, ks = synth.ts_project(intr[m], Pc)
+            assert np.all(ks > 1e-3), (b, m)
+            vc.append(m); vb.append(b); u.append(uu); v.append(vv)
+    V = len(vc)
+    obs_u = np.concatenate(u) + noise_px * rng.normal(size=V * npts)
+    obs_v = np.concatenate(v) + noise_px * rng.normal(size=V * npts)
+    p = Problem(C, B, base.board_xy, np.array(vc, dtype=np.int32), np.array(vb, dtype=np.int32),
+                (np.arange(V) * npts).astype(np.int32), np.full(V, npts, dtype=np.int32), obs_u, obs_v,
+                base.cam_rt.copy(), base.intr.copy(), base.board_rt[:B].copy(), base.cam_pose_constant.copy(), False,
+                meta=dict(gt_intr=intr, gt_cam_rt=cam, gt_board_rt=brd))
+    return p.normalised()
+
+
 # ----------------------------------------------------------------------------- rig initialisation
 def np_project_skew(I, P):
     """TS.cpp:332-344 in numpy (with the skew terms b, c)."""

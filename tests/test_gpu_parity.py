@@ -26,7 +26,7 @@ def _cmp_trace(gs, os_, rtol=1e-6):
 
 def test_native_library_is_loaded(hip_device):
     from tscm_calib_amd import lib
-    assert lib.lib().tscm_abi_version() == 3
+    assert lib.lib().tscm_abi_version() == 4
     assert lib.lib().tscm_device_count() >= 1
 
 
@@ -372,6 +372,45 @@ def test_reduced_solver_geometries(hip_device, C, free_gauge):
         assert max(H.param_rel_err(pg, po).values()) < 1e-6
 
 
+GRAPHS = {
+    "chain4": (4, [(0, 1), (1, 2), (2, 3)]),
+    "complete4": (4, [(a, b) for a in range(4) for b in range(a + 1, 4)]),
+    "chain8": (8, [(i, i + 1) for i in range(7)]),
+    "star6": (6, [(0, m) for m in range(1, 6)]),
+    "two_rings8": (8, [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4)]),
+    "complete8": (8, [(a, b) for a in range(8) for b in range(a + 1, 8)]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRAPHS))
+def test_reduced_solver_along_the_camera_pair_graph(hip_device, name):
+    """The reduced camera system is factored along the camera-pair graph (nested dissection, tscm_nd_plan.h; rings are
+    covered by every BASELINE config).  Chains, stars, two coupled rings and complete graphs (= one dense block) against
+    the oracle's dense Cholesky, and against the same kernel on the dense order (TSCM_EXEC_DENSE_REDUCED_ORDER): the two
+    orders agree to rounding, iteration by iteration."""
+    C, pairs = GRAPHS[name]
+    p = H.rig_with_pairs(C, pairs, frames_per_pair=8 if len(pairs) < 20 else 2, seed=50 + C)
+    opts = dict(max_num_iterations=12)
+    pg, po, gs, os_ = _solve_both(p, **opts)
+    _cmp_trace(gs, os_)
+    assert max(H.param_rel_err(pg, po).values()) < 1e-6
+    pd = p.copy().normalised()
+    with api.Solver(pd) as s:
+        ds = s.solve(exec_flags=lib.EXEC_DENSE_REDUCED_ORDER, **opts)
+    _cmp_trace(ds, gs, rtol=1e-9)
+    assert max(H.param_rel_err(pd, pg).values()) < 1e-8
+
+
+def test_unknown_exec_flags_are_refused(hip_device):
+    from tscm_calib_amd.lib import TscmError
+    p = H.small_rig(4, 4, seed=1).normalised()
+    with api.Solver(p) as s:
+        with pytest.raises(TscmError) as e:
+            s.solve(exec_flags=0x100)
+        assert e.value.code == -1
+        s.solve()
+
+
 def test_rccl_code_path_single_rank(hip_device):
     """The multi-GPU code path (RCCL all-reduce of T, grouped sum/max all-reduce of the staged camera
     tiles, separate k_control) on a one-rank communicator (tscm_options.exec_flags: TSCM_EXEC_KEEP_SINGLE_RANK_COMM):
@@ -499,7 +538,7 @@ def test_repeated_solves_are_the_same_bits_every_time(hip_device):
 def test_late_handoff_is_a_hard_error(hip_device):
     """The reduced solve waits for the Schur-complement tiles of the other workgroups of its launch behind an arrival
     counter.  A hand-off that never comes is a device fault, not a numerical event: with one producer withheld
-    (fault injection, TSCM_EXEC_TEST_WITHHOLD_HANDOFF) the call must return TSCM_E_HIP within the time bound -- not hang,
+    (fault injection, tscm_solver_debug_withhold_handoff) the call must return TSCM_E_HIP within the time bound -- not hang,
     and not go on as a rejected step -- and the same solver must work again afterwards (monotonic counter, reset per solve)."""
     import time
     from tscm_calib_amd.lib import TscmError
@@ -511,7 +550,8 @@ def test_late_handoff_is_a_hard_error(hip_device):
     with api.Solver(q) as s:
         t0 = time.time()
         with pytest.raises(TscmError) as e:
-            s.solve(exec_flags=lib.EXEC_TEST_WITHHOLD_HANDOFF)
+            s.debug_withhold_handoff()
+            s.solve()
         assert e.value.code == -3 and "hand-off" in str(e.value)            # TSCM_E_HIP
         assert time.time() - t0 < 10.0
         assert np.array_equal(q.intr, p.copy().normalised().intr)          # the caller's parameters were not touched
@@ -656,6 +696,44 @@ def test_chunks_longer_than_one_metadata_block(hip_device):
         assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-8 * b["gradient_max_norm"]
         assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(b["step_norm"], 1e-12)
     assert np.max(np.abs(pg.intr[:, :7] - po.intr[:, :7]) / np.abs(po.intr[:, :7])) < 1e-7
+
+
+def test_more_backsub_workgroups_than_the_chip_holds(hip_device):
+    """The back-substitution workgroups that ride in the reduced solve's launch WAIT for the solver workgroup: only as many
+    as are resident next to it are put there (occupancy x CUs), the others follow in a launch of their own.  4 cameras x
+    20,000 views = 40,000 boards = 1,250 groups of 32 against 768 resident workgroups: 25 forced iterations agree bit for
+    bit with the path that keeps the whole back-substitution a launch of its own."""
+    p = synth.make_problem(4, 20000, 77)
+    opts = dict(max_num_iterations=25, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0, min_trust_region_radius=0.0, check_every=25)
+    pa, pb = p.copy().normalised(), p.copy().normalised()
+    with api.Solver(pa) as s:
+        s.upload_params()
+        ra = s.solve_resident(**opts)
+        ca = s.download_params()
+        rb = s.solve_resident(exec_flags=lib.EXEC_SEPARATE_BACKSUB, **opts)
+        cb = s.download_params()
+    assert ra["lm_iterations"] == rb["lm_iterations"] == 25
+    assert [it["cost"] for it in ra["iterations"]] == [it["cost"] for it in rb["iterations"]]
+    for x, y in zip(ca, cb):
+        assert np.array_equal(x, y)
+
+
+def test_schur_grid_of_several_rounds_takes_the_control_step_once(hip_device):
+    """8 cameras x 6,000 views = 24,000 boards = 750 chunks of 32: more workgroups than k_schur_gram has resident at once
+    (2 per CU), so the later rounds read the outcome workgroup 0 publishes instead of taking the control step themselves.
+    Same bits as the path with the step in the reductions' launch, over 20 forced iterations."""
+    p = synth.make_problem(8, 6000, 78)
+    opts = dict(max_num_iterations=20, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0, min_trust_region_radius=0.0, check_every=20)
+    with api.Solver(p.copy().normalised()) as s:
+        s.upload_params()
+        ra = s.solve_resident(**opts)
+        ca = s.download_params()
+        rb = s.solve_resident(exec_flags=lib.EXEC_SEPARATE_CONTROL, **opts)
+        cb = s.download_params()
+    assert ra["lm_iterations"] == rb["lm_iterations"] == 20
+    assert [(it["cost"], it["trust_region_radius"], it["step_is_successful"]) for it in ra["iterations"]] == [(it["cost"], it["trust_region_radius"], it["step_is_successful"]) for it in rb["iterations"]]
+    for x, y in zip(ca, cb):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("cols,rows", [(7, 8), (8, 7), (9, 6), (10, 6), (8, 8), (13, 5), (5, 4), (3, 3), (5, 2), (7, 5), (4, 3), (9, 5),

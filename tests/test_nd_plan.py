@@ -1,0 +1,59 @@
+"""Host logic of the reduced camera system's solver (tscm_calib_amd/csrc/tscm_nd_plan.h): the elimination plan along the
+camera-pair graph -- levels of non-adjacent cameras, panels, steps, the structurally non-zero tiles -- and the tile
+algorithm k_solve_nd runs over it, emulated on the CPU by tests/native/nd_plan_check.cpp (same schedule, same masks, same
+double buffering between the same barriers) against a dense Cholesky solve of the same system.  No GPU."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tmp", "nd_plan_check")
+
+
+@pytest.fixture(scope="module")
+def checker():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-o", EXE, os.path.join(ROOT, "tests", "native", "nd_plan_check.cpp")])
+    return EXE
+
+
+def run(exe, C, graph, const_mask=1, inactive=0, dense=0, seed=1):
+    out = subprocess.check_output([exe, str(C), graph, str(const_mask), str(inactive), str(dense), str(seed)], text=True)
+    return json.loads(out)
+
+
+CASES = [(C, g) for C in range(1, 9) for g in ("ring", "chain", "complete", "star")] + [
+    (8, "pairs:0-1,1-2,2-3,3-0,4-5,5-6,6-7,7-4,0-4"), (8, "pairs:0-1,2-3"), (6, "pairs:0-1,1-2,2-0,3-4,4-5,5-3,0-3"), (7, "pairs:0-3,3-6,6-2,2-5,5-1,1-4")]
+
+
+@pytest.mark.parametrize("C,graph", CASES)
+def test_plan_solves_the_system(checker, C, graph):
+    for dense in (0, 1):
+        for seed in (1, 2):
+            r = run(checker, C, graph, dense=dense, seed=seed)
+            assert r["ok"], r
+            assert r["covered"] == r["free_cols"]
+            assert r["rel_err"] < 1e-12, r
+            assert r["NP"] <= 32 and r["tiles"] <= 384 and r["lds_bytes"] <= 64 * 1024, r
+
+
+def test_constant_and_inactive_cameras(checker):
+    for const_mask, inactive in ((0, 0), (0b101, 0), (1, 0b100), (0b11, 0b1000), (0xff, 0)):
+        for graph in ("ring", "chain", "complete"):
+            r = run(checker, 6, graph, const_mask=const_mask, inactive=inactive)
+            assert r["ok"] and r["rel_err"] < 1e-12, (const_mask, inactive, graph, r)
+
+
+def test_ring_schedules(checker):
+    """BASELINE configs 3-5 are rings (frame f is seen by cameras f and f + 1): 9 phases instead of 12 at
+    four cameras, 13 instead of 25 at eight, the last level being the dense block of the two cameras that are left; the
+    solver workgroup's LDS stays under a third of a CU's (three workgroups of the fused launch per CU)."""
+    r4, r8 = run(checker, 4, "ring"), run(checker, 8, "ring")
+    assert (r4["phases"], r4["levels"], r4["tpt"]) == (9, "1,3|0,2", 1)
+    assert (r8["phases"], r8["levels"], r8["tpt"]) == (13, "1,3,5,7|2,6|0,4", 2)
+    assert r8["lds_bytes"] <= 160 * 1024 // 3 - 2560 and r4["lds_bytes"] <= 32 * 1024
+    d4, d8 = run(checker, 4, "ring", dense=1), run(checker, 8, "ring", dense=1)
+    assert (d4["phases"], d8["phases"]) == (12, 25) and d4["dense"] and d8["dense"]
+    assert run(checker, 4, "complete")["dense"]                       # a complete pair graph IS the dense block

@@ -5,6 +5,7 @@
 names=$1; n=${2:-2}; shift 2
 d=$GRAFT_REPO_ROOT/tscm_calib_amd/csrc
 cp $d/libtscm_hip.so /tmp/libtscm_release.so
+trap 'cp /tmp/libtscm_release.so $d/libtscm_hip.so' EXIT      # an interrupted run must not leave an experiment build as the release library
 for r in $(seq $n); do
   for v in $names; do
     cp $d/variants/lib$v.so $d/libtscm_hip.so
@@ -13,4 +14,3 @@ import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$v round $r: %.0f it/s  %.1f us/step  eval %.2f us (%d launches timed)  frac %.3f' % (d['value'], 1e3*d['ms_per_step'], 1e3*r['avg_launch_ms'], r['launches'], r['frac']))" || tail -3 /tmp/variant_err.log
   done
 done
-cp /tmp/libtscm_release.so $d/libtscm_hip.so

@@ -53,6 +53,10 @@ class Solver:
         self._comm = comm
         _l.check(_l.lib().tscm_solver_set_comm(self._h, comm._h if comm else None))
 
+    def debug_withhold_handoff(self, on: bool = True):
+        """Tests only: one producer of the device-side hand-off of the NEXT solve never reports in (tscm_solver_debug_withhold_handoff)."""
+        _l.check(_l.lib().tscm_solver_debug_withhold_handoff(self._h, 1 if on else 0))
+
     def solve(self, **options) -> dict:
         """ceres::Solve equivalent: in/out through problem.cam_rt / intr / board_rt."""
         o = _l.default_options(self.problem.mono, **options)

@@ -26,6 +26,7 @@
 
 #include "tscm_math.h"
 #include "tscm_fastmath.h"
+#include "tscm_nd_plan.h"
 
 namespace tscm {
 
@@ -58,7 +59,7 @@ constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 do
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
 constexpr int kCamSl = 16;         // the per-camera tile reduction runs in slices of 32 of the 512 raw entries: C * kCamSl workgroups
-constexpr int kSmallBids = 10;     // camera-pair blocks of a rig of <= 4 cameras: their partial-tile ranges travel as kernel arguments
+constexpr int kSmallBids = 36;     // camera-pair blocks of a rig of <= 8 cameras (8 + 28): their partial-tile ranges travel as kernel arguments
 constexpr int kMaxCamLds = 8;      // n_pad = 16*C <= 128: reduced system solved in registers/LDS (k_solve_reduced)
 constexpr int kMaxCam = 32;        // larger rigs: k_solve_reduced_big factors the system in global memory (n_pad <= 512)
 constexpr int kMaxLog = 256;
@@ -197,21 +198,19 @@ struct DevProblem {
     const unsigned char *col_active;   // [n_pad] 1 = column is a free camera-side parameter
     const int *act_map;                // [n_pad] compact index -> padded column (first n_act entries)
     int n_act;
-    // the same map in closed form for the register/LDS solver (<= kMaxCamLds cameras): the free columns of camera q are
-    // compact [cam_pre[q], cam_pre[q + 1]) = padded cam_col0[q] + 0, 1, ...  (cam_pre[q] = n_act from q = C on).
-    // Kernel arguments: the solver computes its operand addresses without a dependent table load.
+    // the compact numbering of the free camera-side columns in closed form for k_solve_reduced (<= 4 cameras): the free columns of
+    // camera q are compact [cam_pre[q], cam_pre[q + 1]) = padded cam_col0[q] + 0, 1, ...  (cam_pre[q] = n_act from q = C on)
     int cam_pre[9], cam_col0[8];
+    unsigned long long pair_mask;      // bit mi * 8 + mj: the camera pair shares a board (its tile of T follows by a population count)
+    const int4 *solve_map;             // [kSolveMapSlots / 4][256] operand offsets of every thread of k_solve_reduced (k_solve_map)
     int cam_wg[9];                     // cam_chunk_ptr by value for rigs of <= kMaxCamLds cameras (k_reduce_control: no index load in front of the tiles)
     // frame sharding (tscm_solver_create_sharded): this rank / number of ranks; 0 / 1 on a single GPU
     int rank, world;
     // T is stored compact: one 16x16 tile per camera-pair block (mi <= mj) that ANY rank contributes to, numbered in
     // lexicographic (mi, mj) order -- the same list on every rank, so the all-reduce is over n_bids * 256 doubles
-    // and every tile is rewritten in full each iteration.  Up to 8 cameras the tile of a pair follows from a 64-bit
-    // presence mask (bit mi * 8 + mj) by a population count: kernel arguments only, no dependent table load.
-    unsigned long long pair_mask;
+    // and every tile is rewritten in full each iteration.
     const short *bid_lut;              // [C*C] tile of block (mi, mj), mi <= mj; -1 = no board is seen by both
-    int bid_part_small[kSmallBids + 1]; // bid_part_ptr by value when n_bids <= kSmallBids (no memory round trip in front of the partial tiles)
-    const int4 *solve_map;             // [kSolveMapSlots / 4][threads of k_solve_reduced] operand offsets of every thread (k_solve_map)
+    int bid_part_small[kSmallBids + 1]; // bid_part_ptr by value (rigs of <= kMaxCamLds cameras: no memory round trip in front of the partial tiles)
 };
 
 struct DevState {
@@ -234,7 +233,12 @@ struct DevState {
     double *bs_part, *st_part;
     int n_bs_blocks, n_st_blocks;
     Ctrl *ctrl;
+    CtrlHead *ctrl_snap;               // copy of the control block's head taken by k_reduce_stats: what the control step in the head of the
+                                       // NEXT launch (k_schur_gram, every workgroup) reads while that launch's writer workgroup advances `ctrl`
+    struct CtlPub *ctl_pub;            // outcome of that step, published by the writer workgroup for the workgroups of later rounds of the grid
 };
+// epoch: number of control steps taken in k_schur_gram's head in this solve so far (monotonic, zeroed by k_begin_solve)
+struct CtlPub { int epoch, cur, done, pad; double radius; };
 
 // ---------------------------------------------------------------------------------------------
 // pose constants of the evaluation target (rotations and their derivatives; the two sincos
@@ -299,6 +303,33 @@ __device__ __forceinline__ void view_point_constants(const double Rc[9], const d
 // (config 5), same bits.  Everything else a kernel writes stays an ordinary store and reaches the next kernel through
 // the kernel boundary as before.  (Counting the arrivals in two levels, sixteen workgroups per counter, was slower:
 // contention on the single counter is not what the producers wait for.)
+//
+// What the ordering rests on.  EVERY handed-over location is written with an agent-scope atomic store and read with an
+// agent-scope atomic load -- no plain access to it on either side inside the launch that hands it over -- so in the
+// language's terms there is no data race; what the relaxed orders leave open is only the ORDER between the data and the
+// flag.  That order is supplied by the machine, in the way the AMDGPU back-end itself implements a release on
+// gfx942 / gfx950 ("buffer_wbl2 sc1; s_waitcnt vmcnt(0)" in front of the flag's store): the write-back is there for PLAIN
+// stores that may still sit in the XCD's L2; an sc1 store is written through, and its vmcnt slot is returned when the write
+// has reached the level all XCDs share.  `s_waitcnt vmcnt(0)` + workgroup barrier + flag is therefore the release
+// sequence minus the part that has nothing to do here.  On the consumer side the sc1 loads do not hit in the L1 / the
+// XCD's L2, so no `buffer_inv` is needed for THESE loads (an acquire fence would issue one per wave: 20 us for the 2,500
+// waves that wait for the camera step).  This is a property of the gfx942 / gfx950 cache hierarchy, not of HIP:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the in-launch hand-offs (handoff_store / handoff_load) rely on gfx942 / gfx950 sc1 write-through semantics: re-derive them for this target"
+#endif
+// The locations handed over inside a launch -- a new read of producer-written data in a waiting workgroup MUST go
+// through handoff_load, a new write of consumer-read data through handoff_store:
+//   T[n_bids][256]                    t_reduce_block (T producers)        -> k_solve_nd, solver workgroup        flag: t_count
+//   yhat[n_pad]                       reduced_solution_tail (solver)      -> backsub_body<.., true>              flag: y_flag
+//   cam_rt[cur^1], intr[cur^1]        reduced_solution_tail (solver)      -> backsub_body<.., true> (phase B)    flag: y_flag
+//   ctrl->done / fault / term_type    solver or a waiting workgroup (late hand-off) -> waiting workgroups        (atomics both sides)
+//   campart2[C][512], st_part[..][3]  cam_reduce_block / board_stats_block -> k_reduce_control's last workgroup  flag: ctrl->fin_count
+// (the solver workgroup ALSO reads cam_rt / intr of the candidate with plain loads in write_camera_record: its own
+// written-through stores, program order within one workgroup, never cached in its L1 before).
+// A hand-off that has not come after this long is a device fault, not a numerical event: the solver workgroup sets the
+// sticky ctrl->fault together with ctrl->done (every later kernel of the stream exits at once) and the host returns
+// TSCM_E_HIP.  s_memrealtime ticks: 100 MHz whatever the shader clock does.
+constexpr long long kHandoffTimeoutTicks = 50 * 1000 * 1000;          // 0.5 s
 __device__ __forceinline__ void handoff_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double handoff_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1003,6 +1034,10 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
 __global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, int cand, int init)
 {
     KTL(1);
+    // snapshot of the LM state for the control step in the head of the next launch (k_schur_gram, DevState::ctrl_snap):
+    // taken BEFORE the early exit, so that a finished -- or faulted -- solve is seen there as well
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < sizeof(CtrlHead) / 8)
+        reinterpret_cast<unsigned long long *>(S.ctrl_snap)[threadIdx.x] = reinterpret_cast<const unsigned long long *>(S.ctrl)[threadIdx.x];
     if (S.ctrl->done) return;
     __shared__ double sm[256];
     const int nc = P.C * kCamSl;
@@ -1018,14 +1053,17 @@ __global__ __launch_bounds__(256) void k_reduce_stats(DevProblem P, DevState S, 
 struct ControlPre { CtrlHead c; double x[2]; bool free_param[2]; };
 // what the kernel that runs the control step in its head goes on with (LDS, written by thread 0)
 struct CtlOut { int cur, done; double radius, dmin, dmax; };
-__device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre)
+// `head`: where the LM state is read from -- S.ctrl where the calling workgroup is the only one that takes the step
+// (k_reduce_control's last workgroup, k_control_tail, k_control), S.ctrl_snap where every workgroup of a launch takes it
+// while one of them writes S.ctrl (k_schur_gram)
+__device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre, const CtrlHead *head)
 {
     // (the LM state through the scalar cache: wave-uniform, and when 500 workgroups take the step at once -- k_schur_gram's
     // head -- 2,000 waves x 22 vector loads of the same six cache lines queue up at one L2 channel)
     {
         static_assert(sizeof(CtrlHead) % 8 == 0, "copied in 8-byte words");
         typedef const unsigned long long __attribute__((address_space(4))) *cq4;
-        const cq4 src = (cq4)(const void *)S.ctrl;
+        const cq4 src = (cq4)(const void *)head;
         unsigned long long w[sizeof(CtrlHead) / 8];
 #pragma unroll
         for (unsigned q = 0; q < sizeof(CtrlHead) / 8; ++q) w[q] = src[q];
@@ -1149,11 +1187,11 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
 // and plain loads let the L2s serve the 500 workgroups of k_schur_gram that all read the same 36 KB
 template <bool THROUGH>
 __device__ __forceinline__ void finish_evaluation(const DevProblem &P, const DevState &S, int init, int have_backsub, bool writer,
-                                                  double *Hl, double *Gall, double *sm, CtlOut *out)
+                                                  double *Hl, double *Gall, double *sm, CtlOut *out, const CtrlHead *head)
 {
     const int t = threadIdx.x;
     ControlPre pre;
-    control_prefetch(P, S, init, pre);
+    control_prefetch(P, S, init, pre, head);
     double gu[kMaxCamLds], gv[kMaxCamLds];
 #pragma unroll
     for (int m = 0; m < kMaxCamLds; ++m) {
@@ -1180,11 +1218,11 @@ __device__ __forceinline__ void finish_evaluation(const DevProblem &P, const Dev
 // The same step for a workgroup that only needs its OUTCOME (every workgroup of k_schur_gram but the extra one that
 // writes): of H only the gradient column and the cost entry of each camera enter the step -- 15 entries per camera, two
 // loads per thread straight from the finished sums instead of 16 KB through LDS and two barriers.  Hl: 256 C + kScal + 8.
-__device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int have_backsub, double *Hl, double *sm, CtlOut *out)
+__device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int have_backsub, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
 {
     const int t = threadIdx.x;
     ControlPre pre;
-    control_prefetch(P, S, 0, pre);
+    control_prefetch(P, S, 0, pre, head);
     // thread (camera m, a): H[m][a][kFR] for a < 14 (a = kFR = 13: the cost entry)
     const int m = min(t >> 4, P.C - 1), a = t & 15;
     const int fa = min(a, 13), ta = f_tile(fa), tb = f_tile(kFR), mk = f_mask(fa) & f_mask(kFR);
@@ -1228,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv: whatever else this workgroup reads from now on is current)
     __syncthreads();
     KTLX(1, true);
-    finish_evaluation<true>(P, S, init, have_backsub, /*writer=*/true, Hl, Gall, sm, nullptr);
+    finish_evaluation<true>(P, S, init, have_backsub, /*writer=*/true, Hl, Gall, sm, nullptr, S.ctrl);
     KTLX(8, true);
     KTLX_FLUSH();
 }
@@ -1241,7 +1279,7 @@ __global__ __launch_bounds__(256) void k_control_tail(DevProblem P, DevState S, 
     __shared__ double sm[256];
     __shared__ double Hl[256 * kMaxCamLds + kScal + 8];
     __shared__ double Gall[512 * kMaxCamLds];
-    finish_evaluation<false>(P, S, 0, have_backsub, true, Hl, Gall, sm, nullptr);
+    finish_evaluation<false>(P, S, 0, have_backsub, true, Hl, Gall, sm, nullptr, S.ctrl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1428,14 +1466,20 @@ struct RawTc {
 // borrowed from the factor records), on the same inputs and to the same bits; workgroup 0 writes the results.  No
 // launch, no hand-off and no single workgroup that the whole chip waits for: what k_reduce_control's last workgroup
 // did in 10 us with 255 CUs idle happens here while nothing else could run anyway.
+// With ctl the grid has one workgroup more: workgroup 0 writes the step's results (S.ctrl, H, the iteration log), publishes
+// the outcome (S.ctl_pub, epoch = ctl_epoch) and does nothing else; workgroups 1 .. first_round - 1 -- those resident when the
+// launch starts -- take the step themselves; the workgroups of LATER rounds of the grid (config 5 on one GPU: 1256 chunks,
+// 2.5 rounds) start when a first-round workgroup has finished, long after workgroup 0, and read the published outcome:
+// the step is paid once per launch, not once per round.
 template <int NV>
-__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl)
+__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch)
 {
     KTL(3);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
-    const bool extra = ctl != 0 && blockIdx.x == gridDim.x - 1;        // the workgroup that writes the control step's results, and nothing else
-    const int4 desc = P.bc_desc[chunk0 + (extra ? 0 : (int)blockIdx.x)];
+    const bool extra = ctl != 0 && blockIdx.x == 0;        // the workgroup that writes the control step's results, and nothing else
+    const int cblk = ctl ? max((int)blockIdx.x - 1, 0) : (int)blockIdx.x;
+    const int4 desc = P.bc_desc[chunk0 + cblk];
     constexpr int NT = NV * (NV + 1) / 2;
     // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
     // 3 x 3 block t_b x t_c of W (9 NV): the t_b x t_b block is built from those in phase 0b with each view's R_c
@@ -1454,19 +1498,50 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
         static_assert(kChunkBoards * kFac >= kHl + 256, "control_outcome's LDS fits the factor records' space");
         __shared__ CtlOut s_ctl;
         double *scratch = reinterpret_cast<double *>(&lds_blk);
-        if (S.ctrl->done) return;
-        if (ctl == 2) {
+        // The LM state comes from the SNAPSHOT the reductions' launch took (k_reduce_stats): the extra workgroup of THIS
+        // launch commits the advanced state to S.ctrl while the others may not even have started -- a workgroup that read
+        // S.ctrl itself could find the step already taken and take it a second time.  Nobody writes the snapshot here.
+        const CtrlHead *head = S.ctrl_snap;
+        if (head->done) return;
+        if (!extra && (int)blockIdx.x >= first_round) {
+            // a later round of the grid: the outcome is published (or about to be)
+            if (threadIdx.x == 0) {
+                const long long t_start = wall_clock64();
+                bool late = false;
+                while (__hip_atomic_load(&S.ctl_pub->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ctl_epoch) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t_start > kHandoffTimeoutTicks) { late = true; break; }
+                }
+                s_ctl.cur = __hip_atomic_load(&S.ctl_pub->cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ctl.done = __hip_atomic_load(&S.ctl_pub->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ctl.radius = handoff_load(&S.ctl_pub->radius);
+                s_ctl.dmin = head->opt.min_lm_diagonal; s_ctl.dmax = head->opt.max_lm_diagonal;
+                if (late) {          // workgroup 0 never reported: a device fault like a late hand-off of the fused solve launch
+                    __hip_atomic_store(&S.ctrl->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S.ctrl->term_type, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_ctl.done = 1;
+                }
+            }
+        } else if (ctl == 2) {
             // communicator path: H_stage holds the all-reduced tiles and scalars -- k_control's work, by every workgroup
             ControlPre pre;
-            control_prefetch(P, S, 0, pre);
-            control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, extra ? nullptr : &s_ctl);
-            if (extra) return;
+            control_prefetch(P, S, 0, pre, head);
+            control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, &s_ctl);
         } else {
-            if (extra) {
-                finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + kHl, scratch + kHl + kGall, nullptr);
-                return;
+            if (extra) finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
+            else control_outcome(P, S, 1, scratch, scratch + kHl, &s_ctl, head);
+        }
+        if (extra) {
+            // thread 0 took the serial part of the step and committed it: the outcome, written through, then the epoch
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&S.ctl_pub->cur, s_ctl.cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&S.ctl_pub->done, s_ctl.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                handoff_store(&S.ctl_pub->radius, s_ctl.radius);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&S.ctl_pub->epoch, ctl_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            control_outcome(P, S, 1, scratch, scratch + kHl, &s_ctl);
+            return;
         }
         __syncthreads();
         // (wave-uniform by construction -- and the compiler has to know: `cur` selects the buffer descriptors)
@@ -1479,7 +1554,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     }
     if (ctrl_done) return;
     PHASE_STAMP(ts0);
-    const int chunk = chunk0 + blockIdx.x;
+    const int chunk = chunk0 + cblk;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int a = lane & 15, kq = lane >> 4;
@@ -1607,7 +1682,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     for (int t = 0; t < NT; ++t)
         S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] = (tiles[0][t][tid] + tiles[1][t][tid]) + (tiles[2][t][tid] + tiles[3][t][tid]);
 #ifdef TSCM_PHASE_PROFILE
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200))
+    if (threadIdx.x == 0 && (cblk == 0 || cblk == 200))
         printf("schur_gram wg %d: boards %d  E sums %lld  factor %lld  gram %lld  tiles %lld [10 ns]\n", (int)blockIdx.x, nbd, ts1 - ts0, ts2 - ts1, ts3 - ts2, wall_clock64() - ts3);
 #endif
 }
@@ -1695,15 +1770,6 @@ __global__ __launch_bounds__(kTEntries * kTSlices) void k_T_reduce(DevProblem P,
 }
 
 // T(i, j) for padded columns i, j of the camera side; the lower blocks are the transposed upper ones
-__device__ __forceinline__ double load_T_small(const DevProblem &P, const double *T, int i, int j)
-{
-    int lo = i >> 4, hi = j >> 4, a = i & 15, b = j & 15;
-    if (lo > hi) { const int t = lo; lo = hi; hi = t; const int u = a; a = b; b = u; }
-    const int bit = lo * 8 + hi;
-    const unsigned long long m = P.pair_mask;
-    const int tile = __popcll(m & ((1ull << bit) - 1ull));
-    return ((m >> bit) & 1ull) ? T[256 * tile + a * 16 + b] : 0.0;
-}
 __device__ __forceinline__ double load_T_lut(const DevProblem &P, const double *T, int i, int j)
 {
     int lo = i >> 4, hi = j >> 4, a = i & 15, b = j & 15;
@@ -1776,472 +1842,18 @@ __device__ __forceinline__ void reduced_solution_tail(const DevProblem &P, const
     if (i == 0) { S.ctrl->model_cam = model; S.ctrl->stepsq_cam = stepsq; S.ctrl->lin_fail = fail; *S.fac_fail = 0; }
 }
 
-// compact index of the reduced system -> padded column (-1 past the last free column), from kernel arguments only
-__device__ __forceinline__ int compact_to_padded(const DevProblem &P, int ci)
-{
-    int base = 0, c0 = P.cam_col0[0];
-#pragma unroll
-    for (int q = 1; q < kMaxCamLds; ++q) { const bool ge = ci >= P.cam_pre[q]; base = ge ? P.cam_pre[q] : base; c0 = ge ? P.cam_col0[q] : c0; }
-    return ci < P.n_act ? c0 + (ci - base) : -1;
-}
-// Tile of thread tid in k_solve_reduced's G x G grid (NP panels of free columns).  Lower tile (ti, tj) of the matrix on
-// thread ti * G + tj.  The right-hand side tiles (NP, p), p < NP, go to threads that own no matrix tile, counted
-// downwards from the end of the last wave that holds matrix tiles: tile p is needed up to panel step p, so the
-// longest-lived ones share a wave with the longest-lived matrix rows and the early waves retire early.  The
-// look-ahead thread (the last thread of the workgroup) is never used.
-struct SolveTile { bool mine, rhsrow; int ri, cj; };
-template <int TS, int G>
-__device__ __forceinline__ SolveTile solve_tile(int tid, int NP)
-{
-    constexpr int NT = (G * G + 63) / 64 * 64;
-    auto owns = [&](int t) { const int ti = t / G, tj = t % G; return tj <= ti && ti < NP; };
-    SolveTile t;
-    t.mine = owns(tid); t.rhsrow = false;
-    t.ri = tid / G; t.cj = tid % G;
-    if (t.mine || tid == NT - 1) return t;
-    const int last = min(NT - 2, ((NP - 1) * G + NP - 1) | 63);        // end of the wave of tile (NP-1, NP-1)
-    if (tid > last) return t;
-    int rank = 0;                                                       // free threads in (tid, last]
-    for (int u = tid + 1; u <= last; ++u) rank += owns(u) ? 0 : 1;
-    if (rank < NP) { t.rhsrow = true; t.ri = NP; t.cj = NP - 1 - rank; }
-    return t;
-}
-// slots of the per-thread operand map (ints): offsets into H[cur] and T per tile element (-1: the element is 0),
-// s_c indices of the tile's rows and columns (-1: padding / rhs row, where 1 is used through kMapOne)
-constexpr int kMapH = 0, kMapT = 16, kMapSci = 32, kMapScj = 36, kMapTile = 40, kSolveMapSlots = 44;   // kMapTile: row, column, 1 = matrix tile / 2 = rhs tile
-constexpr int kMapOne = 1 << 30;       // "scaling 1": the row of a right-hand side tile
-
-// Operand map of k_solve_reduced<TS, G> (run once per solver: the map depends on the camera/pair structure only).
-// grid 1 x NT
-template <int TS, int G>
-__global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem P, int4 *map)
-{
-    static_assert(TS == 4, "the map holds 4 x 4 tiles");
-    constexpr int NT = (G * G + 63) / 64 * 64;
-    const int tid = threadIdx.x;
-    const int NP = (P.n_act + TS - 1) / TS;
-    const SolveTile tl = solve_tile<TS, G>(tid, NP);
-    auto cmap = [&](int ci) -> int { return compact_to_padded(P, ci); };
-    auto t_offset = [&](int i, int j) -> int {                  // as load_T_small
-        int lo = i >> 4, hi = j >> 4, a = i & 15, b = j & 15;
-        if (lo > hi) { const int t = lo; lo = hi; hi = t; const int u = a; a = b; b = u; }
-        const int bit = lo * 8 + hi;
-        const unsigned long long m = P.pair_mask;
-        return ((m >> bit) & 1ull) ? 256 * __popcll(m & ((1ull << bit) - 1ull)) + a * 16 + b : -1;
-    };
-    int off[kSolveMapSlots];
-    for (int q = 0; q < kSolveMapSlots; ++q) off[q] = -1;
-    off[kMapTile] = tl.ri; off[kMapTile + 1] = tl.cj; off[kMapTile + 2] = tl.mine ? 1 : tl.rhsrow ? 2 : 0;
-    if (tl.mine || tl.rhsrow) {
-        int mi[TS], mj[TS];
-        for (int r = 0; r < TS; ++r) { mi[r] = tl.mine ? cmap(tl.ri * TS + r) : -1; mj[r] = cmap(tl.cj * TS + r); }
-        for (int r = 0; r < TS; ++r) { off[kMapSci + r] = mi[r]; off[kMapScj + r] = mj[r]; }
-        if (tl.mine) {
-            for (int r = 0; r < TS; ++r)
-                for (int c = 0; c < TS; ++c) {
-                    const int i = mi[r], j = mj[c];
-                    if (i < 0 || j < 0) continue;
-                    if ((i >> 4) == (j >> 4)) off[kMapH + r * TS + c] = 256 * (i >> 4) + (i & 15) * 16 + (j & 15);
-                    off[kMapT + r * TS + c] = t_offset(i, j);
-                }
-        } else {
-            // right-hand side tile: row 0 = g - t_r of the panel's columns (the fused column kFR of H and T)
-            for (int c = 0; c < TS; ++c) {
-                const int j = mj[c];
-                if (j < 0) continue;
-                const int m = j >> 4, b = j & 15;
-                off[kMapH + c] = 256 * m + b * 16 + kFR;
-                off[kMapT + c] = t_offset(j, m * 16 + kFR);
-            }
-            off[kMapSci] = kMapOne;
-        }
-    }
-    for (int q = 0; q < kSolveMapSlots / 4; ++q) map[q * NT + tid] = make_int4(off[4 * q], off[4 * q + 1], off[4 * q + 2], off[4 * q + 3]);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Reduced camera system (DenseSchurComplementSolver): one 256-thread workgroup.
-//   A = S_c (H_cc - T) S_c + D_c^2, rhs = S_c (g_c - t_r); inactive columns (tile padding,
-//   constant camera pose, cameras without views) become identity rows.
-// Blocked right-looking Cholesky with the matrix held in REGISTERS: thread (ti, tj) owns the
-// TS x TS tile (TS = N/16).  Per panel: the diagonal thread factors and inverts its tile and forward-
-// substitutes its slice of the rhs while the column threads publish their raw tiles; after ONE
-// barrier every trailing thread forms the needed X = A L_kk^{-T} tiles itself and applies the rank-TS
-// update -- 16 barriers in total.
-// Back-substitution: one wave, w in registers, rows of L streamed from LDS.  Writes
-// yhat = S_c y (camera step = -yhat) and the candidate camera parameters.
-// grid 1 x 256, dynamic LDS N*(N+2) + 2*G*(TS*TS+2) + 2*N + 3*NPD doubles.
+// Reduced camera system (DenseSchurComplementSolver), up to kMaxCamLds cameras: k_solve_nd (tscm_solve_nd.h).
 // ---------------------------------------------------------------------------------------------
-// G x G threads, thread (ti, tj) owns the TS x TS tile (ti, tj) of the COMPACT system (N = G * TS >= n_act columns);
-// NPD >= n_pad is the capacity of the arrays indexed by padded column
-// FUSED (256-thread variant, one GPU): the launch carries the T reduction as workgroups 1 .. n_bids * 256 / kFusedEntries;
-// workgroup 0 is the solver and waits for their tiles behind an arrival counter (release -> counter -> acquire) after it
-// has requested everything else.  Unlike the producers of the earlier hand-off experiments these have written 20 KB, not
-// megabytes, when they release -- and a launch with its 5 us is gone.
-constexpr int kFusedEntries = 256 / kTSlices;        // 16 entries x 16 slices = the solver's 256 threads
-// A hand-off that has not come after this long is a device fault, not a numerical event: the solver workgroup sets the
-// sticky ctrl->fault together with ctrl->done (every later kernel of the stream exits at once) and the host returns
-// TSCM_E_HIP.  s_memrealtime ticks: 100 MHz whatever the shader clock does.
-constexpr long long kHandoffTimeoutTicks = 50 * 1000 * 1000;          // 0.5 s
+constexpr int kFusedEntries = 256 / kTSlices;        // fused T reduction: 16 entries x 16 slices = the solver's 256 threads
 // epoch: 1, 2, ... = the number of fused launches of this solve so far, this one included (the host resets the
 // counter to zero in front of every solve).  The arrival counter is MONOTONIC: a launch waits for epoch * producers,
 // so late arrivals of a launch that was given up on can never be mistaken for this launch's.
 template <int NTH, bool WAIT>
 __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState &S, int with_floats, const int blk, const int nblk, const int epoch, const int t_need);
 
-// n_prod: workgroups 1 .. n_prod are the T reduction (FUSED); n_bs > 0: workgroups behind them are the back-substitution
-// of this step (backsub_body<256, true>): their loads are in flight and their registers full while the solver works
-template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
-__global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve_reduced(DevProblem P, DevState S, int epoch, int withhold, int n_prod, int n_bs, int with_floats)
-{
-    constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
-    if constexpr (FUSED) {
-        static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
-        if ((int)blockIdx.x > n_prod) {
-#ifdef TSCM_WAVE_TIMELINE
-            KtlScope ktl_bs(5, S.ctrl);
-            ktl_bs.blk = (int)blockIdx.x - 1 - n_prod;
-#endif
-            backsub_body<256, true>(P, S, with_floats, (int)blockIdx.x - 1 - n_prod, n_bs, epoch, epoch * n_prod);
-            return;
-        }
-    }
-    KTL(4);
-    if constexpr (FUSED) {
-        if (blockIdx.x > 0) {
-            constexpr int kParts = 256 / kFusedEntries;
-            const int bid = ((int)blockIdx.x - 1) / kParts, part = ((int)blockIdx.x - 1) % kParts;
-            const int cb = P.bid_part_small[bid], ce = P.bid_part_small[bid + 1];      // kernel arguments: the partial tiles are the first thing requested
-            if (S.ctrl->done) return;
-            __shared__ double red[kTSlices][kFusedEntries];
-            t_reduce_block<kFusedEntries>(S, bid, part, cb, ce, red);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0 && !(withhold && blockIdx.x == 1))        // (withhold: fault injection, TSCM_EXEC_TEST_WITHHOLD_HANDOFF)
-                __hip_atomic_fetch_add(S.t_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (no release fence: handoff_store)
-            return;
-        }
-    }
-    // control block and the static column tables are requested together (one memory round trip); the early
-    // exit is taken once they are there
-    PHASE_STAMP(ts0);
-    const int ctrl_done = S.ctrl->done;
-    constexpr int N = G * TS;
-    constexpr int LD = N + 2;                       // even: the rows of a diagonal tile are read as 16-byte pairs
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Lm = lds;                 // [N][LD] lower factor: the diagonal tiles as they are factored, the rest at the end
-    constexpr int XT = TS * TS + 2;   // tile stride of the panel column: 16 lanes tj read 16 tiles at once -- a stride of 16 doubles would put them on two bank pairs
-    double *Xb = Lm + N * LD;         // [2][G][XT] raw panel column, one TS x TS tile per row block (double-buffered)
-    double *wp = Xb + 2 * G * XT;     // [N] forward-substituted rhs  w = L^{-1} b
-    double *idg = wp + N;             // [N] 1 / L_kk
-    double *yv = idg + N;             // [NPD] solution by padded column
-    double *s_sc = yv + NPD;          // [NPD]
-    double *s_yh = s_sc + NPD;        // [NPD]
-    __shared__ int s_fail;
-    __shared__ unsigned char s_act[NPD];
-    __shared__ double sred[256];
-    const int n = P.n_pad;            // <= N
-    const int tid = threadIdx.x;
-    const int NP = (P.n_act + TS - 1) / TS;       // panels that hold free columns
-    // ---- operands of my tile (lower tiles only) -------------------------------------------------------
-    // The right-hand side rides along as tile row NP: row 0 of tile (NP, p) is the rhs slice of panel p (rows
-    // 1..TS-1 are zero), so the forward substitution w = L^{-1} b falls out of the panel solves and trailing
-    // updates and no thread treats it specially.  Those tiles live on idle threads of the last wave that holds
-    // matrix tiles (k_solve_map): the fewer waves take part in a panel step, the less they queue at the LDS.
-    // Where a thread's operands sit in H, T and s_c depends on the problem's structure only: k_solve_map wrote
-    // the offsets once, so the head of this kernel is two memory round trips (offsets + control block, then the
-    // operands) and next to no index arithmetic.
-    int off[kSolveMapSlots];
-#pragma unroll
-    for (int q = 0; q < kSolveMapSlots / 4; ++q) {
-        const int4 v = P.solve_map[q * NT + tid];
-        off[4 * q] = v.x; off[4 * q + 1] = v.y; off[4 * q + 2] = v.z; off[4 * q + 3] = v.w;
-    }
-    const int ri = off[kMapTile], cj = off[kMapTile + 1];                // tile (row, column) of this thread
-    const bool mine = off[kMapTile + 2] == 1, rhsrow = off[kMapTile + 2] == 2;
-    const int cur = S.ctrl->cur;
-    const double radius = S.ctrl->radius;
-    const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
-    const int ctrl_fail = S.ctrl->lin_fail | *S.fac_fail;       // (fac_fail is cleared in the tail, by the one workgroup that solves)
-    for (int i = tid; i < NPD; i += NT) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; yv[i] = 0.0; }
-    if (ctrl_done) return;
-    const double *H = S.H[cur];
-    double sci[TS], scj[TS], hh[TS][TS], tt[TS][TS];
-#pragma unroll
-    for (int r = 0; r < TS; ++r) {
-        const int oi = off[kMapSci + r], oj = off[kMapScj + r];
-        sci[r] = oi == kMapOne ? 1.0 : oi >= 0 ? S.s_c[oi] : 0.0;
-        scj[r] = oj >= 0 ? S.s_c[oj] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < TS; ++r)
-#pragma unroll
-        for (int c = 0; c < TS; ++c) { const int oh = off[kMapH + r * TS + c]; hh[r][c] = oh >= 0 ? H[oh] : 0.0; }
-    if constexpr (FUSED) {
-        // everything that does not depend on T is in flight; now the tiles of the other workgroups
-        __shared__ int s_late;
-        if (tid == 0) {
-            const int need = epoch * n_prod;
-            const long long t_start = wall_clock64();
-            int late = 0;
-            while (__hip_atomic_load(S.t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t_start > kHandoffTimeoutTicks) { late = 1; break; }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (late) {
-                // not a failed linear solve (that would merely shrink the trust region and go on): the stream's work stops here
-                S.ctrl->fault = 1; S.ctrl->term_type = 2; S.ctrl->done = 1;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                // (the workgroups waiting for the camera step are let go: they see ctrl->done)
-                if (n_bs > 0) __hip_atomic_store(S.y_flag, 2 * epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_late = late;
-        }
-        __syncthreads();
-        if (s_late) return;
-    }
-#pragma unroll
-    for (int r = 0; r < TS; ++r)
-#pragma unroll
-        for (int c = 0; c < TS; ++c) { const int ot = off[kMapT + r * TS + c]; tt[r][c] = ot >= 0 ? (FUSED ? handoff_load(&S.T[ot]) : S.T[ot]) : 0.0; }
-    PHASE_STAMP(ts0b);
-    if (tid == 0) s_fail = ctrl_fail;
-    double a[TS][TS];
-    const double inv_radius = 1.0 / radius;
-#pragma unroll
-    for (int r = 0; r < TS; ++r) {
-#pragma unroll
-        for (int c = 0; c < TS; ++c) {
-            // matrix tiles: S_c (H - T) S_c, damped diagonal; identity on the padding columns.  rhs tiles: row 0 of
-            // the map holds (g, t_r) of the panel's columns, s_c of the ROW is stored as 1 there.
-            const bool dg = mine && ri == cj && r == c;
-            double v = sci[r] * scj[c] * (hh[r][c] - tt[r][c]);
-            if (dg) v = (off[kMapSci + r] >= 0 && off[kMapSci + r] != kMapOne) ? v + fmin(fmax(sci[r] * sci[r] * hh[r][c], dmin), dmax) * inv_radius : 1.0;
-            a[r][c] = v;
-        }
-    }
-    PHASE_STAMP(ts1);
-#ifdef TSCM_PHASE_PROFILE
-    const long long cy1 = clock64();
-#endif
-    // ---- factorisation: one barrier per panel, diagonal tiles factored one panel ahead ---------------------
-    // State at the top of step tk: L_kk (factor of diagonal tile tk) and 1 / diag are in Lm / idg; the tiles of
-    // column tk (rows below the diagonal, the rhs row among them), updated through panel tk-1, are in Ar; the
-    // diagonal tile tk+1, updated through panel tk-1, is in dt.
-    //   * trailing threads (ti > tk, tk <= tj <= ti): X_i = A_i L_kk^{-T} and X_j by forward substitution from the
-    //     raw tiles (every thread forms the two it needs itself: no second barrier), then A_ij -= X_i X_j^T; the
-    //     threads of column tk keep X_i -- their tile of L.  Column tk+1 and diagonal tile tk+2 are published for
-    //     the next step.
-    //   * one thread of the otherwise idle last wave applies panel tk's update to diagonal tile tk+1 alone and
-    //     factors it WHILE the others run the trailing update: the per-panel critical path is
-    //     max(factor, update) instead of their sum.
-    auto publish_tile = [&](double *dst, const double (&t)[TS][TS]) {
-#pragma unroll
-        for (int r = 0; r < TS; ++r)
-#pragma unroll
-            for (int c = 0; c < TS; ++c) dst[r * TS + c] = t[r][c];
-    };
-    // Cholesky of the TS x TS tile t (lower part, in place); factor -> Lm, inverse diagonal -> idg
-    auto factor_diag = [&](double (&t)[TS][TS], int tk) {
-        double il[TS];
-#pragma unroll
-        for (int c = 0; c < TS; ++c) {
-            double d = t[c][c];
-#pragma unroll
-            for (int q = 0; q < c; ++q) d -= t[c][q] * t[c][q];
-            if (!(d > 0.0)) { s_fail = 1; d = 1.0; }
-            const double isd = fast_rsqrt(d);
-            t[c][c] = d * isd; il[c] = isd;
-#pragma unroll
-            for (int r = c + 1; r < TS; ++r) {
-                double v = t[r][c];
-#pragma unroll
-                for (int q = 0; q < c; ++q) v -= t[r][q] * t[c][q];
-                t[r][c] = v * isd;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < TS; ++r) {
-            idg[tk * TS + r] = il[r];
-#pragma unroll
-            for (int c = 0; c < TS; ++c) Lm[(tk * TS + r) * LD + tk * TS + c] = c <= r ? t[r][c] : 0.0;
-        }
-    };
-    struct PanelFactor { double l[TS][TS], il[TS]; };
-    auto load_factor = [&](PanelFactor &f, int tk) {
-#pragma unroll
-        for (int r = 0; r < TS; ++r) {
-            f.il[r] = idg[tk * TS + r];
-#pragma unroll
-            for (int c = 0; c < TS; ++c) f.l[r][c] = Lm[(tk * TS + r) * LD + tk * TS + c];
-        }
-    };
-    // X = A L^{-T}:  x[r][c] = (A[r][c] - sum_{q < c} x[r][q] L[c][q]) / L[c][c]
-    auto load_tile = [&](const double *src, double (&t)[TS][TS]) {
-#pragma unroll
-        for (int r = 0; r < TS; ++r)
-#pragma unroll
-            for (int c = 0; c < TS; ++c) t[r][c] = src[r * TS + c];
-    };
-    auto panel_solve = [&](const double (&At)[TS][TS], const PanelFactor &f, double (&x)[TS][TS]) {
-#pragma unroll
-        for (int r = 0; r < TS; ++r)
-#pragma unroll
-            for (int c = 0; c < TS; ++c) {
-                double v = At[r][c];
-#pragma unroll
-                for (int q = 0; q < c; ++q) v -= x[r][q] * f.l[c][q];
-                x[r][c] = v * f.il[c];
-            }
-    };
-    __shared__ __attribute__((aligned(16))) double s_dt[2][TS * TS];
-    const bool dthread = tid == NT - 1;                     // no tile of its own: NP < G (host-checked)
-    if (cj == 0 && ri > 0 && (mine || rhsrow)) publish_tile(Xb + ri * XT, a);
-    if (ri == 1 && cj == 1 && mine) publish_tile(s_dt[0], a);
-    if (tid == 0) factor_diag(a, 0);
-    __syncthreads();
-    for (int tk = 0; tk < NP; ++tk) {
-        const double *Ar = Xb + (tk & 1) * (G * XT);
-        double *ArN = Xb + ((tk + 1) & 1) * (G * XT);
-#ifdef TSCM_PHASE_PROFILE
-        __shared__ long long s_ph[8];
-        if (tk == 3 && (dthread || tid == 11 * G + 5)) s_ph[dthread ? 0 : 4] = wall_clock64();
-#endif
-        if (dthread && tk + 1 < NP) {
-            // (all LDS operands requested before the first use: one exposed latency instead of one per group)
-            PanelFactor f;
-            double araw[TS][TS], dt[TS][TS], x[TS][TS], t[TS][TS];
-            load_factor(f, tk);
-            load_tile(Ar + (tk + 1) * XT, araw);
-            load_tile(s_dt[tk & 1], dt);
-            __builtin_amdgcn_sched_barrier(0);
-            panel_solve(araw, f, x);
-#pragma unroll
-            for (int r = 0; r < TS; ++r)
-#pragma unroll
-                for (int c = 0; c <= r; ++c) {
-                    double v = dt[r][c];
-#pragma unroll
-                    for (int q = 0; q < TS; ++q) v -= x[r][q] * x[c][q];
-                    t[r][c] = v;
-                }
-#ifdef TSCM_PHASE_PROFILE
-            if (tk == 3) { asm volatile("" : "+v"(t[3][3])); s_ph[1] = wall_clock64(); }
-#endif
-            factor_diag(t, tk + 1);
-#ifdef TSCM_PHASE_PROFILE
-            if (tk == 3) s_ph[2] = wall_clock64();
-#endif
-        }
-        if ((mine || rhsrow) && ri > tk && cj >= tk && !(ri == cj && ri == tk + 1)) {
-            PanelFactor f;
-            double ai[TS][TS], aj[TS][TS], xi[TS][TS];
-            load_factor(f, tk);
-            load_tile(Ar + ri * XT, ai);
-            load_tile(Ar + cj * XT, aj);
-            __builtin_amdgcn_sched_barrier(0);
-            panel_solve(ai, f, xi);
-            if (cj == tk) {
-                // my tile IS the panel column: keep the final factor entries (rhs row: w of this panel)
-#pragma unroll
-                for (int r = 0; r < TS; ++r)
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) a[r][c] = xi[r][c];
-                if (rhsrow) {
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) wp[tk * TS + c] = xi[0][c];
-                }
-            } else {
-                double xj[TS][TS];
-                panel_solve(aj, f, xj);                    // (diagonal tiles: the same operations as xi -- no divergent copy)
-#pragma unroll
-                for (int r = 0; r < TS; ++r)
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) {
-                        double v = a[r][c];
-#pragma unroll
-                        for (int q = 0; q < TS; ++q) v -= xi[r][q] * xj[c][q];
-                        a[r][c] = v;
-                    }
-            }
-        }
-        {
-            // column tk+1 for the next step and diagonal tile tk+2 for the look-ahead thread: ONE store sequence
-            const bool col = cj == tk + 1 && ri > tk + 1 && (mine || rhsrow), dg = ri == tk + 2 && cj == tk + 2 && mine;
-            if (col || dg) publish_tile(col ? ArN + ri * XT : s_dt[(tk + 1) & 1], a);
-        }
-#ifdef TSCM_PHASE_PROFILE
-        if (tk == 3 && tid == 11 * G + 5) { asm volatile("" : "+v"(a[3][3])); s_ph[5] = wall_clock64(); }
-        if (tk + 1 < NP) __syncthreads();
-        if (tk == 3 && tid == 0) { s_ph[6] = wall_clock64(); printf("  panel 3: D x,t %lld  factor %lld | update %lld | to barrier exit %lld\n", s_ph[1] - s_ph[0], s_ph[2] - s_ph[1], s_ph[5] - s_ph[4], s_ph[6] - s_ph[0]); }
-#else
-        if (tk + 1 < NP) __syncthreads();
-#endif
-    }
-    // ---- publish L (the diagonal tiles are there already), back-substitute L^T y = w with one wave -----------
-    if (cj < ri && mine) {
-#pragma unroll
-        for (int r = 0; r < TS; ++r)
-#pragma unroll
-            for (int c = 0; c < TS; ++c) Lm[(ri * TS + r) * LD + cj * TS + c] = a[r][c];
-    }
-    __syncthreads();
-    PHASE_STAMP(ts2);
-#ifdef TSCM_PHASE_PROFILE
-    const long long cy2 = clock64();
-#endif
-    TailOperands tail_ops;
-    tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
-    if (tid < 64) {
-        // blocked back-substitution, TS unknowns per step: all lanes solve the TS x TS upper-triangular
-        // diagonal system redundantly (operands by broadcast), then lane i applies the TS columns to w[i]
-        constexpr int R = (N + 63) / 64;
-        double w[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) w[q] = tid + 64 * q < NP * TS ? wp[tid + 64 * q] : 0.0;
-        for (int tk = NP - 1; tk >= 0; --tk) {
-            const int k0 = tk * TS;
-            double y[TS];
-#pragma unroll
-            for (int c = 0; c < TS; ++c) {
-                const int k = k0 + c;
-                double v = 0.0;
-#pragma unroll
-                for (int q = 0; q < R; ++q) if ((k >> 6) == q) v = w[q];
-                y[c] = __shfl(v, k & 63);
-            }
-#pragma unroll
-            for (int c = TS - 1; c >= 0; --c) {
-                double v = y[c];
-#pragma unroll
-                for (int q = c + 1; q < TS; ++q) v -= Lm[(k0 + q) * LD + k0 + c] * y[q];
-                y[c] = v * idg[k0 + c];
-            }
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const int i = tid + 64 * q;
-                if (i < k0) {
-                    double v = w[q];
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) v -= Lm[(k0 + c) * LD + i] * y[c];
-                    w[q] = v;
-                } else if (i < k0 + TS) {
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) if (i == k0 + c) w[q] = y[c];
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < R; ++q) { const int pi = tid + 64 * q < N ? compact_to_padded(P, tid + 64 * q) : -1; if (pi >= 0) yv[pi] = w[q]; }    // back to padded columns
-    }
-    __syncthreads();
-    PHASE_STAMP(ts3);
-    reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred, FUSED && n_bs > 0 ? epoch : 0);
-#ifdef TSCM_PHASE_PROFILE
-    if (tid == 0) printf("solve_reduced: ctrl %lld operands %lld  factor %lld (%lld shader clocks)  backsub %lld  tail %lld [10 ns]\n", ts0b - ts0, ts1 - ts0b, ts2 - ts1, cy2 - cy1, ts3 - ts2, wall_clock64() - ts3);
-#endif
-}
+#include "tscm_solve_nd.h"
+#include "tscm_solve_dense4.h"
 
 // ---------------------------------------------------------------------------------------------
 // Reduced camera system of rigs with more than kMaxCamLds cameras (up to kMaxCam: 410 free columns): the
@@ -2606,7 +2218,7 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
     // the candidate's per-camera records (rotation, left-Jacobian vectors, intrinsics: write_camera_record): one camera
     // per workgroup, by the first lane of the second wave while the loads requested above are in flight -- a serial
     // chain of a few hundred operations that cost workgroup 0 4.6 us when it did all cameras after its board solves
-    if constexpr (!WAIT) { if (t == 64) for (int m = blk; m < P.C; m += nblk) write_camera_record(S, cur ^ 1, m); }
+    if constexpr (!WAIT) { if (t == 64 && nblk > 0) for (int m = blk; m < P.C; m += nblk) write_camera_record(S, cur ^ 1, m); }
     // ---- phase A -----------------------------------------------------------------------------------------------------
     {
         const int grp = t >> 4, a = t & 15;
@@ -2788,11 +2400,13 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
 #endif
 }
 
+// blk0: first group of this launch -- 0, or the number of groups that rode in the reduced solve's launch (the solver
+// workgroup of that launch has written the candidate's camera records then: nblk = 0 switches the writing off here)
 template <int NTH>
-__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
+__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats, int blk0)
 {
     KTL(5);
-    backsub_body<NTH, false>(P, S, with_floats, (int)blockIdx.x, (int)gridDim.x, 0, 0);
+    backsub_body<NTH, false>(P, S, with_floats, blk0 + (int)blockIdx.x, blk0 ? 0 : (int)gridDim.x, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2944,7 +2558,7 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
 {
     __shared__ double sm[256];
     ControlPre pre;
-    control_prefetch(P, S, init, pre);
+    control_prefetch(P, S, init, pre, S.ctrl);
     control_step(P, S, init, pre, sm, S.H_stage, S.H_stage + 256 * P.C, nullptr);
 }
 
@@ -2960,7 +2574,7 @@ __global__ __launch_bounds__(256) void k_begin_solve(DevState S, CtrlHead head, 
 {
     const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
     if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
-    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
+    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
     if (!reset) return;
     for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = init_cam[i];
     for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = init_intr[i];

@@ -1,0 +1,460 @@
+// tscm_solve_nd.h -- k_solve_nd: the reduced camera system (what DENSE_SCHUR hands to its dense Cholesky: TS.cpp:271-278,
+// multi_calib.cpp:209-216), up to 8 cameras, factored along the camera-pair graph.  Included by tscm_kernels.h.
+//
+//   A = S_c (H_cc - T) S_c + D_c^2,  rhs = S_c (g_c - t_r)  on the free camera-side columns.
+//
+// The plan (tscm_nd_plan.h, host, once per solver) orders the cameras by nested dissection of the pair graph -- a LEVEL is a
+// set of cameras that are not adjacent, eliminated concurrently; what is left when the rest is a clique is one dense
+// block -- cuts their blocks into panels of 4 columns and lists the PHASES: up to four panels, one per camera of a level.
+// The kernel is a blocked right-looking Cholesky with the matrix in REGISTERS, one 4 x 4 tile per thread (two where a rig
+// of 8 cameras has more than 192 tiles), run over that schedule:
+//   * threads 0..191 hold the structurally non-zero tiles (and the right-hand side as an extra tile row, so the
+//     forward substitution falls out of the panel solves), in the order their column panel is eliminated: early
+//     waves retire early;
+//   * a phase has two steps.  A: the owners of the tiles in the phase's panel columns solve X = A L_kk^-T from their
+//     registers and publish X (LDS, [slot][row panel]) -- their final factor entries.  B: a trailing tile (i, j) takes
+//     A_ij -= X_ik X_jk^T for every panel k of the phase it has both tiles for: two tile loads and 64 FMAs per update,
+//     so the tiles next to two cameras of a level (two updates per phase) cost little more than the others.  (Rounds
+//     1-3 and the first version here published the RAW column and let every trailing thread solve the two X tiles it
+//     needed itself -- one barrier per phase instead of two, but 144 dependent FMAs per update: 0.7 us, and a level's
+//     phases with two updates per tile took 1.6 us each.  A version with left-looking "boundary" updates per level paid
+//     for its structure lookups on every phase's dependent chain: 1.45 us per phase.)
+//   * lanes 0..3 of the fourth wave are the look-ahead lanes: lane q brings the diagonal tile of slot q of the NEXT
+//     phase up to date -- from the raw tiles (next panel, this phase's panels) their owners hand it one phase ahead --
+//     and factors it (4 x 4 Cholesky, rsq seeds) while the tile threads work: same instructions in the four lanes;
+//   * no table lookup on a phase's dependent chain: a tile's coordinates, its update mask and the rows it reads are
+//     in its registers, the phase's panels in an SGPR.
+// Ring of 8 cameras: 13 phases instead of 25, 227 matrix tiles instead of 325; ring of 4: 9 phases instead of 12.
+// Back-substitution: one wave, lane = unknown (two per lane), phases in reverse, the factor tile-packed and transposed in
+// LDS (a lane reads its column of a tile as two 16-byte loads; the tile's index follows from the row's structure mask by
+// a population count).  Then the common tail (yhat, candidate camera parameters, camera part of the model cost change).
+//
+// FUSED: the launch also carries the T reduction (workgroups 1 .. n_prod) and the back-substitution workgroups (behind
+// them), both in this kernel's 256-thread shape; see the hand-off notes at handoff_store() in tscm_kernels.h.
+// grid (1 + n_prod + n_bs) x 256, dynamic LDS NdPlan::lds_doubles (solver) / BsGeom<256>::kLds (back-substitution)
+#pragma once
+
+template <int TPT, bool FUSED>
+__global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProblem P, DevState S, const int4 *__restrict__ nd_map, const int *__restrict__ nd_tab, NdDims nd,
+                                                                       int epoch, int withhold, int n_prod, int n_bs, int with_floats)
+{
+    constexpr int NT = kNdThreads, TS = 4, XT = kNdXT, NPD = 128;
+    static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
+    if constexpr (FUSED) {
+        if ((int)blockIdx.x > n_prod) {
+#ifdef TSCM_WAVE_TIMELINE
+            KtlScope ktl_bs(5, S.ctrl);
+            ktl_bs.blk = (int)blockIdx.x - 1 - n_prod;
+#endif
+            backsub_body<256, true>(P, S, with_floats, (int)blockIdx.x - 1 - n_prod, n_bs, epoch, epoch * n_prod);
+            return;
+        }
+    }
+    KTL(4);
+    if constexpr (FUSED) {
+        if (blockIdx.x > 0) {
+            constexpr int kParts = 256 / kFusedEntries;
+            const int bid = ((int)blockIdx.x - 1) / kParts, part = ((int)blockIdx.x - 1) % kParts;
+            const int cb = P.bid_part_small[bid], ce = P.bid_part_small[bid + 1];      // kernel arguments: the partial tiles are the first thing requested
+            if (S.ctrl->done) return;
+            __shared__ double red[kTSlices][kFusedEntries];
+            t_reduce_block<kFusedEntries>(S, bid, part, cb, ce, red);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0 && !(withhold && blockIdx.x == 1))        // (withhold: fault injection, tscm_solver_debug_withhold_handoff)
+                __hip_atomic_fetch_add(S.t_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (no release fence: handoff_store)
+            return;
+        }
+    }
+    PHASE_STAMP(ts0);
+    const int ctrl_done = S.ctrl->done;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Ld = lds;                         // [32][20]  factor of each diagonal tile (16, row-major) and 1 / diag (4)
+    double *wp = Ld + 20 * kNdMaxPanels;      // [128] forward-substituted rhs  w = L^-1 b, in elimination order
+    double *yv = wp + NPD;                    // [128] solution by padded column
+    double *s_sc = yv + NPD;                  // [128]
+    double *s_yh = s_sc + NPD;                // [128]
+    double *s_dt = s_yh + NPD;                // [2][4][16] diagonal tiles handed to the look-ahead lanes (by the phase they are factored for)
+    double *s_dr = s_dt + 2 * kNdSlots * 16;  // [2][4][4][16] raw tiles (next phase's panel, this phase's panel) for the same lanes
+    int *s_tab = reinterpret_cast<int *>(s_dr + 2 * kNdSlots * kNdSlots * 16);
+    static_assert(kNdTabInts % 4 == 0, "the tiles behind the tables start on a 16-byte boundary");
+    double *Xs = reinterpret_cast<double *>(s_tab + kNdTabInts);      // [slots][NP + 1][XT] solved panel columns; later the packed factor
+    __shared__ int s_fail;
+    __shared__ unsigned char s_act[NPD];
+    __shared__ double sred[256];
+    const int n = P.n_pad;            // <= 128
+    const int tid = threadIdx.x;
+    const int NP = nd.NP, n_phases = nd.n_phases;
+    const int xs_slot = (NP + 1) * XT;
+    // ---- head: the operand map and the tables (structure only: written once per solver), the control block ----------------
+    // (the tile's coordinates stay packed in two words and are extracted where they are used)
+    struct Unit {
+        double a[TS][TS];
+        int m0, m1, lt;                 // m0: row panel | column panel << 8 | kind << 16 | look-ahead slot that needs this tile raw << 24; m1: phase | slot << 8 of the column panel
+        unsigned umask;
+        __device__ __forceinline__ int ri() const { return m0 & 0xff; }
+        __device__ __forceinline__ int cj() const { return (m0 >> 8) & 0xff; }
+        __device__ __forceinline__ int kind() const { return (m0 >> 16) & 0xff; }
+        __device__ __forceinline__ int dr() const { return (m0 >> 24) & 0xff; }
+        __device__ __forceinline__ int phase_c() const { return m1 & 0xff; }
+        __device__ __forceinline__ int slot_c() const { return (m1 >> 8) & 0xff; }
+        __device__ __forceinline__ bool diag() const { return ((m0 ^ (m0 >> 8)) & 0xff) == 0; }
+    };
+    Unit U[TPT];
+    int off[TPT][kNdUnitInts];
+#pragma unroll
+    for (int u = 0; u < TPT; ++u)
+#pragma unroll
+        for (int q = 0; q < kNdUnitInts / 4; ++q) {
+            const int4 v = nd_map[(u * (kNdUnitInts / 4) + q) * NT + tid];
+            off[u][4 * q] = v.x; off[u][4 * q + 1] = v.y; off[u][4 * q + 2] = v.z; off[u][4 * q + 3] = v.w;
+        }
+    for (int i = tid; i < kNdTabInts; i += NT) s_tab[i] = nd_tab[i];
+    const int cur = S.ctrl->cur;
+    const double radius = S.ctrl->radius;
+    const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
+    const int ctrl_fail = S.ctrl->lin_fail | *S.fac_fail;       // (fac_fail is cleared in the tail, by the one workgroup that solves)
+    for (int i = tid; i < NPD; i += NT) { s_sc[i] = i < n ? S.s_c[i] : 1.0; s_act[i] = i < n ? P.col_active[i] : 0; yv[i] = 0.0; }
+    if (ctrl_done) return;
+    PHASE_STAMP(tsA);
+    const double *H = S.H[cur];
+    double sci[TPT][TS], scj[TPT][TS], hh[TPT][TS][TS];
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r) {
+            const int oi = off[u][32 + r], oj = off[u][36 + r];
+            sci[u][r] = oi == kNdMapOne ? 1.0 : oi >= 0 ? S.s_c[oi] : 0.0;
+            scj[u][r] = oj >= 0 ? S.s_c[oj] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int c = 0; c < TS; ++c) { const int oh = off[u][r * TS + c]; hh[u][r][c] = oh >= 0 ? H[oh] : 0.0; }
+    }
+    if constexpr (FUSED) {
+        // everything that does not depend on T is in flight; now the tiles of the other workgroups
+        __shared__ int s_late;
+        if (tid == 0) {
+            const int need = epoch * n_prod;
+            const long long t_start = wall_clock64();
+            int late = 0;
+            while (__hip_atomic_load(S.t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t_start > kHandoffTimeoutTicks) { late = 1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (late) {
+                // not a failed linear solve (that would merely shrink the trust region and go on): the stream's work stops here
+                S.ctrl->fault = 1; S.ctrl->term_type = 2; S.ctrl->done = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // (the workgroups waiting for the camera step are let go: they see ctrl->done)
+                if (n_bs > 0) __hip_atomic_store(S.y_flag, 2 * epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_late = late;
+        }
+        __syncthreads();
+        if (s_late) return;
+    }
+    PHASE_STAMP(tsB);
+    const double inv_radius = 1.0 / radius;
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        U[u].m0 = off[u][40]; U[u].umask = (unsigned)off[u][41]; U[u].m1 = off[u][42]; U[u].lt = off[u][43];
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int c = 0; c < TS; ++c) {
+                const int ot = off[u][16 + r * TS + c];
+                const double tt = ot >= 0 ? (FUSED ? handoff_load(&S.T[ot]) : S.T[ot]) : 0.0;
+                // matrix tiles: S_c (H - T) S_c, damped diagonal; identity on the padding columns.  rhs tiles: row 0 of
+                // the map holds (g, t_r) of the panel's columns, s_c of the ROW is stored as 1 there.
+                const bool dg = U[u].kind() == 1 && U[u].diag() && r == c;
+                double v = sci[u][r] * scj[u][c] * (hh[u][r][c] - tt);
+                if (dg) v = off[u][32 + r] >= 0 ? v + fmin(fmax(sci[u][r] * sci[u][r] * hh[u][r][c], dmin), dmax) * inv_radius : 1.0;
+                U[u].a[r][c] = v;
+            }
+    }
+    PHASE_STAMP(ts1);
+    if (tid == 0) s_fail = ctrl_fail;
+    // ---- helpers ----------------------------------------------------------------------------------------------------------------
+    // tiles move as 16-byte pieces (every tile in LDS starts on a 16-byte boundary): ds_read_b128 / ds_write_b128.  Left to
+    // itself the compiler pairs the 8-byte accesses into ds_read2_b64, which the LDS serves in 16-lane groups with two-way
+    // bank conflicts (MI355X_MICROARCH.md, LDS; what cost k_eval_gram 4 M conflict cycles in round 2)
+    auto publish_tile = [&](double *dst, const double (&t)[TS][TS]) {
+        d2 *p = reinterpret_cast<d2 *>(dst);
+#pragma unroll
+        for (int r = 0; r < TS; ++r) { p[2 * r] = d2{ t[r][0], t[r][1] }; p[2 * r + 1] = d2{ t[r][2], t[r][3] }; }
+    };
+    auto load_tile = [&](const double *src, double (&t)[TS][TS]) {
+        const d2 *p = reinterpret_cast<const d2 *>(src);
+#pragma unroll
+        for (int r = 0; r < TS; ++r) { const d2 lo = p[2 * r], hi = p[2 * r + 1]; t[r][0] = lo[0]; t[r][1] = lo[1]; t[r][2] = hi[0]; t[r][3] = hi[1]; }
+    };
+    // Cholesky of the 4 x 4 tile t (lower part, in place); factor and inverse diagonal -> Ld[k]
+    auto factor_diag = [&](double (&t)[TS][TS], int k) {
+        double il[TS];
+#pragma unroll
+        for (int c = 0; c < TS; ++c) {
+            double d = t[c][c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) d -= t[c][q] * t[c][q];
+            if (!(d > 0.0)) { s_fail = 1; d = 1.0; }
+            const double isd = fast_rsqrt(d);
+            t[c][c] = d * isd; il[c] = isd;
+#pragma unroll
+            for (int r = c + 1; r < TS; ++r) {
+                double v = t[r][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= t[r][q] * t[c][q];
+                t[r][c] = v * isd;
+            }
+        }
+        double *dst = Ld + 20 * k;
+#pragma unroll
+        for (int r = 0; r < TS; ++r) {
+            dst[16 + r] = il[r];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) dst[r * TS + c] = c <= r ? t[r][c] : 0.0;
+        }
+    };
+    struct PanelFactor { double l[TS][TS], il[TS]; };
+    auto load_factor = [&](PanelFactor &f, int k) {
+        const double *src = Ld + 20 * k;
+#pragma unroll
+        for (int r = 0; r < TS; ++r) {
+            f.il[r] = src[16 + r];
+#pragma unroll
+            for (int c = 0; c < TS; ++c) f.l[r][c] = src[r * TS + c];
+        }
+    };
+    // X = A L^-T:  x[r][c] = (A[r][c] - sum_{q < c} x[r][q] L[c][q]) / L[c][c]
+    auto panel_solve = [&](const double (&At)[TS][TS], const PanelFactor &f, double (&x)[TS][TS]) {
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int c = 0; c < TS; ++c) {
+                double v = At[r][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= x[r][q] * f.l[c][q];
+                x[r][c] = v * f.il[c];
+            }
+    };
+    const bool dlane = tid >= kNdTileThreads && tid < kNdTileThreads + kNdSlots;
+    const int dq = tid - kNdTileThreads;                      // slot of a look-ahead lane
+    // The schedule in REGISTERS: lane l of every wave holds the panels of phase l and the row structure of panel l; a phase
+    // reads them with v_readlane (wave-uniform index) -- a table in LDS would put two or three dependent LDS round trips
+    // (0.1-0.15 us each) on every phase's critical path.  The look-ahead lanes hold their update masks as four words.
+    const int lane64 = tid & 63;
+    const int sp_v = lane64 < kNdMaxPhases ? nd_tab[kNdTabPhasePanels + lane64] : -1;
+    const int lm_v = lane64 <= kNdMaxPanels ? nd_tab[kNdTabLmask + lane64] : 0;
+    const int rs_v = lane64 <= kNdMaxPanels ? nd_tab[kNdTabRowStart + lane64] : 0;
+    int dm_w[4] = { 0, 0, 0, 0 };
+    if (dlane) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) dm_w[w] = nd_tab[kNdTabDmask + 4 * dq + w];
+    }
+    __syncthreads();                                          // the tables are in LDS
+    // ---- before the first phase: the diagonal tiles of phases 0 and 1, the raw tiles the look-ahead lanes need in phase 0 ----
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        if (!U[u].kind()) continue;
+        if (U[u].diag() && U[u].phase_c() <= 1) publish_tile(s_dt + (U[u].phase_c() * kNdSlots + U[u].slot_c()) * 16, U[u].a);
+        if (U[u].dr() != 0xff && U[u].phase_c() == 0) publish_tile(s_dr + (U[u].dr() * kNdSlots + U[u].slot_c()) * 16, U[u].a);
+    }
+    __syncthreads();
+    if (dlane) {
+        const int k = (__builtin_amdgcn_readlane(sp_v, 0) >> (8 * dq)) & 0xff;
+        if (k != 0xff) {
+            double t[TS][TS];
+            load_tile(s_dt + dq * 16, t);
+            factor_diag(t, k);
+        }
+    }
+    __syncthreads();
+#ifdef TSCM_PHASE_PROFILE
+    __shared__ long long s_pht[kNdMaxPhases + 1];
+    if (tid == 0) s_pht[0] = wall_clock64();
+#endif
+    // ---- factorisation: two barriers per phase ----------------------------------------------------------------------------------
+    // State at the top of phase t: the factors of its panels are in Ld; every tile is updated through phase t - 1;
+    // s_dt[(t + 1) & 1] holds the diagonal tiles of phase t + 1 (updated through t - 1), s_dr[t & 1] the raw tiles (panel of
+    // phase t + 1, panel of phase t).
+    unsigned sp = (unsigned)__builtin_amdgcn_readlane(sp_v, 0);
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const unsigned spn = ph + 1 < n_phases ? (unsigned)__builtin_amdgcn_readlane(sp_v, ph + 1) : 0xffffffffu;
+        if (tid >= kNdTileThreads) {
+            // look-ahead lanes: the diagonal tile of slot dq of the next phase, brought up to date through this phase, factored
+            double t[TS][TS];
+            const int kp = (spn >> (8 * dq)) & 0xff;
+            const bool on = dlane && kp != 0xff;
+            if (on) {
+                const int w8 = ph >> 3;                                          // (wave-uniform selects)
+                const unsigned dmask = ((unsigned)(w8 == 0 ? dm_w[0] : w8 == 1 ? dm_w[1] : w8 == 2 ? dm_w[2] : dm_w[3]) >> (4 * (ph & 7))) & 15u;
+                load_tile(s_dt + (((ph + 1) & 1) * kNdSlots + dq) * 16, t);
+#pragma unroll
+                for (int q = 0; q < kNdSlots; ++q) {
+                    const int k = (sp >> (8 * q)) & 0xff;
+                    if ((dmask >> q) & 1u) {
+                        PanelFactor f;
+                        double araw[TS][TS], x[TS][TS];
+                        load_factor(f, k);
+                        load_tile(s_dr + (((ph & 1) * kNdSlots + dq) * kNdSlots + q) * 16, araw);
+                        panel_solve(araw, f, x);
+#pragma unroll
+                        for (int r = 0; r < TS; ++r)
+#pragma unroll
+                            for (int c = 0; c <= r; ++c) {
+                                double v = t[r][c];
+#pragma unroll
+                                for (int e = 0; e < TS; ++e) v -= x[r][e] * x[c][e];
+                                t[r][c] = v;
+                            }
+                    }
+                }
+            }
+            __syncthreads();                                  // (barrier A: nothing of step A concerns these lanes)
+            if (on) factor_diag(t, kp);
+        } else {
+            // step A: the tiles of this phase's panel columns
+#pragma unroll
+            for (int u = 0; u < TPT; ++u) {
+                Unit &T = U[u];
+                if (T.kind() && T.phase_c() == ph && !T.diag()) {
+                    PanelFactor f;
+                    double x[TS][TS];
+                    load_factor(f, T.cj());
+                    panel_solve(T.a, f, x);
+#pragma unroll
+                    for (int r = 0; r < TS; ++r)
+#pragma unroll
+                        for (int c = 0; c < TS; ++c) T.a[r][c] = x[r][c];
+                    publish_tile(Xs + T.slot_c() * xs_slot + T.ri() * XT, x);
+                    if (T.kind() == 2) {
+#pragma unroll
+                        for (int c = 0; c < TS; ++c) wp[T.cj() * TS + c] = x[0][c];       // w of this panel
+                    }
+                }
+            }
+            __syncthreads();                                  // barrier A
+            // step B: trailing updates, then what the next two phases need
+#pragma unroll
+            for (int u = 0; u < TPT; ++u) {
+                Unit &T = U[u];
+                if (!T.kind() || T.phase_c() <= ph) continue;
+                const bool dskip = T.diag() && T.phase_c() == ph + 1;       // (the look-ahead lane takes that one)
+#pragma unroll
+                for (int q = 0; q < kNdSlots; ++q) {
+                    const int k = (sp >> (8 * q)) & 0xff;                   // (wave-uniform)
+                    if (k == 0xff) continue;
+                    if (((T.umask >> (k & 31)) & 1u) && !dskip) {
+                        double xi[TS][TS], xj[TS][TS];
+                        load_tile(Xs + q * xs_slot + T.ri() * XT, xi);
+                        load_tile(Xs + q * xs_slot + T.cj() * XT, xj);
+#pragma unroll
+                        for (int r = 0; r < TS; ++r)
+#pragma unroll
+                            for (int c = 0; c < TS; ++c) {
+                                double v = T.a[r][c];
+#pragma unroll
+                                for (int e = 0; e < TS; ++e) v -= xi[r][e] * xj[c][e];
+                                T.a[r][c] = v;
+                            }
+                    }
+                }
+                if (T.diag() && T.phase_c() == ph + 2) publish_tile(s_dt + (((ph + 2) & 1) * kNdSlots + T.slot_c()) * 16, T.a);
+                if (T.dr() != 0xff && T.phase_c() == ph + 1) publish_tile(s_dr + ((((ph + 1) & 1) * kNdSlots + T.dr()) * kNdSlots + T.slot_c()) * 16, T.a);
+            }
+        }
+        __syncthreads();                                      // barrier B
+        sp = spn;
+#ifdef TSCM_PHASE_PROFILE
+        if (tid == 0) s_pht[ph + 1] = wall_clock64();
+#endif
+    }
+    PHASE_STAMP(ts2);
+    // ---- the packed factor (row-major by (row panel, column panel), tiles transposed: a lane of the back-substitution reads one
+    //      COLUMN of a tile) -------------------------------------------------------------------------------------------------------
+    double *Lt = Xs;
+#pragma unroll
+    for (int u = 0; u < TPT; ++u)
+        if (U[u].kind() == 1 && U[u].lt >= 0) {
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c) Lt[16 * U[u].lt + 4 * c + r] = U[u].a[r][c];
+        }
+    __syncthreads();
+    TailOperands tail_ops;
+    tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
+    if (tid < 64) {
+        // L^T y = w, phases in reverse.  The panels of a phase do not depend on each other: their 4 x 4 upper triangular
+        // systems are solved by every lane redundantly (operands by broadcast), then lane i applies the columns it
+        // has a factor tile for to its two unknowns
+        double w[2];
+        int myp[2], myc[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int i = tid + 64 * e; w[e] = i < NP * TS ? wp[i] : 0.0; myp[e] = i >> 2; myc[e] = i & 3; }
+        for (int ph = n_phases - 1; ph >= 0; --ph) {
+            const unsigned spb = (unsigned)__builtin_amdgcn_readlane(sp_v, ph);
+            // every LDS operand of the phase is requested before the first use: the diagonal factors (wave-uniform addresses) and
+            // this lane's columns of the factor tiles it has -- none of them depends on the solution so far, so the phase's
+            // dependent chain is v_readlane -> 4 x 4 triangular solve -> four FMAs, with ONE exposed LDS latency in front
+            double ldg[kNdSlots][10], col[kNdSlots][2][TS];
+            bool has[kNdSlots][2];
+#pragma unroll
+            for (int q = 0; q < kNdSlots; ++q) {
+                const int k = (spb >> (8 * q)) & 0xff;
+                if (k == 0xff) continue;
+                const double *ld = Ld + 20 * k;
+                // (the strictly upper part of L_kk^T, row by row, and 1 / diag)
+                ldg[q][0] = ld[1 * TS + 0]; ldg[q][1] = ld[2 * TS + 0]; ldg[q][2] = ld[2 * TS + 1]; ldg[q][3] = ld[3 * TS + 0]; ldg[q][4] = ld[3 * TS + 1]; ldg[q][5] = ld[3 * TS + 2];
+#pragma unroll
+                for (int c = 0; c < TS; ++c) ldg[q][6 + c] = ld[16 + c];
+                const unsigned lmk = (unsigned)__builtin_amdgcn_readlane(lm_v, k);
+                const int rsk = __builtin_amdgcn_readlane(rs_v, k);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    has[q][e] = myp[e] < k && ((lmk >> (myp[e] & 31)) & 1u);
+                    const double *cp = Lt + 16 * (rsk + __popc(lmk & ((1u << (myp[e] & 31)) - 1u))) + 4 * myc[e];
+#pragma unroll
+                    for (int r = 0; r < TS; ++r) col[q][e][r] = has[q][e] ? cp[r] : 0.0;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < kNdSlots; ++q) {
+                const int k = (spb >> (8 * q)) & 0xff;
+                if (k == 0xff) continue;
+                // (w of the panel's four unknowns: v_readlane with a wave-uniform lane -- not the LDS crossbar)
+                double y[TS];
+#pragma unroll
+                for (int c = 0; c < TS; ++c) {
+                    const int i = k * TS + c;
+                    const double src = (i >> 6) ? w[1] : w[0];
+                    y[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(src), i & 63), __builtin_amdgcn_readlane(__double2loint(src), i & 63));
+                }
+                y[3] = y[3] * ldg[q][9];
+                y[2] = (y[2] - ldg[q][5] * y[3]) * ldg[q][8];
+                y[1] = (y[1] - ldg[q][2] * y[2] - ldg[q][4] * y[3]) * ldg[q][7];
+                y[0] = (y[0] - ldg[q][0] * y[1] - ldg[q][1] * y[2] - ldg[q][3] * y[3]) * ldg[q][6];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (myp[e] == k) w[e] = myc[e] == 0 ? y[0] : myc[e] == 1 ? y[1] : myc[e] == 2 ? y[2] : y[3];
+                    else if (has[q][e]) w[e] -= col[q][e][0] * y[0] + col[q][e][1] * y[1] + col[q][e][2] * y[2] + col[q][e][3] * y[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int i = tid + 64 * e; const int pi = i < NP * TS ? s_tab[kNdTabPcol + i] : -1; if (pi >= 0) yv[pi] = w[e]; }    // back to padded columns
+    }
+    __syncthreads();
+    PHASE_STAMP(ts3);
+    reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred, FUSED && n_bs > 0 ? epoch : 0);
+#ifdef TSCM_PHASE_PROFILE
+    if (tid == 0) {
+        printf("solve_nd: ctrl %lld  T wait %lld  operands %lld  to first phase %lld  factor %lld (%d phases)  backsub %lld  tail %lld [10 ns]\n", tsA - ts0, tsB - tsA, ts1 - tsB, s_pht[0] - ts1, ts2 - s_pht[0], n_phases, ts3 - ts2, wall_clock64() - ts3);
+        for (int ph = 0; ph < n_phases; ++ph) printf("  phase %d: %lld\n", ph, s_pht[ph + 1] - s_pht[ph]);
+    }
+#endif
+}

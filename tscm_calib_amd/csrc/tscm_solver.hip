@@ -91,12 +91,24 @@ struct tscm_solver {
     bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
     bool fuse_backsub = true;           // this solve: k_backsub_prep rides in it too (TSCM_EXEC_SEPARATE_BACKSUB clears it)
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
-    int schur_one_round = 0;            // largest grid of k_schur_gram whose workgroups are all resident at once (2 per CU)
+    int schur_resident[4] = { 0, 0, 0, 0 };   // workgroups of k_schur_gram<NV> that are resident at once (occupancy x CUs): the first round of its grid
+    int ctl_epoch = 0;                  // control steps taken in k_schur_gram's head in this solve so far
     int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator)
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
-    int withhold = 0;                   // this solve: TSCM_EXEC_TEST_WITHHOLD_HANDOFF
+    int withhold = 0, withhold_next = 0; // this solve / the next one: fault injection (tscm_solver_debug_withhold_handoff)
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
-    int solve_variant = 0;              // 0: k_solve_reduced<4,16,64>, 1: <4,25,128>, 2: <4,32,128>, 3: k_solve_reduced_big (more than 8 cameras)
+    int solve_variant = 0;              // 0: k_solve_reduced (up to 4 cameras: one dense block), 1: k_solve_nd (5..8 cameras, or TSCM_EXEC_GRAPH_REDUCED_ORDER), 3: k_solve_reduced_big (more than 8 cameras)
+    int dense4_resident = 0;            // workgroups of k_solve_reduced<4, 16, 64, true>'s launch that are resident at once
+    // k_solve_nd: [0] the nested-dissection plan of the camera-pair graph, [1] one dense block (TSCM_EXEC_DENSE_REDUCED_ORDER; also what
+    // [0] is when the graph is complete); operand map and tables of each on the device; workgroups of the fused launch
+    // that are resident at once (occupancy x CUs)
+    NdPlan plan[2];
+    const int4 *d_nd_map[2] = { nullptr, nullptr };
+    const int *d_nd_tab[2] = { nullptr, nullptr };
+    size_t lds_nd[2] = { 0, 0 }, lds_dense4 = 0;
+    int nd_resident[2] = { 0, 0 };
+    int nd = 0;                         // this solve: which of the two
+    bool graph_order = false;           // this solve: k_solve_nd also for a rig of up to 4 cameras (TSCM_EXEC_GRAPH_REDUCED_ORDER / _DENSE_REDUCED_ORDER there)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
     size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4 (boards of <= 56 corners)
@@ -419,7 +431,10 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         // get equal numbers of workgroups: two per CU on big problems (a multiple of the CU count), never more than
         // kChunkBoards boards each, at least 16 (four waves of one group of four).
         const int target_bchunks = 2 * std::max(1, prop.multiProcessorCount);
-        s->schur_one_round = target_bchunks;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[1], reinterpret_cast<const void *>(k_schur_gram<1>), 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[2], reinterpret_cast<const void *>(k_schur_gram<2>), 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[3], reinterpret_cast<const void *>(k_schur_gram<3>), 256, 0));
+        for (int nv = 1; nv <= 3; ++nv) s->schur_resident[nv] *= prop.multiProcessorCount;
         const int per_bchunk = std::min<int>(kChunkBoards, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
         size_t i = 0;
         while (i < order_b.size()) {
@@ -483,9 +498,6 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     DevState &S = s->S;
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
     P.rank = rank; P.world = world;
-    P.pair_mask = 0;
-    if (C <= kMaxCamLds)
-        for (int mi = 0; mi < C; ++mi) for (int mj = mi; mj < C; ++mj) if (bid_of[mi * C + mj] >= 0) P.pair_mask |= 1ull << (mi * 8 + mj);
     P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double));
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
     P.n_bchunks = (int)bc_begin.size(); P.n_tiles = n_tiles;
@@ -525,8 +537,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         // groups of 16 boards while they all fit the chip at once (5 workgroups per CU), groups of 32 beyond that
         s->bs_threads = (B + 15) / 16 > 5 * std::max(1, prop.multiProcessorCount) * 3 / 2 ? 256 : 128;
         // ... and groups of 32 (256 threads, the reduced solve's workgroup shape) wherever the back-substitution can ride
-        // in the reduced solve's launch (one GPU, <= 4 cameras: k_solve_reduced<4, 16, 64, true>)
-        if (16 * C <= 64 && n_bids > 0 && n_bids <= kSmallBids) s->bs_threads = 256;
+        // in the reduced solve's launch (up to 8 cameras: k_solve_nd<.., true>)
+        if (C <= kMaxCamLds && n_bids > 0) s->bs_threads = 256;
         s->lds_bs = sizeof(double) * (size_t)(s->bs_threads == 256 ? BsGeom<256>::kLds : BsGeom<128>::kLds);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_backsub_prep<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bs));
@@ -537,6 +549,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.pc_end, pc_end))) return rc;
     if ((rc = dev_upload(s, &P.pc_tile, pc_tile))) return rc;
     if ((rc = dev_upload(s, &P.bid_part_ptr, bid_part_ptr))) return rc;
+    static_assert(kSmallBids >= kMaxCamLds * (kMaxCamLds + 1) / 2, "every camera pair of a rig the register/LDS solver takes");
     for (int b = 0; b <= kSmallBids; ++b) P.bid_part_small[b] = bid_part_ptr[std::min(b, n_bids)];
     if ((rc = dev_upload(s, &P.sslot, sslot))) return rc;
     if ((rc = dev_upload(s, &P.sboard, sboard))) return rc;
@@ -558,6 +571,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         std::vector<short> lut(bid_of.begin(), bid_of.end());
         if ((rc = dev_upload(s, &P.bid_lut, lut))) return rc;
     }
+    std::vector<unsigned char> col_active_host;
     if ((rc = dev_upload(s, &P.cam_const, cam_const))) return rc;
     if ((rc = dev_upload(s, &P.cam_active, cam_active))) return rc;
     {
@@ -566,7 +580,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         if ((rc = dev_upload(s, &P.board_const, board_const))) return rc;
     }
     {
-        std::vector<unsigned char> col_active((size_t)s->n_pad, 0);
+        std::vector<unsigned char> &col_active = col_active_host;
+        col_active.assign((size_t)s->n_pad, 0);
         for (int i = 0; i < s->n_pad; ++i) { const int m = i >> 4, a = i & 15; col_active[i] = (a < kFA && cam_active[m] && !(a < 6 && cam_const[m])) ? 1 : 0; }
         if ((rc = dev_upload(s, &P.col_active, col_active))) return rc;
         // compact numbering of the free camera-side columns: the reduced system is factored without the
@@ -575,24 +590,18 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         int n_act = 0;
         for (int i = 0; i < s->n_pad; ++i) if (col_active[i]) act_map[n_act++] = i;
         P.n_act = n_act;
-        // closed form of the same map for the register/LDS solver (kernel arguments, see DevProblem)
+        // closed form of the same map for k_solve_reduced (kernel arguments, see DevProblem)
         for (int q = 0; q < 9; ++q) P.cam_pre[q] = n_act;
         for (int q = 0; q < 8; ++q) P.cam_col0[q] = 0;
+        P.pair_mask = 0;
         if (C <= kMaxCamLds) {
+            for (int mi = 0; mi < C; ++mi) for (int mj = mi; mj < C; ++mj) if (bid_of[mi * C + mj] >= 0) P.pair_mask |= 1ull << (mi * 8 + mj);
             int run = 0;
             for (int m = 0; m < C; ++m) {
                 P.cam_pre[m] = run;
                 P.cam_col0[m] = 16 * m + (cam_const[m] ? 6 : 0);
                 if (cam_active[m]) run += cam_const[m] ? kFA - 6 : kFA;
             }
-            // (host replica of the kernel's cmap(): must reproduce act_map exactly)
-            bool same = run == n_act;
-            for (int ci = 0; ci < n_act && same; ++ci) {
-                int base = 0, c0 = P.cam_col0[0];
-                for (int q = 1; q < kMaxCamLds; ++q) if (ci >= P.cam_pre[q]) { base = P.cam_pre[q]; c0 = P.cam_col0[q]; }
-                same = c0 + (ci - base) == act_map[ci];
-            }
-            if (!same) return fail(TSCM_E_UNSUPPORTED, "internal error: closed-form column map disagrees with the table");
         }
         if ((rc = dev_upload(s, &P.act_map, act_map))) return rc;
     }
@@ -632,10 +641,14 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     S.n_bs_blocks = (B + s->bs_threads / 8 - 1) / (s->bs_threads / 8);        // groups of k_backsub_prep's geometry
     if ((rc = dev_alloc(s, &S.st_part, 3 * (size_t)S.n_st_blocks))) return rc;
     if ((rc = dev_alloc(s, &S.ctrl, 1))) return rc;
+    if ((rc = dev_alloc(s, &S.ctrl_snap, 1))) return rc;
+    if ((rc = dev_alloc(s, &S.ctl_pub, 1))) return rc;
+    HIP_TRY(hipMemset(S.ctl_pub, 0, sizeof(CtlPub)));
     HIP_TRY(hipMemset(S.T, 0, sizeof(double) * 256 * (size_t)n_bids));
     HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal + world)));
     HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 512 * (size_t)C));
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
+    HIP_TRY(hipMemset(S.ctrl_snap, 0, sizeof(CtrlHead)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
     s->lds_eval = 4 * lds_eval_bytes;
@@ -645,37 +658,62 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     s->lds_eval4 += TSCM_G4_LDS_PAD;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval4));
 #endif
-    // reduced solve on the compact system, 4 x 4 tiles, one more tile row for the right-hand side: 16 x 16 threads
-    // (<= 4 cameras: at most 13 panels), 25 x 25 threads (<= 24 panels, e.g. 7 cameras with one constant pose: 85
-    // columns) or 32 x 32 threads (8 cameras: <= 104 columns, 26 panels)
-    {
-        auto lds_doubles = [](size_t NN, size_t TT, size_t NPD) { return NN * (NN + 2) + 2 * (NN / TT) * (TT * TT + 2) + 2 * NN + 3 * NPD; };
-        s->solve_variant = s->n_pad <= 64 ? 0 : s->n_pad > 16 * kMaxCamLds ? 3 : (P.n_act <= 96 ? 1 : 2);
-        s->lds_solve = sizeof(double) * (s->solve_variant == 0 ? lds_doubles(64, 4, 64) : s->solve_variant == 1 ? lds_doubles(100, 4, 128) : lds_doubles(128, 4, 128));
-        if (s->solve_variant == 3) {
-            // rigs of 9..32 cameras: the compact system (+ rhs row) lives in global memory
-            const int NN = (P.n_act + 15) & ~15;
-            s->lds_solve = solve_big_lds_bytes(NN, s->n_pad);
-            if ((rc = dev_alloc(s, &S.Abig, (size_t)256 * (NN / 16 + 1) * (NN / 16 + 2) / 2))) return rc;      // packed lower triangle of 16x16 blocks, incl. the rhs block row
-        }
-    }
-    if (s->solve_variant <= 2) {
+    // reduced solve: up to 8 cameras k_solve_nd on the plan of the camera-pair graph (tscm_nd_plan.h), larger rigs in global memory
+    s->solve_variant = C <= 4 ? 0 : C <= kMaxCamLds ? 1 : 3;
+    if (s->solve_variant == 0) {
         // where every thread of k_solve_reduced finds its operands (camera / pair structure only): written once
-        const int nt = s->solve_variant == 0 ? 256 : s->solve_variant == 1 ? 640 : 1024;
         int4 *map = nullptr;
-        if ((rc = dev_alloc(s, &map, (size_t)(kSolveMapSlots / 4) * nt))) return rc;
-        if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_map<4, 16>), dim3(1), dim3(nt), 0, 0, P, map);
-        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_map<4, 25>), dim3(1), dim3(nt), 0, 0, P, map);
-        else hipLaunchKernelGGL((k_solve_map<4, 32>), dim3(1), dim3(nt), 0, 0, P, map);
+        if ((rc = dev_alloc(s, &map, (size_t)(kSolveMapSlots / 4) * 256))) return rc;
+        hipLaunchKernelGGL((k_solve_map<4, 16>), dim3(1), dim3(256), 0, 0, P, map);
         HIP_TRY(hipGetLastError());
         P.solve_map = map;
+        const size_t NN = 64, TT = 4, NPD = 64;
+        s->lds_dense4 = sizeof(double) * (NN * (NN + 2) + 2 * (NN / TT) * (TT * TT + 2) + 2 * NN + 3 * NPD);
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_reduced<4, 16, 64, true>), 256, std::max(s->lds_dense4, s->lds_bs)));
+        s->dense4_resident = per_cu * prop.multiProcessorCount;
+    }
+    if (s->solve_variant <= 1) {
+        int ncols[kMaxCamLds], col0[kMaxCamLds];
+        for (int m = 0; m < C; ++m) { ncols[m] = cam_active[m] ? (cam_const[m] ? kFA - 6 : kFA) : 0; col0[m] = 16 * m + (cam_const[m] ? 6 : 0); }
+        for (int v = 0; v < 2; ++v) {
+            if (!nd_build_plan(C, ncols, col0, pair_present.data(), bid_of.data(), /*dense_only=*/v == 1, s->plan[v]))
+                return fail(TSCM_E_UNSUPPORTED, "internal error: the reduced system does not fit the register/LDS solver");
+            const NdPlan &pl = s->plan[v];
+            // (host replica check: the plan's columns are exactly the free columns)
+            std::vector<int> cols;
+            for (int pc : pl.pcol) if (pc >= 0) cols.push_back(pc);
+            std::sort(cols.begin(), cols.end());
+            std::vector<int> want;
+            for (int i = 0; i < s->n_pad; ++i) if (col_active_host[i]) want.push_back(i);
+            if (cols != want) return fail(TSCM_E_UNSUPPORTED, "internal error: elimination plan does not cover the free columns");
+            const int4 *map = nullptr;
+            {
+                std::vector<int4> m4(pl.map.size() / 4);
+                std::memcpy(m4.data(), pl.map.data(), pl.map.size() * sizeof(int));
+                if ((rc = dev_upload(s, &map, m4))) return rc;
+            }
+            s->d_nd_map[v] = map;
+            if ((rc = dev_upload(s, &s->d_nd_tab[v], pl.tab))) return rc;
+            s->lds_nd[v] = sizeof(double) * pl.lds_doubles;
+            // workgroups of the fused launch that are resident at once: the back-substitution workgroups that ride in it WAIT
+            // for the solver workgroup, so only as many are put there as fit the chip next to it (and the T producers)
+            const size_t lds = std::max(s->lds_nd[v], s->lds_bs);
+            int per_cu = 0;
+            if (pl.tpt == 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<1, true>), kNdThreads, lds));
+            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<2, true>), kNdThreads, lds));
+            s->nd_resident[v] = per_cu * prop.multiProcessorCount;
+        }
+        s->lds_solve = std::max(s->lds_nd[0], s->lds_nd[1]);
+    }
+    if (s->solve_variant == 3) {
+        // rigs of 9..32 cameras: the compact system (+ rhs row) lives in global memory
+        const int NN = (P.n_act + 15) & ~15;
+        s->lds_solve = solve_big_lds_bytes(NN, s->n_pad);
+        if ((rc = dev_alloc(s, &S.Abig, (size_t)256 * (NN / 16 + 1) * (NN / 16 + 2) / 2))) return rc;      // packed lower triangle of 16x16 blocks, incl. the rhs block row
+        if (s->lds_solve > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
     }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
-    if (s->lds_solve > 64 * 1024) {
-        if (s->solve_variant == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<4, 25, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
-        else if (s->solve_variant == 3) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
-        else HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_reduced<4, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_solve));
-    }
     HIP_TRY(hipDeviceSynchronize());
     *out = sp.release();
     return 0;
@@ -690,6 +728,16 @@ static tscm_comm *effective_comm(const tscm_solver *s, int exec_flags)
 {
     tscm_comm *c = s->comm_reg;
     return (c && (c->world > 1 || c->group || (exec_flags & TSCM_EXEC_KEEP_SINGLE_RANK_COMM))) ? c : nullptr;
+}
+
+// Fault injection for the tests of the device-side hand-off: in the NEXT solve of this solver one producer of the fused
+// hand-off never reports in, and the solve must end with TSCM_E_HIP within the hand-off's time bound.  Not an option of
+// a solve (tscm_options carries nothing that can make a production solve fail).
+extern "C" int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    s->withhold_next = on ? 1 : 0;
+    return 0;
 }
 
 extern "C" int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm)
@@ -889,9 +937,9 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
     return 0;
 }
 
-// one GPU, reduced system of at most 64 columns: the T reduction rides in the reduced solve's launch (k_solve_reduced<..., true>);
-// with a communicator the all-reduce of T sits between the two
-static bool fused_reduce(const tscm_solver *s) { return s->fuse_reduce && s->solve_variant == 0 && !s->comm && s->P.n_bids > 0 && s->P.n_bids <= kSmallBids; }
+// one GPU, up to 8 cameras: the T reduction rides in the reduced solve's launch (k_solve_nd<.., true>); with a communicator the
+// all-reduce of T sits between the two
+static bool fused_reduce(const tscm_solver *s) { return s->fuse_reduce && s->solve_variant <= 1 && !s->comm && s->P.n_bids > 0 && s->P.n_bids <= kSmallBids; }
 
 static int enqueue_iteration(LmRun &run)
 {
@@ -901,9 +949,10 @@ static int enqueue_iteration(LmRun &run)
         const int ctl = s->eval_pending;                  // (ctl_in_schur: exactly one of the three variants below is launched)
         s->eval_pending = 0;
         if (P.n_slow) hipLaunchKernelGGL(k_schur_factor, dim3((P.n_slow + 255) / 256), dim3(256), 0, s->stream, P, S);
-        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl);
-        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl);
-        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl);
+        const int ce = ctl ? ++s->ctl_epoch : 0;
+        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce);
+        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce);
+        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce);
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
@@ -912,28 +961,45 @@ static int enqueue_iteration(LmRun &run)
         const DevProblem &P = s->P;
         DevState &S = s->S;
         const int wf = s->f32_jacobian ? 1 : 0;
-        if (fused_reduce(s)) {
-            // one GPU, <= 4 cameras: T reduction, reduced solve and (unless TSCM_EXEC_SEPARATE_BACKSUB) the back-substitution
-            // workgroups, which wait for the camera step with their operands loaded, in ONE launch
-            const int n_prod = P.n_bids * (256 / kFusedEntries);
-            const int n_bs = s->fuse_backsub && s->bs_threads == 256 ? S.n_bs_blocks : 0;
-            hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_solve, n_bs ? s->lds_bs : (size_t)0), s->stream,
-                               P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
-            if (n_bs) continue;
-        }
-        else if (s->solve_variant == 0 && s->fuse_backsub && s->bs_threads == 256 && S.n_bs_blocks) {
-            // T was reduced (and all-reduced) by launches of its own: no producers, but the back-substitution workgroups
-            // still ride in the solve's launch
-            hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + S.n_bs_blocks), dim3(256), std::max(s->lds_solve, s->lds_bs), s->stream,
-                               P, S, ++s->t_epoch, 0, 0, S.n_bs_blocks, wf);
+        if (s->solve_variant == 0 && !s->graph_order) {
+            // up to 4 cameras, one dense block: the same launch shape with k_solve_reduced as the solver workgroup
+            const int n_prod = fused_reduce(s) ? P.n_bids * (256 / kFusedEntries) : 0;
+            const int n_bs = s->fuse_backsub && s->bs_threads == 256 ? std::max(0, std::min(S.n_bs_blocks, s->dense4_resident - 1 - n_prod)) : 0;
+            if (n_prod || n_bs)
+                hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
+                                   P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+            else hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_dense4, s->stream, P, S, 0, 0, 0, 0, 0);
+            const int rest = S.n_bs_blocks - n_bs;
+            if (rest > 0 && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(rest), dim3(128), s->lds_bs, s->stream, P, S, wf, n_bs);
+            if (rest > 0 && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(rest), dim3(256), s->lds_bs, s->stream, P, S, wf, n_bs);
             continue;
         }
-        else if (s->solve_variant == 0) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
-        else if (s->solve_variant == 1) hipLaunchKernelGGL((k_solve_reduced<4, 25, 128>), dim3(1), dim3(640), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
-        else if (s->solve_variant == 2) hipLaunchKernelGGL((k_solve_reduced<4, 32, 128>), dim3(1), dim3(1024), s->lds_solve, s->stream, P, S, 0, 0, 0, 0, 0);
-        else hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
-        if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
-        if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, s->f32_jacobian ? 1 : 0);
+        if (s->solve_variant <= 1) {
+            // 5 to 8 cameras (and TSCM_EXEC_GRAPH_REDUCED_ORDER): T reduction (one GPU), reduced solve and -- unless TSCM_EXEC_SEPARATE_BACKSUB -- the back-substitution
+            // workgroups, which wait for the camera step with their operands loaded, in ONE launch.  Only as many of them as
+            // are resident next to the solver workgroup and the producers ride there (a waiting workgroup that keeps the
+            // solver off the chip would wait for ever): the others follow in a launch of their own
+            const int v = s->nd;
+            const int n_prod = fused_reduce(s) ? P.n_bids * (256 / kFusedEntries) : 0;
+            const int n_bs = s->fuse_backsub && s->bs_threads == 256 ? std::max(0, std::min(S.n_bs_blocks, s->nd_resident[v] - 1 - n_prod)) : 0;
+            const bool two = s->plan[v].tpt == 2;
+            if (n_prod || n_bs) {
+                const size_t lds = std::max(s->lds_nd[v], n_bs ? s->lds_bs : (size_t)0);
+                const dim3 grid(1 + n_prod + n_bs);
+                if (two) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                else hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+            } else {
+                if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
+                else hipLaunchKernelGGL((k_solve_nd<1, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
+            }
+            const int rest = S.n_bs_blocks - n_bs;
+            if (rest > 0 && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(rest), dim3(128), s->lds_bs, s->stream, P, S, wf, n_bs);
+            if (rest > 0 && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(rest), dim3(256), s->lds_bs, s->stream, P, S, wf, n_bs);
+            continue;
+        }
+        hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
+        if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf, 0);
+        if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf, 0);
     }
     return enqueue_eval(run, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
@@ -1014,6 +1080,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     tscm_options opt;
     if (opt_in) opt = *opt_in; else tscm_default_options(&opt, s0->mono);
     if (opt.max_num_iterations < 0 || opt.max_num_iterations > TSCM_MAX_ITERATIONS) return fail(TSCM_E_INVALID, "max_num_iterations must be in [0, 255]");
+    if (opt.exec_flags & ~TSCM_EXEC_ALL) return fail(TSCM_E_INVALID, "unknown bits in tscm_options.exec_flags (an options struct of an older ABI?)");
     HIP_TRY(hipSetDevice(s0->device));
     LmRunGuard guard{ run };
     for (tscm_solver *s : run.m) {
@@ -1023,15 +1090,17 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         {
             // one GPU with <= 8 cameras (finish_evaluation's LDS fits k_schur_gram's) or a communicator; exactly one Schur kernel per iteration
             const int n_variants = (s->nv_chunks[1] ? 1 : 0) + (s->nv_chunks[2] ? 1 : 0) + (s->nv_chunks[3] ? 1 : 0);
-            // ... whose workgroups are resident at once: the step costs every workgroup 4.5 us, and a grid of several
-            // rounds (config 5: 1256 workgroups, 2.5 rounds) pays that per round -- measured: 391 against 383 us
-            const int n_chunks = s->nv_chunks[1] + s->nv_chunks[2] + s->nv_chunks[3];
-            s->ctl_in_schur = (s->comm || s->P.C <= kMaxCamLds) && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 && n_chunks <= s->schur_one_round &&
+            // (a grid of several rounds -- config 5 on one GPU: 1256 workgroups, 2.5 rounds -- pays the step in its first round
+            // only: the later rounds read the outcome workgroup 0 publishes)
+            s->ctl_in_schur = (s->comm || s->P.C <= kMaxCamLds) && s->P.n_slow == 0 && s->P.n_pchunks == 0 && n_variants == 1 &&
                               !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
             s->eval_pending = 0;
+            s->ctl_epoch = 0;
         }
-        s->withhold = (opt.exec_flags & TSCM_EXEC_TEST_WITHHOLD_HANDOFF) ? 1 : 0;
+        s->withhold = s->withhold_next; s->withhold_next = 0;
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
+        s->nd = (opt.exec_flags & TSCM_EXEC_DENSE_REDUCED_ORDER) ? 1 : 0;
+        s->graph_order = (opt.exec_flags & TSCM_EXEC_GRAPH_REDUCED_ORDER) != 0 || (s->solve_variant == 0 && s->nd);
         s->t_epoch = 0;
     }
     if (s0->comm && !s0->comm->group && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");

@@ -23,7 +23,8 @@ EXEC_KEEP_SINGLE_RANK_COMM = 2
 EXEC_GRAM_16X16 = 4
 EXEC_SEPARATE_BACKSUB = 8
 EXEC_SEPARATE_CONTROL = 16
-EXEC_TEST_WITHHOLD_HANDOFF = 0x100
+EXEC_DENSE_REDUCED_ORDER = 32
+EXEC_GRAPH_REDUCED_ORDER = 64
 
 E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
            -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM"}
@@ -111,7 +112,7 @@ class CCornerSet(C.Structure):
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_device_peak_fp64_ex", "tscm_default_options",
-    "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_solve", "tscm_solver_upload_params",
+    "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
     "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
@@ -162,6 +163,7 @@ def lib():
     L.tscm_solver_gather_boards.argtypes = [vp, dp]
     L.tscm_comm_info.argtypes = [vp, ip, ip, ip]
     L.tscm_solver_set_comm.argtypes = [vp, vp]
+    L.tscm_solver_debug_withhold_handoff.argtypes = [vp, C.c_int]
     L.tscm_solver_solve.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary)]
     L.tscm_solver_upload_params.argtypes = [vp, dp, dp, dp]
     L.tscm_solver_solve_resident.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary), C.c_int]
