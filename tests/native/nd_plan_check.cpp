@@ -212,31 +212,31 @@ int main(int argc, char **argv)
     std::vector<double> Lt((size_t)16 * std::max(pl.n_lt, 1), 0.0);
     for (int t = 0; t < nt; ++t) if (pl.tiles[t].lt >= 0)
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Lt[(size_t)16 * pl.tiles[t].lt + 4 * c + r] = a[t].v[r][c];
-    auto lt_tile = [&](int i, int k) { return &Lt[(size_t)16 * pl.lt_of(i, k)]; };
-    // back-substitution L^T y = w, phases in reverse
+    // back-substitution L^T y = w, phases in reverse, left-looking: y_k = L_kk^-T (w_k - sum_{i > k} L_ik^T y_i), the tiles of a
+    // panel's column gathered by the 16 lanes of its slot (NdPlan::bs_tab) and summed over the lanes
     std::vector<double> w(wp);
     for (int ph = pl.n_phases - 1; ph >= 0; --ph) {
         const unsigned sp = pl.phase_panels[ph];
-        double y[4][4];
-        int ks[4];
+        double acc[64][4];
+        for (int l = 0; l < 64; ++l) for (int c = 0; c < 4; ++c) acc[l][c] = 0.0;
+        for (int rd = 0; rd < pl.bs_rounds; ++rd)
+            for (int l = 0; l < 64; ++l) {
+                const int e = pl.bs_tab[((size_t)ph * pl.bs_rounds + rd) * 64 + l];
+                if (e < 0) continue;
+                const int lt = e & 0xffff, i = e >> 16;
+                for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) acc[l][c] += Lt[(size_t)16 * lt + 4 * c + r] * w[4 * i + r];
+            }
         for (int q = 0; q < 4; ++q) {
-            ks[q] = (sp >> (8 * q)) & 0xff;
-            if (ks[q] == 0xff) continue;
-            const int k = ks[q];
+            const int k = (sp >> (8 * q)) & 0xff;
+            if (k == 0xff) continue;
+            double v[4];
+            for (int c = 0; c < 4; ++c) { double sum = 0.0; for (int j = 0; j < kNdBsGroup; ++j) sum += acc[kNdBsGroup * q + j][c]; v[c] = w[4 * k + c] - sum; }
             for (int c = 3; c >= 0; --c) {
-                double v = w[4 * k + c];
-                for (int e = c + 1; e < 4; ++e) v -= LdM(k)[e][c] * y[q][e];
-                y[q][c] = v * il[4 * k + c];
+                double x = v[c];
+                for (int e = c + 1; e < 4; ++e) x -= LdM(k)[e][c] * v[e];
+                v[c] = x * il[4 * k + c];
             }
-        }
-        for (int q = 0; q < 4; ++q) {
-            if (ks[q] == 0xff) continue;
-            const int k = ks[q];
-            for (int i = 0; i < 4 * NP; ++i) {
-                const int p = i >> 2, c = i & 3;
-                if (p == k) w[i] = y[q][c];
-                else if (p < k && ((pl.lmask[k] >> p) & 1u)) { const double *L = lt_tile(k, p); for (int r = 0; r < 4; ++r) w[i] -= L[4 * c + r] * y[q][r]; }
-            }
+            for (int c = 0; c < 4; ++c) w[4 * k + c] = v[c];
         }
     }
     double err = 0.0, ref = 0.0;

@@ -346,7 +346,7 @@ def test_boards_seen_by_one_to_four_cameras(hip_device):
 
 
 def test_eight_camera_rig(hip_device):
-    """C = 8 (BASELINE config 5 shape, small): 128-wide reduced system (second solver template)."""
+    """C = 8 (BASELINE config 5 shape, small): k_solve_nd along the ring of 8 cameras, two tiles per thread."""
     p = synth.make_problem(8, 6, 23)
     pg, po, gs, os_ = _solve_both(p)
     _cmp_trace(gs, os_)
@@ -358,10 +358,10 @@ def test_eight_camera_rig(hip_device):
 
 @pytest.mark.parametrize("C,free_gauge", [(2, False), (3, False), (4, True), (5, False), (6, False), (7, False), (7, True), (8, False), (8, True)])
 def test_reduced_solver_geometries(hip_device, C, free_gauge):
-    """Every shape of the blocked reduced solve: 16 x 16 threads up to 13 panels (4 cameras, no constant pose: the last
-    panel row shares a wave with the look-ahead thread), 25 x 25 up to 24 panels (5-7 cameras), 32 x 32 above
-    (7 cameras with every pose free: 91 columns -> 23 panels still 25 x 25; 8 cameras: 98 / 104 columns).  With no
-    constant camera pose the system has a gauge freedom that only the LM damping removes (Ceres accepts that too)."""
+    """Ring rigs of 2-8 cameras: the dense k_solve_reduced up to 4 cameras (13 panels with no constant pose: the last panel
+    row shares a wave with the look-ahead thread), k_solve_nd along the ring from 5 (one tile per thread up to 7 cameras,
+    two at 8).  With no constant camera pose the system has a gauge freedom that only the LM damping removes (Ceres accepts
+    that too)."""
     p = synth.make_problem(C, 8, 40 + C)
     if free_gauge:
         p.cam_pose_constant[:] = 0
@@ -384,21 +384,37 @@ GRAPHS = {
 
 @pytest.mark.parametrize("name", sorted(GRAPHS))
 def test_reduced_solver_along_the_camera_pair_graph(hip_device, name):
-    """The reduced camera system is factored along the camera-pair graph (nested dissection, tscm_nd_plan.h; rings are
-    covered by every BASELINE config).  Chains, stars, two coupled rings and complete graphs (= one dense block) against
-    the oracle's dense Cholesky, and against the same kernel on the dense order (TSCM_EXEC_DENSE_REDUCED_ORDER): the two
-    orders agree to rounding, iteration by iteration."""
+    """Rigs of 5-8 cameras factor the reduced camera system along the camera-pair graph (k_solve_nd on the nested-dissection
+    plan of tscm_nd_plan.h; rings are covered by BASELINE config 5 and test_eight_camera_rig), rigs of up to 4 as one dense
+    block (k_solve_reduced).  Chains, stars, two coupled rings and complete graphs (= one dense block) against the oracle's
+    dense Cholesky, and the three code paths against each other -- default, k_solve_nd along the graph
+    (TSCM_EXEC_GRAPH_REDUCED_ORDER: what a rig of up to 4 cameras would not run otherwise), k_solve_nd on the dense order
+    (TSCM_EXEC_DENSE_REDUCED_ORDER): they agree to rounding, iteration by iteration."""
     C, pairs = GRAPHS[name]
     p = H.rig_with_pairs(C, pairs, frames_per_pair=8 if len(pairs) < 20 else 2, seed=50 + C)
     opts = dict(max_num_iterations=12)
     pg, po, gs, os_ = _solve_both(p, **opts)
     _cmp_trace(gs, os_)
     assert max(H.param_rel_err(pg, po).values()) < 1e-6
-    pd = p.copy().normalised()
-    with api.Solver(pd) as s:
-        ds = s.solve(exec_flags=lib.EXEC_DENSE_REDUCED_ORDER, **opts)
-    _cmp_trace(ds, gs, rtol=1e-9)
-    assert max(H.param_rel_err(pd, pg).values()) < 1e-8
+    for flag in (lib.EXEC_GRAPH_REDUCED_ORDER, lib.EXEC_DENSE_REDUCED_ORDER):
+        pd = p.copy().normalised()
+        with api.Solver(pd) as s:
+            ds = s.solve(exec_flags=flag, **opts)
+        _cmp_trace(ds, gs, rtol=1e-9)
+        assert max(H.param_rel_err(pd, pg).values()) < 1e-8
+
+
+def test_ring_of_four_along_the_graph_and_as_a_dense_block(hip_device):
+    """BASELINE config 3 (4-camera ring, 500 views per camera) through k_solve_nd (9 phases along the ring) and through the dense
+    k_solve_reduced (12 panels, the default up to 4 cameras): same trace and parameters to rounding, both equal to the oracle's."""
+    p = synth.make_config(3)
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    pn = p.copy().normalised()
+    with api.Solver(pn) as s:
+        ns = s.solve(exec_flags=lib.EXEC_GRAPH_REDUCED_ORDER)
+    _cmp_trace(ns, gs, rtol=1e-9)
+    assert max(H.param_rel_err(pn, pg).values()) < 1e-8 and max(H.param_rel_err(pn, po).values()) < 1e-6
 
 
 def test_unknown_exec_flags_are_refused(hip_device):

@@ -36,7 +36,7 @@ def test_plan_solves_the_system(checker, C, graph):
             assert r["ok"], r
             assert r["covered"] == r["free_cols"]
             assert r["rel_err"] < 1e-12, r
-            assert r["NP"] <= 32 and r["tiles"] <= 384 and r["lds_bytes"] <= 64 * 1024, r
+            assert r["NP"] <= 32 and r["tiles"] <= 384 and r["lds_bytes"] <= 72 * 1024, r
 
 
 def test_constant_and_inactive_cameras(checker):

@@ -40,7 +40,8 @@ constexpr int kNdTabPhasePanels = 0,                                   // [kNdMa
                                                                        // that phase whose panel updates the diagonal tile lane q factors for the NEXT phase
               kNdTabInts = (kNdTabDmask + kNdSlots * 4 + 3) & ~3;
 // what the kernel needs of the plan before its first memory access: kernel arguments
-struct NdDims { int NP, n_phases, slots, n_lt; };
+struct NdDims { int NP, n_phases, slots, n_lt, bs_rounds; };
+constexpr int kNdBsGroup = 16;         // lanes per panel in the back-substitution (one DPP row): lane 16 q + j takes the j-th tile of slot q's column
 
 struct NdTile { int ri, cj, kind, lt; };       // kind 1: matrix tile (ri >= cj), 2: right-hand side tile (ri = NP); lt: index in the packed factor (-1: none)
 
@@ -55,9 +56,11 @@ struct NdPlan {
     std::vector<unsigned> phase_panels;        // [n_phases]
     std::vector<NdTile> tiles;                 // in thread order: tile i belongs to thread i % kNdTileThreads, unit i / kNdTileThreads
     std::vector<int> tab;                      // [kNdTabInts]
+    int bs_rounds = 1;                         // back-substitution: tiles per panel column / kNdBsGroup, rounded up
+    std::vector<int> bs_tab;                   // [n_phases][bs_rounds][64] lt | row panel << 16 of the tile lane l gathers in that phase, -1: none
     std::vector<int> map;                      // [tpt][kNdUnitInts / 4][kNdThreads] int4
     size_t lds_doubles = 0;
-    NdDims dims() const { return NdDims{ NP, n_phases, max_slots, n_lt }; }
+    NdDims dims() const { return NdDims{ NP, n_phases, max_slots, n_lt, bs_rounds }; }
     int lt_of(int i, int k) const { return rowstart[i] + __builtin_popcount(lmask[i] & ((1u << k) - 1u)); }
     // slot of row panel i's look-ahead lane if tile (i, k) is the one that lane needs raw (i is a panel of the phase after k's), else 0xff
     int dr_slot(int i, int k) const { return i < NP && phase_of[i] == phase_of[k] + 1 ? slot_of[i] : 0xff; }
@@ -208,7 +211,26 @@ inline bool nd_build_plan(int C, const int *ncols, const int *col0, const unsign
     //      look-ahead lanes (diagonal: [2][4][16], below-diagonal raw: [2][4][4][16]), tables, then the solved panel columns
     //      [slots][NP + 1][XT] -- the packed factor takes their place for the back-substitution -----------------------------------
     const size_t xs = (size_t)pl.max_slots * (pl.NP + 1) * kNdXT;
-    pl.lds_doubles = 20 * (size_t)kNdMaxPanels + 4 * 128 + 2 * kNdSlots * 16 + 2 * kNdSlots * kNdSlots * 16 + kNdTabInts / 2 + std::max(xs, 16 * (size_t)pl.n_lt);
+    // ---- back-substitution table: the tiles (i, k), i > k, of every panel column, spread over the 16 lanes of the panel's slot
+    {
+        int most = 1;
+        for (int k = 0; k < pl.NP; ++k) { int cnt = 0; for (int i = k + 1; i < pl.NP; ++i) if ((pl.lmask[i] >> k) & 1u) ++cnt; most = std::max(most, cnt); }
+        pl.bs_rounds = (most + kNdBsGroup - 1) / kNdBsGroup;
+        pl.bs_tab.assign((size_t)pl.n_phases * pl.bs_rounds * 64, -1);
+        for (int t = 0; t < pl.n_phases; ++t)
+            for (int q = 0; q < kNdSlots; ++q) {
+                const int k = (pl.phase_panels[t] >> (8 * q)) & 0xff;
+                if (k == 0xff) continue;
+                int j = 0;
+                for (int i = k + 1; i < pl.NP; ++i) {
+                    if (!((pl.lmask[i] >> k) & 1u)) continue;
+                    pl.bs_tab[((size_t)t * pl.bs_rounds + j / kNdBsGroup) * 64 + kNdBsGroup * q + j % kNdBsGroup] = pl.lt_of(i, k) | (i << 16);
+                    ++j;
+                }
+            }
+    }
+    const size_t bs_doubles = ((size_t)pl.n_phases * pl.bs_rounds * 64 + 1) / 2;
+    pl.lds_doubles = 20 * (size_t)kNdMaxPanels + 4 * 128 + 2 * kNdSlots * 16 + 2 * kNdSlots * kNdSlots * 16 + kNdTabInts / 2 + std::max(xs, 16 * (size_t)pl.n_lt) + bs_doubles;
     // ---- tables ----------------------------------------------------------------------------------------------------------------
     pl.tab.assign(kNdTabInts, -1);
     for (int t = 0; t < kNdMaxPhases; ++t) pl.tab[kNdTabPhasePanels + t] = t < pl.n_phases ? (int)pl.phase_panels[t] : -1;

@@ -35,7 +35,7 @@
 #pragma once
 
 template <int TPT, bool FUSED>
-__global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProblem P, DevState S, const int4 *__restrict__ nd_map, const int *__restrict__ nd_tab, NdDims nd,
+__global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProblem P, DevState S, const int4 *__restrict__ nd_map, const int *__restrict__ nd_tab, const int *__restrict__ nd_bs, NdDims nd,
                                                                        int epoch, int withhold, int n_prod, int n_bs, int with_floats)
 {
     constexpr int NT = kNdThreads, TS = 4, XT = kNdXT, NPD = 128;
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
     double *s_dr = s_dt + 2 * kNdSlots * 16;  // [2][4][4][16] raw tiles (next phase's panel, this phase's panel) for the same lanes
     int *s_tab = reinterpret_cast<int *>(s_dr + 2 * kNdSlots * kNdSlots * 16);
     static_assert(kNdTabInts % 4 == 0, "the tiles behind the tables start on a 16-byte boundary");
-    double *Xs = reinterpret_cast<double *>(s_tab + kNdTabInts);      // [slots][NP + 1][XT] solved panel columns; later the packed factor
+    double *Xs = reinterpret_cast<double *>(s_tab + kNdTabInts);
+    const int xs_doubles = max(nd.slots * (nd.NP + 1) * XT, 16 * nd.n_lt);
+    int *s_bs = reinterpret_cast<int *>(Xs + xs_doubles);                          // [n_phases][bs_rounds][64] the back-substitution's tile table      // [slots][NP + 1][XT] solved panel columns; later the packed factor
     __shared__ int s_fail;
     __shared__ unsigned char s_act[NPD];
     __shared__ double sred[256];
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
             off[u][4 * q] = v.x; off[u][4 * q + 1] = v.y; off[u][4 * q + 2] = v.z; off[u][4 * q + 3] = v.w;
         }
     for (int i = tid; i < kNdTabInts; i += NT) s_tab[i] = nd_tab[i];
+    for (int i = tid; i < nd.n_phases * nd.bs_rounds * 64; i += NT) s_bs[i] = nd_bs[i];
     const int cur = S.ctrl->cur;
     const double radius = S.ctrl->radius;
     const double dmin = S.ctrl->opt.min_lm_diagonal, dmax = S.ctrl->opt.max_lm_diagonal;
@@ -247,8 +250,6 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
     // (0.1-0.15 us each) on every phase's critical path.  The look-ahead lanes hold their update masks as four words.
     const int lane64 = tid & 63;
     const int sp_v = lane64 < kNdMaxPhases ? nd_tab[kNdTabPhasePanels + lane64] : -1;
-    const int lm_v = lane64 <= kNdMaxPanels ? nd_tab[kNdTabLmask + lane64] : 0;
-    const int rs_v = lane64 <= kNdMaxPanels ? nd_tab[kNdTabRowStart + lane64] : 0;
     int dm_w[4] = { 0, 0, 0, 0 };
     if (dlane) {
 #pragma unroll
@@ -288,14 +289,16 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
             double t[TS][TS];
             const int kp = (spn >> (8 * dq)) & 0xff;
             const bool on = dlane && kp != 0xff;
-            if (on) {
+            {
                 const int w8 = ph >> 3;                                          // (wave-uniform selects)
-                const unsigned dmask = ((unsigned)(w8 == 0 ? dm_w[0] : w8 == 1 ? dm_w[1] : w8 == 2 ? dm_w[2] : dm_w[3]) >> (4 * (ph & 7))) & 15u;
-                load_tile(s_dt + (((ph + 1) & 1) * kNdSlots + dq) * 16, t);
-#pragma unroll
-                for (int q = 0; q < kNdSlots; ++q) {
-                    const int k = (sp >> (8 * q)) & 0xff;
-                    if ((dmask >> q) & 1u) {
+                const unsigned dmask = on ? ((unsigned)(w8 == 0 ? dm_w[0] : w8 == 1 ? dm_w[1] : w8 == 2 ? dm_w[2] : dm_w[3]) >> (4 * (ph & 7))) & 15u : 0u;
+                if (on) load_tile(s_dt + (((ph + 1) & 1) * kNdSlots + dq) * 16, t);
+                // (ONE block of code whatever slot a lane's update comes from: a wave executes every block any of its lanes needs,
+                // and four blocks with one lane each were four times the instructions on the phase's critical path)
+                for (unsigned mm = dmask; __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull; mm &= mm - 1u) {
+                    if (mm != 0u) {
+                        const int q = __builtin_ctz(mm);
+                        const int k = (sp >> (8 * q)) & 0xff;
                         PanelFactor f;
                         double araw[TS][TS], x[TS][TS];
                         load_factor(f, k);
@@ -337,20 +340,27 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
                 }
             }
             __syncthreads();                                  // barrier A
-            // step B: trailing updates, then what the next two phases need
+            // step B: trailing updates, then what the next two phases need.  (One block of code per slot; a loop in which every
+            // lane walks its own slots -- as the look-ahead lanes do -- was measured slower here: 24.6 against 23.5 us for the 13
+            // phases of an 8-camera ring, the per-lane addressing costs more than the blocks a wave skips.)
 #pragma unroll
             for (int u = 0; u < TPT; ++u) {
                 Unit &T = U[u];
-                if (!T.kind() || T.phase_c() <= ph) continue;
-                const bool dskip = T.diag() && T.phase_c() == ph + 1;       // (the look-ahead lane takes that one)
+                const bool live = T.kind() && T.phase_c() > ph && !(T.diag() && T.phase_c() == ph + 1);       // (the look-ahead lane takes that one)
+                unsigned mm = 0;
 #pragma unroll
                 for (int q = 0; q < kNdSlots; ++q) {
                     const int k = (sp >> (8 * q)) & 0xff;                   // (wave-uniform)
-                    if (k == 0xff) continue;
-                    if (((T.umask >> (k & 31)) & 1u) && !dskip) {
+                    if (k != 0xff && ((T.umask >> (k & 31)) & 1u)) mm |= 1u << q;
+                }
+                if (!live) mm = 0;
+#pragma unroll
+                for (int q = 0; q < kNdSlots; ++q) {
+                    if ((mm >> q) & 1u) {
+                        const double *base = Xs + q * xs_slot;
                         double xi[TS][TS], xj[TS][TS];
-                        load_tile(Xs + q * xs_slot + T.ri() * XT, xi);
-                        load_tile(Xs + q * xs_slot + T.cj() * XT, xj);
+                        load_tile(base + T.ri() * XT, xi);
+                        load_tile(base + T.cj() * XT, xj);
 #pragma unroll
                         for (int r = 0; r < TS; ++r)
 #pragma unroll
@@ -362,8 +372,10 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
                             }
                     }
                 }
-                if (T.diag() && T.phase_c() == ph + 2) publish_tile(s_dt + (((ph + 2) & 1) * kNdSlots + T.slot_c()) * 16, T.a);
-                if (T.dr() != 0xff && T.phase_c() == ph + 1) publish_tile(s_dr + ((((ph + 1) & 1) * kNdSlots + T.dr()) * kNdSlots + T.slot_c()) * 16, T.a);
+                if (T.kind() && T.phase_c() > ph) {
+                    if (T.diag() && T.phase_c() == ph + 2) publish_tile(s_dt + (((ph + 2) & 1) * kNdSlots + T.slot_c()) * 16, T.a);
+                    if (T.dr() != 0xff && T.phase_c() == ph + 1) publish_tile(s_dr + ((((ph + 1) & 1) * kNdSlots + T.dr()) * kNdSlots + T.slot_c()) * 16, T.a);
+                }
             }
         }
         __syncthreads();                                      // barrier B
@@ -388,65 +400,52 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProbl
     TailOperands tail_ops;
     tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
     if (tid < 64) {
-        // L^T y = w, phases in reverse.  The panels of a phase do not depend on each other: their 4 x 4 upper triangular
-        // systems are solved by every lane redundantly (operands by broadcast), then lane i applies the columns it
-        // has a factor tile for to its two unknowns
-        double w[2];
-        int myp[2], myc[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { const int i = tid + 64 * e; w[e] = i < NP * TS ? wp[i] : 0.0; myp[e] = i >> 2; myc[e] = i & 3; }
+        // L^T y = w, phases in reverse, LEFT-looking: y_k = L_kk^-T (w_k - sum_{i > k} L_ik^T y_i).  The panels of a phase do not
+        // depend on each other; the 16 lanes of a DPP row take the tiles of ONE panel's column (table s_bs, from the plan), one
+        // tile per lane and round: 16 FMAs, a row-wide sum of the four components (DPP butterfly, fixed order), the 4 x 4
+        // upper triangular solve -- about a hundred instructions per phase whatever the number of panels in it.  (The first
+        // version walked the panels one after the other with lane = unknown: six hundred instructions per phase of four
+        // panels on the one wave that runs this, 1.2 us per phase.)  y overwrites w in LDS (one wave: LDS accesses in order).
+        const int lane = tid, q = lane >> 4;
         for (int ph = n_phases - 1; ph >= 0; --ph) {
             const unsigned spb = (unsigned)__builtin_amdgcn_readlane(sp_v, ph);
-            // every LDS operand of the phase is requested before the first use: the diagonal factors (wave-uniform addresses) and
-            // this lane's columns of the factor tiles it has -- none of them depends on the solution so far, so the phase's
-            // dependent chain is v_readlane -> 4 x 4 triangular solve -> four FMAs, with ONE exposed LDS latency in front
-            double ldg[kNdSlots][10], col[kNdSlots][2][TS];
-            bool has[kNdSlots][2];
+            const int k = (spb >> (8 * q)) & 0xff;
+            double acc[TS] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int rd = 0; rd < nd.bs_rounds; ++rd) {
+                const int e = s_bs[(ph * nd.bs_rounds + rd) * 64 + lane];
+                if (e >= 0) {
+                    double lt[TS][TS], y[TS];                       // lt[c][r] = L_ik[r][c]
+                    load_tile(Lt + 16 * (e & 0xffff), lt);
+                    const d2 *yp = reinterpret_cast<const d2 *>(wp + TS * (e >> 16));
+                    const d2 y01 = yp[0], y23 = yp[1];
+                    y[0] = y01[0]; y[1] = y01[1]; y[2] = y23[0]; y[3] = y23[1];
 #pragma unroll
-            for (int q = 0; q < kNdSlots; ++q) {
-                const int k = (spb >> (8 * q)) & 0xff;
-                if (k == 0xff) continue;
+                    for (int c = 0; c < TS; ++c)
+#pragma unroll
+                        for (int r = 0; r < TS; ++r) acc[c] += lt[c][r] * y[r];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < TS; ++c) acc[c] = row16_allsum(acc[c]);
+            if ((lane & 15) == 0 && k != 0xff) {
                 const double *ld = Ld + 20 * k;
-                // (the strictly upper part of L_kk^T, row by row, and 1 / diag)
-                ldg[q][0] = ld[1 * TS + 0]; ldg[q][1] = ld[2 * TS + 0]; ldg[q][2] = ld[2 * TS + 1]; ldg[q][3] = ld[3 * TS + 0]; ldg[q][4] = ld[3 * TS + 1]; ldg[q][5] = ld[3 * TS + 2];
+                double v[TS];
 #pragma unroll
-                for (int c = 0; c < TS; ++c) ldg[q][6 + c] = ld[16 + c];
-                const unsigned lmk = (unsigned)__builtin_amdgcn_readlane(lm_v, k);
-                const int rsk = __builtin_amdgcn_readlane(rs_v, k);
+                for (int c = 0; c < TS; ++c) v[c] = wp[TS * k + c] - acc[c];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    has[q][e] = myp[e] < k && ((lmk >> (myp[e] & 31)) & 1u);
-                    const double *cp = Lt + 16 * (rsk + __popc(lmk & ((1u << (myp[e] & 31)) - 1u))) + 4 * myc[e];
+                for (int c = TS - 1; c >= 0; --c) {
+                    double x = v[c];
 #pragma unroll
-                    for (int r = 0; r < TS; ++r) col[q][e][r] = has[q][e] ? cp[r] : 0.0;
+                    for (int e = c + 1; e < TS; ++e) x -= ld[e * TS + c] * v[e];
+                    v[c] = x * ld[16 + c];
                 }
+#pragma unroll
+                for (int c = 0; c < TS; ++c) wp[TS * k + c] = v[c];
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < kNdSlots; ++q) {
-                const int k = (spb >> (8 * q)) & 0xff;
-                if (k == 0xff) continue;
-                // (w of the panel's four unknowns: v_readlane with a wave-uniform lane -- not the LDS crossbar)
-                double y[TS];
-#pragma unroll
-                for (int c = 0; c < TS; ++c) {
-                    const int i = k * TS + c;
-                    const double src = (i >> 6) ? w[1] : w[0];
-                    y[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(src), i & 63), __builtin_amdgcn_readlane(__double2loint(src), i & 63));
-                }
-                y[3] = y[3] * ldg[q][9];
-                y[2] = (y[2] - ldg[q][5] * y[3]) * ldg[q][8];
-                y[1] = (y[1] - ldg[q][2] * y[2] - ldg[q][4] * y[3]) * ldg[q][7];
-                y[0] = (y[0] - ldg[q][0] * y[1] - ldg[q][1] * y[2] - ldg[q][3] * y[3]) * ldg[q][6];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (myp[e] == k) w[e] = myc[e] == 0 ? y[0] : myc[e] == 1 ? y[1] : myc[e] == 2 ? y[2] : y[3];
-                    else if (has[q][e]) w[e] -= col[q][e][0] * y[0] + col[q][e][1] * y[1] + col[q][e][2] * y[2] + col[q][e][3] * y[3];
-                }
-            }
+            wave_lds_fence();
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) { const int i = tid + 64 * e; const int pi = i < NP * TS ? s_tab[kNdTabPcol + i] : -1; if (pi >= 0) yv[pi] = w[e]; }    // back to padded columns
+        for (int e = 0; e < 2; ++e) { const int i = tid + 64 * e; const int pi = i < NP * TS ? s_tab[kNdTabPcol + i] : -1; if (pi >= 0) yv[pi] = wp[i]; }    // back to padded columns
     }
     __syncthreads();
     PHASE_STAMP(ts3);

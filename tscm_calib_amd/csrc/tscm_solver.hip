@@ -104,7 +104,7 @@ struct tscm_solver {
     // that are resident at once (occupancy x CUs)
     NdPlan plan[2];
     const int4 *d_nd_map[2] = { nullptr, nullptr };
-    const int *d_nd_tab[2] = { nullptr, nullptr };
+    const int *d_nd_tab[2] = { nullptr, nullptr }, *d_nd_bs[2] = { nullptr, nullptr };
     size_t lds_nd[2] = { 0, 0 }, lds_dense4 = 0;
     int nd_resident[2] = { 0, 0 };
     int nd = 0;                         // this solve: which of the two
@@ -695,10 +695,17 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
             }
             s->d_nd_map[v] = map;
             if ((rc = dev_upload(s, &s->d_nd_tab[v], pl.tab))) return rc;
+            if ((rc = dev_upload(s, &s->d_nd_bs[v], pl.bs_tab))) return rc;
             s->lds_nd[v] = sizeof(double) * pl.lds_doubles;
             // workgroups of the fused launch that are resident at once: the back-substitution workgroups that ride in it WAIT
             // for the solver workgroup, so only as many are put there as fit the chip next to it (and the T producers)
             const size_t lds = std::max(s->lds_nd[v], s->lds_bs);
+            if (lds > 64 * 1024) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
             int per_cu = 0;
             if (pl.tpt == 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<1, true>), kNdThreads, lds));
             else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<2, true>), kNdThreads, lds));
@@ -986,11 +993,11 @@ static int enqueue_iteration(LmRun &run)
             if (n_prod || n_bs) {
                 const size_t lds = std::max(s->lds_nd[v], n_bs ? s->lds_bs : (size_t)0);
                 const dim3 grid(1 + n_prod + n_bs);
-                if (two) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
-                else hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                if (two) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                else hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
             } else {
-                if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
-                else hipLaunchKernelGGL((k_solve_nd<1, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
+                if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
+                else hipLaunchKernelGGL((k_solve_nd<1, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
             }
             const int rest = S.n_bs_blocks - n_bs;
             if (rest > 0 && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(rest), dim3(128), s->lds_bs, s->stream, P, S, wf, n_bs);
