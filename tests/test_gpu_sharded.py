@@ -172,6 +172,33 @@ def test_sharded_config3_vs_oracle(hip_device):
     assert abs(sums[0]["rmse"] - orc.rmse(po)) <= 1e-6 * orc.rmse(po)
 
 
+def test_config4_on_eight_local_shards_is_the_unsharded_solve(hip_device):
+    """BASELINE config 4 at FULL size (2.16 M corners) on 8 in-process shards -- north_star's multi-GPU configuration -- against
+    the unsharded HIP solve, which tests/test_gpu_parity.py::test_lm_multi_config4_vs_oracle pins to the oracle: same
+    trace, decisions and termination, parameters to 1e-8 (the sums are associated per shard)."""
+    p = synth.make_config(4)
+    q1, s1 = _solve_unsharded(p)
+    q2, sums = _solve_group(p, 8)
+    _ranks_agree(sums)
+    _same_run(sums[0], s1)
+    assert max(H.param_rel_err(q2, q1).values()) < 1e-8
+    assert abs(sums[0]["rmse"] - s1["rmse"]) <= 1e-10 * s1["rmse"]
+
+
+def test_config5_on_two_local_shards_is_the_unsharded_solve(hip_device):
+    """BASELINE config 5 at FULL size (8 cameras, 8.64 M corners) on 2 in-process shards against the unsharded HIP solve (pinned to
+    the oracle by test_lm_multi_config5_vs_oracle): the communicator path of an 8-camera rig -- k_solve_nd without T
+    producers, the back-substitution split between the solve's launch and a trailing one, the control step in the Schur
+    kernel's head on the all-reduced tiles with a grid of several rounds."""
+    p = synth.make_config(5)
+    q1, s1 = _solve_unsharded(p)
+    q2, sums = _solve_group(p, 2)
+    _ranks_agree(sums)
+    _same_run(sums[0], s1)
+    assert max(H.param_rel_err(q2, q1).values()) < 1e-8
+    assert abs(sums[0]["rmse"] - s1["rmse"]) <= 1e-10 * s1["rmse"]
+
+
 def test_group_api_misuse_is_refused(hip_device):
     from tscm_calib_amd.lib import TscmError
     p = H.small_rig(4, 6, seed=1).normalised()
