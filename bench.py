@@ -351,6 +351,9 @@ def main():
         import ctypes
         pk = (ctypes.c_double * 3)()
         lib.check(lib.lib().tscm_device_peak_fp64_ex(local_rank, pk))
+        pk32 = ctypes.c_double(0.0)
+        if args.jacobian_fp32:
+            lib.check(lib.lib().tscm_device_peak_fp32_mfma(local_rank, ctypes.byref(pk32)))
     # natural solve (reference options, termination tests on): untimed, doubles as warmup
     extra = dict(jacobian_fp32=1) if args.jacobian_fp32 else {}
     if args.exec_flags:
@@ -404,6 +407,14 @@ def main():
             "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
             "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
         }
+        if not stub and args.jacobian_fp32:
+            # fp32-Jacobian tier: the contraction (836 flop per corner) runs on v_mfma_f32_16x16x4, the projection and
+            # residual in fp64 and the derivatives in packed fp32 on the VALU.  `peak` above is the fp32 datasheet figure
+            # (what BASELINE's "fp64 vs fp32" asks to see); the floor prices the 600 VALU flop at the measured fp64 VALU
+            # rate (an upper bound of their cost: part of them is fp32) and the contraction at the measured fp32 MFMA rate
+            floor_ms = 1e3 * n_local * (FLOP_MFMA_PER_CORNER / (pk32.value * 1e12) + FLOP_VALU_PER_CORNER / (pk[2] * 1e12))
+            roof.update(peak_measured_mfma_f32_16x16x4=pk32.value, peak_measured_valu_f64=pk[2], measured_floor_ms=floor_ms,
+                        frac_of_measured_ceiling=floor_ms / avg_ms if avg_ms > 0 else 0.0)
         if not stub and not args.jacobian_fp32:
             # measured ceilings of THIS device (taken before the warmup).  fp64 MFMA and fp64 VALU share the DP pipe
             # (no overlap: tools/ubench_fp64.hip), so the kernel's floor is the SUM of its two parts at their own rates

@@ -179,6 +179,8 @@ int tscm_device_peak_fp64(int device, double *mfma_tflops, double *valu_tflops);
  * half the datasheet rate on gfx950), peaks[1] = v_mfma_f64_4x4x4_4b_f64 (the one the dominant kernel uses since round 3:
  * the datasheet rate), peaks[2] = v_fma_f64; TFLOP/s. */
 int tscm_device_peak_fp64_ex(int device, double peaks[3]);
+/* ... and of v_mfma_f32_16x16x4_f32, the contraction of the fp32-Jacobian tier (tscm_options.jacobian_fp32), TFLOP/s */
+int tscm_device_peak_fp32_mfma(int device, double *tflops);
 
 void tscm_default_options(tscm_options *opt, int mono);
 

@@ -535,6 +535,28 @@ def test_every_fusion_switched_off_gives_the_same_bits(hip_device):
         assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+def test_fusions_of_an_eight_camera_rig_give_the_same_bits(hip_device):
+    """Round 4 lifted the one-GPU fusions from 4 to 8 cameras: T producers and back-substitution workgroups ride in k_solve_nd's
+    launch (only as many as are resident next to the solver workgroup; the others follow in a launch of their own) and the
+    control step is taken in k_schur_gram's head.  Each switched off on its own and all together: same log, same bits, over
+    25 forced iterations of an 8-camera ring (600 views per camera: 2,400 boards = 75 groups of 32) and the natural solve."""
+    forced = dict(max_num_iterations=25, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
+                  min_trust_region_radius=0.0)
+    p = synth.make_problem(8, 600, 81)
+    for opts in (dict(), forced):
+        ref = None
+        for flags in (0, lib.EXEC_SEPARATE_T_REDUCE, lib.EXEC_SEPARATE_BACKSUB, lib.EXEC_SEPARATE_CONTROL,
+                      lib.EXEC_SEPARATE_T_REDUCE | lib.EXEC_SEPARATE_BACKSUB | lib.EXEC_SEPARATE_CONTROL):
+            q = p.copy().normalised()
+            with api.Solver(q) as s:
+                r = s.solve(exec_flags=flags, **opts)
+            cur = (r["iterations"], r["final_cost"], q.intr.tobytes(), q.cam_rt.tobytes(), q.board_rt.tobytes())
+            if ref is None:
+                ref = cur
+            assert cur[0] == ref[0] and cur[1] == ref[1], flags
+            assert cur[2:] == ref[2:], flags
+
+
 def test_repeated_solves_are_the_same_bits_every_time(hip_device):
     """The hand-offs inside the launches (T tiles -> reduced solve, camera step -> waiting back-substitution workgroups)
     order data by completion, not by fences: a lost ordering would show as a solve that differs from the others.  100

@@ -34,8 +34,14 @@
 // grid (1 + n_prod + n_bs) x 256, dynamic LDS NdPlan::lds_doubles (solver) / BsGeom<256>::kLds (back-substitution)
 #pragma once
 
+// workgroups of the fused launch per CU: 2.  At 3 the two-tiles-per-thread variant spills ten doubles inside the phase loop, and
+// config 5 runs 364.5 us per iteration (130.7 us per rank on 8 shards, all back-substitution groups riding) against 359.9 (126.3,
+// none riding) at 2 -- measured in one call, tools/r04_ab_libs.sh
+#ifndef TSCM_ND_WGS_PER_CU
+#define TSCM_ND_WGS_PER_CU 2
+#endif
 template <int TPT, bool FUSED>
-__global__ __launch_bounds__(kNdThreads, FUSED ? 2 : 1) void k_solve_nd(DevProblem P, DevState S, const int4 *__restrict__ nd_map, const int *__restrict__ nd_tab, const int *__restrict__ nd_bs, NdDims nd,
+__global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_solve_nd(DevProblem P, DevState S, const int4 *__restrict__ nd_map, const int *__restrict__ nd_tab, const int *__restrict__ nd_bs, NdDims nd,
                                                                        int epoch, int withhold, int n_prod, int n_bs, int with_floats)
 {
     constexpr int NT = kNdThreads, TS = 4, XT = kNdXT, NPD = 128;

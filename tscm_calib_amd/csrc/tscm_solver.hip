@@ -971,7 +971,7 @@ static int enqueue_iteration(LmRun &run)
         if (s->solve_variant == 0 && !s->graph_order) {
             // up to 4 cameras, one dense block: the same launch shape with k_solve_reduced as the solver workgroup
             const int n_prod = fused_reduce(s) ? P.n_bids * (256 / kFusedEntries) : 0;
-            const int n_bs = s->fuse_backsub && s->bs_threads == 256 ? std::max(0, std::min(S.n_bs_blocks, s->dense4_resident - 1 - n_prod)) : 0;
+            const int n_bs = s->fuse_backsub && s->bs_threads == 256 && S.n_bs_blocks <= s->dense4_resident - 1 - n_prod ? S.n_bs_blocks : 0;       // all of them, or none: see below
             if (n_prod || n_bs)
                 hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
                                    P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
@@ -983,12 +983,14 @@ static int enqueue_iteration(LmRun &run)
         }
         if (s->solve_variant <= 1) {
             // 5 to 8 cameras (and TSCM_EXEC_GRAPH_REDUCED_ORDER): T reduction (one GPU), reduced solve and -- unless TSCM_EXEC_SEPARATE_BACKSUB -- the back-substitution
-            // workgroups, which wait for the camera step with their operands loaded, in ONE launch.  Only as many of them as
-            // are resident next to the solver workgroup and the producers ride there (a waiting workgroup that keeps the
-            // solver off the chip would wait for ever): the others follow in a launch of their own
+            // workgroups, which wait for the camera step with their operands loaded, in ONE launch -- if ALL of them are
+            // resident next to the solver workgroup and the producers (occupancy x CUs: a waiting workgroup that keeps the
+            // solver off the chip would wait for ever); otherwise the back-substitution is a launch of its own.  Splitting
+            // it between the two was measured and lost: at config 5 (5,000 groups, 255 of them riding) 364.3 against 356.7 us
+            // per iteration -- the riders share the solver workgroup's CU and the rest needs its launch anyway
             const int v = s->nd;
             const int n_prod = fused_reduce(s) ? P.n_bids * (256 / kFusedEntries) : 0;
-            const int n_bs = s->fuse_backsub && s->bs_threads == 256 ? std::max(0, std::min(S.n_bs_blocks, s->nd_resident[v] - 1 - n_prod)) : 0;
+            const int n_bs = s->fuse_backsub && s->bs_threads == 256 && S.n_bs_blocks <= s->nd_resident[v] - 1 - n_prod ? S.n_bs_blocks : 0;
             const bool two = s->plan[v].tpt == 2;
             if (n_prod || n_bs) {
                 const size_t lds = std::max(s->lds_nd[v], n_bs ? s->lds_bs : (size_t)0);

@@ -68,6 +68,24 @@ __global__ __launch_bounds__(256) void k_peak_mfma4(double *out, int iters, doub
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// four independent fp32 accumulator tiles per wave: v_mfma_f32_16x16x4_f32, the instruction k_eval_gram_f32 contracts with
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_peak_mfma_f32(double *out, int iters, float seed)
+{
+    f4v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f4v{ seed, 0.f, 0.f, 0.f };
+    const float a = 1.f + threadIdx.x * 1e-6f, b = 1.f - threadIdx.x * 1e-6f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 bool time_launches(F launch, int reps, double *ms_per_launch)
 {
@@ -104,6 +122,27 @@ extern "C" int tscm_device_peak_fp64_ex(int device, double peaks[3])
     (void)hipFree(out);
     if (!ok || ms <= 0.0) return tscm_set_error(TSCM_E_HIP, "fp64 peak measurement failed");
     peaks[1] = 512.0 * 8.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;       // 4 blocks x 4x4x4x2 flop per instruction, 8 per wave and iteration, 4 waves
+    return 0;
+}
+
+// v_mfma_f32_16x16x4_f32 with every CU busy, TFLOP/s: the ceiling of the contraction of the fp32-Jacobian tier
+extern "C" int tscm_device_peak_fp32_mfma(int device, double *tflops)
+{
+    if (!tflops) return tscm_set_error(TSCM_E_INVALID, "NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return tscm_set_error(TSCM_E_NO_DEVICE, "no usable HIP device");
+    if (hipSetDevice(device) != hipSuccess) return tscm_set_error(TSCM_E_NO_DEVICE, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return tscm_set_error(TSCM_E_HIP, "hipGetDeviceProperties failed");
+    const int blocks = prop.multiProcessorCount * 8;
+    double *out = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&out), sizeof(double) * 256 * (size_t)blocks) != hipSuccess) return tscm_set_error(TSCM_E_NOMEM, "hipMalloc failed");
+    const int iters = 8000, reps = 5;
+    double ms = 0.0;
+    const bool ok = time_launches([&] { hipLaunchKernelGGL(k_peak_mfma_f32, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f); }, reps, &ms);
+    (void)hipFree(out);
+    if (!ok || ms <= 0.0) return tscm_set_error(TSCM_E_HIP, "fp32 MFMA peak measurement failed");
+    *tflops = 2048.0 * 4.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;       // 16x16x4x2 flop per instruction, 4 per wave and iteration, 4 waves
     return 0;
 }
 

@@ -111,7 +111,7 @@ class CCornerSet(C.Structure):
 
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
-    "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_device_peak_fp64_ex", "tscm_default_options",
+    "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_device_peak_fp64_ex", "tscm_device_peak_fp32_mfma", "tscm_default_options",
     "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
     "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
@@ -154,6 +154,7 @@ def lib():
     L.tscm_device_synchronize.argtypes = [C.c_int]
     L.tscm_device_peak_fp64.argtypes = [C.c_int, dp, dp]
     L.tscm_device_peak_fp64_ex.argtypes = [C.c_int, dp]
+    L.tscm_device_peak_fp32_mfma.argtypes = [C.c_int, dp]
     L.tscm_default_options.argtypes = [C.POINTER(COptions), C.c_int]
     L.tscm_default_options.restype = None
     L.tscm_solver_create.argtypes = [C.POINTER(CProblem), C.c_int, C.POINTER(vp)]
