@@ -737,10 +737,11 @@ def test_chunks_longer_than_one_metadata_block(hip_device):
 
 
 def test_more_backsub_workgroups_than_the_chip_holds(hip_device):
-    """The back-substitution workgroups that ride in the reduced solve's launch WAIT for the solver workgroup: only as many
-    as are resident next to it are put there (occupancy x CUs), the others follow in a launch of their own.  4 cameras x
-    20,000 views = 40,000 boards = 1,250 groups of 32 against 768 resident workgroups: 25 forced iterations agree bit for
-    bit with the path that keeps the whole back-substitution a launch of its own."""
+    """The back-substitution workgroups that ride in the reduced solve's launch WAIT for the solver workgroup, so they ride
+    there only if ALL of them are resident next to it (occupancy x CUs, queried at create); otherwise the back-substitution
+    is a launch of its own.  4 cameras x 20,000 views = 40,000 boards = 1,250 groups of 32 against 768 resident
+    workgroups: the solve must neither hang nor fault (0.5 s hand-off bound) over 25 forced iterations, and agrees bit
+    for bit with the path that was told to keep the back-substitution separate."""
     p = synth.make_problem(4, 20000, 77)
     opts = dict(max_num_iterations=25, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0, min_trust_region_radius=0.0, check_every=25)
     pa, pb = p.copy().normalised(), p.copy().normalised()

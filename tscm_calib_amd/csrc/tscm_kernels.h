@@ -2218,7 +2218,7 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
     // the candidate's per-camera records (rotation, left-Jacobian vectors, intrinsics: write_camera_record): one camera
     // per workgroup, by the first lane of the second wave while the loads requested above are in flight -- a serial
     // chain of a few hundred operations that cost workgroup 0 4.6 us when it did all cameras after its board solves
-    if constexpr (!WAIT) { if (t == 64 && nblk > 0) for (int m = blk; m < P.C; m += nblk) write_camera_record(S, cur ^ 1, m); }
+    if constexpr (!WAIT) { if (t == 64) for (int m = blk; m < P.C; m += nblk) write_camera_record(S, cur ^ 1, m); }
     // ---- phase A -----------------------------------------------------------------------------------------------------
     {
         const int grp = t >> 4, a = t & 15;
@@ -2400,13 +2400,11 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
 #endif
 }
 
-// blk0: first group of this launch -- 0, or the number of groups that rode in the reduced solve's launch (the solver
-// workgroup of that launch has written the candidate's camera records then: nblk = 0 switches the writing off here)
 template <int NTH>
-__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats, int blk0)
+__global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, int with_floats)
 {
     KTL(5);
-    backsub_body<NTH, false>(P, S, with_floats, blk0 + (int)blockIdx.x, blk0 ? 0 : (int)gridDim.x, 0, 0);
+    backsub_body<NTH, false>(P, S, with_floats, (int)blockIdx.x, (int)gridDim.x, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -976,9 +976,8 @@ static int enqueue_iteration(LmRun &run)
                 hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
                                    P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
             else hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_dense4, s->stream, P, S, 0, 0, 0, 0, 0);
-            const int rest = S.n_bs_blocks - n_bs;
-            if (rest > 0 && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(rest), dim3(128), s->lds_bs, s->stream, P, S, wf, n_bs);
-            if (rest > 0 && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(rest), dim3(256), s->lds_bs, s->stream, P, S, wf, n_bs);
+            if (!n_bs && S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf);
+            if (!n_bs && S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf);
             continue;
         }
         if (s->solve_variant <= 1) {
@@ -1001,14 +1000,13 @@ static int enqueue_iteration(LmRun &run)
                 if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
                 else hipLaunchKernelGGL((k_solve_nd<1, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
             }
-            const int rest = S.n_bs_blocks - n_bs;
-            if (rest > 0 && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(rest), dim3(128), s->lds_bs, s->stream, P, S, wf, n_bs);
-            if (rest > 0 && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(rest), dim3(256), s->lds_bs, s->stream, P, S, wf, n_bs);
+            if (!n_bs && S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf);
+            if (!n_bs && S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf);
             continue;
         }
         hipLaunchKernelGGL(k_solve_reduced_big, dim3(1), dim3(kBigNT), s->lds_solve, s->stream, P, S);
-        if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf, 0);
-        if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf, 0);
+        if (S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf);
+        if (S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf);
     }
     return enqueue_eval(run, /*cand=*/1, /*init=*/0, /*have_backsub=*/1);
 }
