@@ -190,7 +190,9 @@ inline bool nd_build_plan(int C, const int *ncols, const int *col0, const unsign
     pl.rowstart.assign(pl.NP + 1, 0);
     for (int p = 0; p < pl.NP; ++p) pl.rowstart[p + 1] = pl.rowstart[p] + popc(pl.lmask[p]);
     pl.n_lt = pl.rowstart[pl.NP];
-    // ---- tiles, in the order their column panel is eliminated (waves retire early) ---------------------------------------------
+    // ---- tiles, in the order their column panel is eliminated (waves retire early).  Grouping them by the level and camera of their
+    //      column instead -- so that the lanes of a wave take their updates from few slots -- was measured at config 5 and is no
+    //      better (358.9-364.9 against 357.7 us per iteration) ---------------------------------------------------------------------
     std::vector<NdTile> tiles;
     for (int p = 0; p < pl.NP; ++p) {
         tiles.push_back({ p, p, 1, -1 });
@@ -230,7 +232,7 @@ inline bool nd_build_plan(int C, const int *ncols, const int *col0, const unsign
             }
     }
     const size_t bs_doubles = ((size_t)pl.n_phases * pl.bs_rounds * 64 + 1) / 2;
-    pl.lds_doubles = 20 * (size_t)kNdMaxPanels + 4 * 128 + 2 * kNdSlots * 16 + 2 * kNdSlots * kNdSlots * 16 + kNdTabInts / 2 + std::max(xs, 16 * (size_t)pl.n_lt) + bs_doubles;
+    pl.lds_doubles = 20 * (size_t)kNdMaxPanels + 4 * 128 + 2 * kNdSlots * 16 + 2 * kNdSlots * kNdSlots * 16 + kNdTabInts / 2 + std::max(xs, kNdXT * (size_t)pl.n_lt) + bs_doubles;
     // ---- tables ----------------------------------------------------------------------------------------------------------------
     pl.tab.assign(kNdTabInts, -1);
     for (int t = 0; t < kNdMaxPhases; ++t) pl.tab[kNdTabPhasePanels + t] = t < pl.n_phases ? (int)pl.phase_panels[t] : -1;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     int *s_tab = reinterpret_cast<int *>(s_dr + 2 * kNdSlots * kNdSlots * 16);
     static_assert(kNdTabInts % 4 == 0, "the tiles behind the tables start on a 16-byte boundary");
     double *Xs = reinterpret_cast<double *>(s_tab + kNdTabInts);
-    const int xs_doubles = max(nd.slots * (nd.NP + 1) * XT, 16 * nd.n_lt);
+    const int xs_doubles = max(nd.slots * (nd.NP + 1) * XT, XT * nd.n_lt);
     int *s_bs = reinterpret_cast<int *>(Xs + xs_doubles);                          // [n_phases][bs_rounds][64] the back-substitution's tile table      // [slots][NP + 1][XT] solved panel columns; later the packed factor
     __shared__ int s_fail;
     __shared__ unsigned char s_act[NPD];
@@ -393,6 +393,8 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     PHASE_STAMP(ts2);
     // ---- the packed factor (row-major by (row panel, column panel), tiles transposed: a lane of the back-substitution reads one
     //      COLUMN of a tile) -------------------------------------------------------------------------------------------------------
+    // (tile pitch XT = 18 doubles, like the panel columns: at a pitch of 16 doubles = 32 banks the 16 lanes of a row that gather a
+    // panel's column in the back-substitution hit two bank groups -- a 32-way conflict on every ds_read_b128, 0.6 us per phase)
     double *Lt = Xs;
 #pragma unroll
     for (int u = 0; u < TPT; ++u)
@@ -400,9 +402,13 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
 #pragma unroll
             for (int r = 0; r < TS; ++r)
 #pragma unroll
-                for (int c = 0; c < TS; ++c) Lt[16 * U[u].lt + 4 * c + r] = U[u].a[r][c];
+                for (int c = 0; c < TS; ++c) Lt[XT * U[u].lt + 4 * c + r] = U[u].a[r][c];
         }
     __syncthreads();
+    PHASE_STAMP(ts2b);
+#ifdef TSCM_PHASE_PROFILE
+    __shared__ long long s_bst[kNdMaxPhases + 2];
+#endif
     TailOperands tail_ops;
     tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
     if (tid < 64) {
@@ -413,6 +419,73 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
         // version walked the panels one after the other with lane = unknown: six hundred instructions per phase of four
         // panels on the one wave that runs this, 1.2 us per phase.)  y overwrites w in LDS (one wave: LDS accesses in order).
         const int lane = tid, q = lane >> 4;
+        if (nd.bs_rounds == 1) {
+            // one tile per lane and phase (every plan but the dense one of 7-8 cameras).  What does NOT depend on the solution so far
+            // -- the phase's table entry, this lane's factor tile, the diagonal factor its group's leader solves with -- is
+            // requested one phase AHEAD: a phase's dependent chain is then the load of y_i, 16 FMAs, the row sum, the 4 x 4 solve
+            // and the store of y_k (one LDS round trip instead of four)
+            int e_n = s_bs[(n_phases - 1) * 64 + lane];
+            double lt_n[TS][TS], ld_n[10];
+            unsigned sp_n = (unsigned)__builtin_amdgcn_readlane(sp_v, n_phases - 1);
+            auto prefetch = [&](int e, unsigned spb) {
+                load_tile(Lt + XT * (max(e, 0) & 0xffff), lt_n);
+                const int k = (spb >> (8 * q)) & 0xff;
+                const double *ld = Ld + 20 * (k == 0xff ? 0 : k);
+                ld_n[0] = ld[1 * TS + 0]; ld_n[1] = ld[2 * TS + 0]; ld_n[2] = ld[2 * TS + 1]; ld_n[3] = ld[3 * TS + 0]; ld_n[4] = ld[3 * TS + 1]; ld_n[5] = ld[3 * TS + 2];
+#pragma unroll
+                for (int c = 0; c < TS; ++c) ld_n[6 + c] = ld[16 + c];
+            };
+            prefetch(e_n, sp_n);
+#ifdef TSCM_PHASE_PROFILE
+            if (tid == 0) s_bst[n_phases] = wall_clock64();
+#endif
+            for (int ph = n_phases - 1; ph >= 0; --ph) {
+                const int e = e_n;
+                const unsigned spb = sp_n;
+                double lt[TS][TS], ldg[10];
+#pragma unroll
+                for (int c = 0; c < TS; ++c)
+#pragma unroll
+                    for (int r = 0; r < TS; ++r) lt[c][r] = lt_n[c][r];
+#pragma unroll
+                for (int c = 0; c < 10; ++c) ldg[c] = ld_n[c];
+                if (ph > 0) {
+                    e_n = s_bs[(ph - 1) * 64 + lane];
+                    sp_n = (unsigned)__builtin_amdgcn_readlane(sp_v, ph - 1);
+                    prefetch(e_n, sp_n);
+                }
+                const int k = (spb >> (8 * q)) & 0xff;
+                double acc[TS] = { 0.0, 0.0, 0.0, 0.0 };
+                if (e >= 0) {
+                    const d2 *yp = reinterpret_cast<const d2 *>(wp + TS * (e >> 16));
+                    const d2 y01 = yp[0], y23 = yp[1];
+                    const double y[TS] = { y01[0], y01[1], y23[0], y23[1] };
+#pragma unroll
+                    for (int c = 0; c < TS; ++c)
+#pragma unroll
+                        for (int r = 0; r < TS; ++r) acc[c] += lt[c][r] * y[r];
+                }
+#pragma unroll
+                for (int c = 0; c < TS; ++c) acc[c] = row16_allsum(acc[c]);
+                if ((lane & 15) == 0 && k != 0xff) {
+                    double v[TS];
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) v[c] = wp[TS * k + c] - acc[c];
+                    v[3] = v[3] * ldg[9];
+                    v[2] = (v[2] - ldg[5] * v[3]) * ldg[8];
+                    v[1] = (v[1] - ldg[2] * v[2] - ldg[4] * v[3]) * ldg[7];
+                    v[0] = (v[0] - ldg[0] * v[1] - ldg[1] * v[2] - ldg[3] * v[3]) * ldg[6];
+#pragma unroll
+                    for (int c = 0; c < TS; ++c) wp[TS * k + c] = v[c];
+                }
+                // (y_k is read by other lanes of THIS wave in the next phase: LDS operations of a wave are served in order, only
+                // the compiler must not move them -- a fence here would also wait for the tail's global prefetch, 2-3 us)
+                asm volatile("" ::: "memory");
+#ifdef TSCM_PHASE_PROFILE
+                if (tid == 0) s_bst[ph] = wall_clock64();
+#endif
+            }
+        } else
         for (int ph = n_phases - 1; ph >= 0; --ph) {
             const unsigned spb = (unsigned)__builtin_amdgcn_readlane(sp_v, ph);
             const int k = (spb >> (8 * q)) & 0xff;
@@ -421,7 +494,7 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
                 const int e = s_bs[(ph * nd.bs_rounds + rd) * 64 + lane];
                 if (e >= 0) {
                     double lt[TS][TS], y[TS];                       // lt[c][r] = L_ik[r][c]
-                    load_tile(Lt + 16 * (e & 0xffff), lt);
+                    load_tile(Lt + XT * (e & 0xffff), lt);
                     const d2 *yp = reinterpret_cast<const d2 *>(wp + TS * (e >> 16));
                     const d2 y01 = yp[0], y23 = yp[1];
                     y[0] = y01[0]; y[1] = y01[1]; y[2] = y23[0]; y[3] = y23[1];
@@ -460,6 +533,9 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     if (tid == 0) {
         printf("solve_nd: ctrl %lld  T wait %lld  operands %lld  to first phase %lld  factor %lld (%d phases)  backsub %lld  tail %lld [10 ns]\n", tsA - ts0, tsB - tsA, ts1 - tsB, s_pht[0] - ts1, ts2 - s_pht[0], n_phases, ts3 - ts2, wall_clock64() - ts3);
         for (int ph = 0; ph < n_phases; ++ph) printf("  phase %d: %lld\n", ph, s_pht[ph + 1] - s_pht[ph]);
+        printf("  backsub: factor store + barrier %lld, to loop %lld, phases (last first):", ts2b - ts2, s_bst[n_phases] - ts2b);
+        for (int ph = n_phases - 1; ph >= 0; --ph) printf(" %lld", s_bst[ph] - s_bst[ph + 1]);
+        printf("\n");
     }
 #endif
 }
