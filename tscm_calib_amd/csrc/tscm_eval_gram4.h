@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
 {
     KTL(0);
 #ifdef TSCM_ABLATE
-    constexpr int ablate = TSCM_ABLATE;      // profiling builds only (make ABLATE=n): 1 no MFMA phases, 2 no epilogue, 4 no geometry
+    constexpr int ablate = TSCM_ABLATE;      // profiling builds only (make ABLATE=n): 1 no MFMA phases, 2 no epilogue, 4 no geometry, 8 one constant record per chunk
 #else
     constexpr int ablate = 0;
 #endif
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));      // priority by progress: see k_eval_gram
 #endif
         TL_STAMP(ts0);
-        const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);
+        const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * ((ablate & 8) ? vb : view));      // (ablate 8: every view reads the chunk's first constant record: scalar-cache hits)
         auto VC = [&](int k) { return vcs[k]; };
         const bool valid = lane < cnt;
         double fv[16];                          // v-rows wait in registers until the u-rows have been consumed (index = tile column)
