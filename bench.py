@@ -24,7 +24,9 @@ all-reduces per iteration.  The ranks are either started by `python -m torch.dis
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or by this script itself: `python bench.py --gpus N`
 without WORLD_SIZE spawns N fresh child processes BEFORE anything touches the GPU.  No torch in any of them: the
 ncclUniqueId, the barriers and the max-over-ranks travel over a TCP side channel (tscm_calib_amd/rendezvous.py), so
-the only HIP runtime and RCCL in the process are the ones libtscm_hip.so links.
+the only HIP runtime and RCCL in the process are the ones libtscm_hip.so links.  (Under a launcher whose ranks do NOT share a
+parent process -- a wrapper shell per rank, several nodes -- set TSCM_RDZV_NONCE to one value for all ranks of the launch: without it the
+side channel's handshake token contains the parent's process id, which keeps stale ranks of an earlier launch out.)
 
 Before anything is timed (all of it untimed, none of it skipping work inside the timed region): the device's fp64
 ceilings are measured (three dense kernels, ~70 ms: they are part of the roofline block anyway and leave the device

@@ -28,7 +28,8 @@ constexpr int kNdTileThreads = 192;
 constexpr int kNdSlots = 4;            // panels per phase at most (cameras per level)
 constexpr int kNdMaxPanels = 32;       // 8 cameras x 4 panels
 constexpr int kNdMaxPhases = 32;       // one panel per phase at least
-constexpr int kNdUnitInts = 44;        // per thread and tile: 16 offsets into H, 16 into T, 4 + 4 scaling indices, 4 meta words
+constexpr int kNdUnitInts = 48;        // per thread and tile: 16 offsets into H, 16 into T, 4 + 4 scaling indices, 4 meta words, 4 words of update masks
+                                       // (phases 8 w .. 8 w + 7 in word w, four bits each: the slots of that phase whose panel updates the tile)
 constexpr int kNdMapOne = 1 << 30;     // "scaling 1": the row of a right-hand side tile
 constexpr int kNdXT = 18;              // doubles per published tile (16 + 2: 16 lanes read 16 tiles on distinct bank pairs)
 // table block (ints) read by every thread at the head of the kernel
@@ -261,6 +262,7 @@ inline bool nd_build_plan(int C, const int *ncols, const int *col0, const unsign
             int off[kNdUnitInts];
             for (int q = 0; q < kNdUnitInts; ++q) off[q] = -1;
             off[40] = 0xff << 24; off[41] = 0; off[42] = 0xffff; off[43] = -1;
+            off[44] = off[45] = off[46] = off[47] = 0;
             const size_t ti = (size_t)u * kNdTileThreads + t;
             if (t < kNdTileThreads && ti < tiles.size()) {
                 const NdTile &tl = tiles[ti];
@@ -293,6 +295,14 @@ inline bool nd_build_plan(int C, const int *ncols, const int *col0, const unsign
                 off[41] = (int)um;
                 off[42] = pl.phase_of[tl.cj] | (pl.slot_of[tl.cj] << 8);
                 off[43] = tl.lt;
+                // per phase: the slots whose panel k updates this tile (k < column panel, both factor tiles exist; the diagonal tile of the NEXT
+                // phase's panel is brought up to date by its look-ahead lane instead)
+                for (int t = 0; t < pl.phase_of[tl.cj]; ++t) {
+                    if (tl.ri == tl.cj && pl.phase_of[tl.cj] == t + 1) continue;
+                    unsigned bits = 0;
+                    for (int q = 0; q < kNdSlots; ++q) { const int k = (pl.phase_panels[t] >> (8 * q)) & 0xff; if (k != 0xff && k < tl.cj && ((um >> k) & 1u)) bits |= 1u << q; }
+                    off[44 + t / 8] |= (int)(bits << (4 * (t % 8)));
+                }
             }
             for (int q = 0; q < kNdUnitInts / 4; ++q)
                 for (int e = 0; e < 4; ++e) pl.map[(((size_t)u * (kNdUnitInts / 4) + q) * kNdThreads + t) * 4 + e] = off[4 * q + e];

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     // (the tile's coordinates stay packed in two words and are extracted where they are used)
     struct Unit {
         double a[TS][TS];
+        int pm[4];                      // update masks: phases 8 w .. 8 w + 7 in word w, four bits each
         int m0, m1, lt;                 // m0: row panel | column panel << 8 | kind << 16 | look-ahead slot that needs this tile raw << 24; m1: phase | slot << 8 of the column panel
-        unsigned umask;
         __device__ __forceinline__ int ri() const { return m0 & 0xff; }
         __device__ __forceinline__ int cj() const { return (m0 >> 8) & 0xff; }
         __device__ __forceinline__ int kind() const { return (m0 >> 16) & 0xff; }
@@ -169,7 +169,9 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     const double inv_radius = 1.0 / radius;
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
-        U[u].m0 = off[u][40]; U[u].umask = (unsigned)off[u][41]; U[u].m1 = off[u][42]; U[u].lt = off[u][43];
+        U[u].m0 = off[u][40]; U[u].m1 = off[u][42]; U[u].lt = off[u][43];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) U[u].pm[w] = off[u][44 + w];
 #pragma unroll
         for (int r = 0; r < TS; ++r)
 #pragma unroll
@@ -352,14 +354,10 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
 #pragma unroll
             for (int u = 0; u < TPT; ++u) {
                 Unit &T = U[u];
-                const bool live = T.kind() && T.phase_c() > ph && !(T.diag() && T.phase_c() == ph + 1);       // (the look-ahead lane takes that one)
-                unsigned mm = 0;
-#pragma unroll
-                for (int q = 0; q < kNdSlots; ++q) {
-                    const int k = (sp >> (8 * q)) & 0xff;                   // (wave-uniform)
-                    if (k != 0xff && ((T.umask >> (k & 31)) & 1u)) mm |= 1u << q;
-                }
-                if (!live) mm = 0;
+                // (which slots: four bits of the plan's per-tile table -- deriving them from the phase's panels and the tile's mask was 48
+                // instructions per phase, at 3 ns each on a wave that is alone on its SIMD)
+                const int w8 = ph >> 3;
+                const unsigned mm = ((unsigned)(w8 == 0 ? T.pm[0] : w8 == 1 ? T.pm[1] : w8 == 2 ? T.pm[2] : T.pm[3]) >> (4 * (ph & 7))) & 15u;
 #pragma unroll
                 for (int q = 0; q < kNdSlots; ++q) {
                     if ((mm >> q) & 1u) {
@@ -424,66 +422,74 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
             // -- the phase's table entry, this lane's factor tile, the diagonal factor its group's leader solves with -- is
             // requested one phase AHEAD: a phase's dependent chain is then the load of y_i, 16 FMAs, the row sum, the 4 x 4 solve
             // and the store of y_k (one LDS round trip instead of four)
-            int e_n = s_bs[(n_phases - 1) * 64 + lane];
-            double lt_n[TS][TS], ld_n[10];
-            unsigned sp_n = (unsigned)__builtin_amdgcn_readlane(sp_v, n_phases - 1);
-            auto prefetch = [&](int e, unsigned spb) {
-                load_tile(Lt + XT * (max(e, 0) & 0xffff), lt_n);
-                const int k = (spb >> (8 * q)) & 0xff;
+            // (two operand buffers that take turns -- the loop is unrolled by two -- instead of a copy of 26 doubles per phase: on this
+            // one wave an instruction is 2.2-2.9 ns whatever it does)
+            struct BsOps { int e; unsigned sp; double lt[TS][TS], ld[10]; };
+            auto prefetch = [&](BsOps &o, int ph) {
+                o.e = s_bs[ph * 64 + lane];
+                o.sp = (unsigned)__builtin_amdgcn_readlane(sp_v, ph);
+                load_tile(Lt + XT * (max(o.e, 0) & 0xffff), o.lt);
+                const int k = (o.sp >> (8 * q)) & 0xff;
                 const double *ld = Ld + 20 * (k == 0xff ? 0 : k);
-                ld_n[0] = ld[1 * TS + 0]; ld_n[1] = ld[2 * TS + 0]; ld_n[2] = ld[2 * TS + 1]; ld_n[3] = ld[3 * TS + 0]; ld_n[4] = ld[3 * TS + 1]; ld_n[5] = ld[3 * TS + 2];
+                o.ld[0] = ld[1 * TS + 0]; o.ld[1] = ld[2 * TS + 0]; o.ld[2] = ld[2 * TS + 1]; o.ld[3] = ld[3 * TS + 0]; o.ld[4] = ld[3 * TS + 1]; o.ld[5] = ld[3 * TS + 2];
 #pragma unroll
-                for (int c = 0; c < TS; ++c) ld_n[6 + c] = ld[16 + c];
+                for (int c = 0; c < TS; ++c) o.ld[6 + c] = ld[16 + c];
             };
-            prefetch(e_n, sp_n);
-#ifdef TSCM_PHASE_PROFILE
-            if (tid == 0) s_bst[n_phases] = wall_clock64();
-#endif
-            for (int ph = n_phases - 1; ph >= 0; --ph) {
-                const int e = e_n;
-                const unsigned spb = sp_n;
-                double lt[TS][TS], ldg[10];
-#pragma unroll
-                for (int c = 0; c < TS; ++c)
-#pragma unroll
-                    for (int r = 0; r < TS; ++r) lt[c][r] = lt_n[c][r];
-#pragma unroll
-                for (int c = 0; c < 10; ++c) ldg[c] = ld_n[c];
-                if (ph > 0) {
-                    e_n = s_bs[(ph - 1) * 64 + lane];
-                    sp_n = (unsigned)__builtin_amdgcn_readlane(sp_v, ph - 1);
-                    prefetch(e_n, sp_n);
-                }
-                const int k = (spb >> (8 * q)) & 0xff;
+            const int b0 = lane & 1, b1 = (lane >> 1) & 1;
+            auto phase = [&](const BsOps &o, BsOps &nxt, int ph) {
+                const int e = o.e;
+                const int k = (o.sp >> (8 * q)) & 0xff;
+                const bool lead = (lane & 15) == 0 && k != 0xff;
+                // the loads ON the chain first: y_i of this lane's tile, w_k of the group's leader (LDS returns a wave's loads in order)
+                d2 y01 = { 0.0, 0.0 }, y23 = { 0.0, 0.0 }, w01 = { 0.0, 0.0 }, w23 = { 0.0, 0.0 };
+                if (e >= 0) { const d2 *yp = reinterpret_cast<const d2 *>(wp + TS * (e >> 16)); y01 = yp[0]; y23 = yp[1]; }
+                if (lead) { const d2 *wq = reinterpret_cast<const d2 *>(wp + TS * k); w01 = wq[0]; w23 = wq[1]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ph > 0) prefetch(nxt, ph - 1);
                 double acc[TS] = { 0.0, 0.0, 0.0, 0.0 };
                 if (e >= 0) {
-                    const d2 *yp = reinterpret_cast<const d2 *>(wp + TS * (e >> 16));
-                    const d2 y01 = yp[0], y23 = yp[1];
                     const double y[TS] = { y01[0], y01[1], y23[0], y23[1] };
 #pragma unroll
                     for (int c = 0; c < TS; ++c)
 #pragma unroll
-                        for (int r = 0; r < TS; ++r) acc[c] += lt[c][r] * y[r];
+                        for (int r = 0; r < TS; ++r) acc[c] += o.lt[c][r] * y[r];
                 }
-#pragma unroll
-                for (int c = 0; c < TS; ++c) acc[c] = row16_allsum(acc[c]);
-                if ((lane & 15) == 0 && k != 0xff) {
-                    double v[TS];
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) v[c] = wp[TS * k + c] - acc[c];
-                    v[3] = v[3] * ldg[9];
-                    v[2] = (v[2] - ldg[5] * v[3]) * ldg[8];
-                    v[1] = (v[1] - ldg[2] * v[2] - ldg[4] * v[3]) * ldg[7];
-                    v[0] = (v[0] - ldg[0] * v[1] - ldg[1] * v[2] - ldg[3] * v[3]) * ldg[6];
-#pragma unroll
-                    for (int c = 0; c < TS; ++c) wp[TS * k + c] = v[c];
+                // sum of the four components over the 16 lanes of the row by recursive halving: after two exchange steps a lane
+                // holds ONE component summed over its quad (lane & 3 = 0, 1, 2, 3 <-> component 0, 2, 1, 3), two rotations by 4 and 8
+                // lanes complete it -- 27 instructions instead of the 48 of four full butterflies; fixed order
+                double kA = b0 ? acc[2] : acc[0], kB = b0 ? acc[3] : acc[1];
+                const double sA = b0 ? acc[0] : acc[2], sB = b0 ? acc[1] : acc[3];
+                kA += dpp_f64<0xB1>(sA); kB += dpp_f64<0xB1>(sB);                  // quad_perm [1,0,3,2]
+                double kv = b1 ? kB : kA;
+                const double sv = b1 ? kA : kB;
+                kv += dpp_f64<0x4E>(sv);                                           // quad_perm [2,3,0,1]
+                kv += dpp_f64<0x124>(kv);                                          // row_ror:4
+                kv += dpp_f64<0x128>(kv);                                          // row_ror:8
+                const double s2 = dpp_f64<0x55>(kv), s1 = dpp_f64<0xAA>(kv), s3 = dpp_f64<0xFF>(kv);      // lanes 1, 2, 3 of the quad -> components 2, 1, 3
+                if (lead) {
+                    double v[TS] = { w01[0] - kv, w01[1] - s1, w23[0] - s2, w23[1] - s3 };
+                    v[3] = v[3] * o.ld[9];
+                    v[2] = (v[2] - o.ld[5] * v[3]) * o.ld[8];
+                    v[1] = (v[1] - o.ld[2] * v[2] - o.ld[4] * v[3]) * o.ld[7];
+                    v[0] = (v[0] - o.ld[0] * v[1] - o.ld[1] * v[2] - o.ld[3] * v[3]) * o.ld[6];
+                    d2 *wq = reinterpret_cast<d2 *>(wp + TS * k);
+                    wq[0] = d2{ v[0], v[1] }; wq[1] = d2{ v[2], v[3] };
                 }
                 // (y_k is read by other lanes of THIS wave in the next phase: LDS operations of a wave are served in order, only
-                // the compiler must not move them -- a fence here would also wait for the tail's global prefetch, 2-3 us)
+                // the compiler must not move them -- a fence here would also wait for the tail's global prefetch)
                 asm volatile("" ::: "memory");
 #ifdef TSCM_PHASE_PROFILE
                 if (tid == 0) s_bst[ph] = wall_clock64();
 #endif
+            };
+            BsOps oa, ob;
+            prefetch(oa, n_phases - 1);
+#ifdef TSCM_PHASE_PROFILE
+            if (tid == 0) s_bst[n_phases] = wall_clock64();
+#endif
+            for (int ph = n_phases - 1; ph >= 0; ph -= 2) {
+                phase(oa, ob, ph);
+                if (ph > 0) phase(ob, oa, ph - 1);
             }
         } else
         for (int ph = n_phases - 1; ph >= 0; --ph) {

@@ -29,7 +29,11 @@ def _token(addr: str, port: int, world: int) -> bytes:
     (bench.py's own launcher), and the launcher process itself -- under a static torchrun rendezvous
     TORCHELASTIC_RUN_ID is a constant and MASTER_PORT may be re-used, but every rank of a launch is a child of the same
     agent process (single node: the side channel is a loopback star)."""
-    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + os.environ.get("TSCM_RDZV_RUN", "") + "|" + os.environ.get("TSCM_RDZV_NONCE", str(os.getppid()))
+    own = os.environ.get("TSCM_RDZV_RUN", "")
+    # (bench.py's own launcher hands every rank a random id: the parent's process id adds nothing there, and would keep ranks apart
+    # that a wrapper script starts one by one)
+    nonce = os.environ.get("TSCM_RDZV_NONCE", "" if own else str(os.getppid()))
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + own + "|" + nonce
     return hashlib.sha256(f"{addr}|{port}|{world}|{run}".encode()).digest()[:16]
 
 
