@@ -404,6 +404,28 @@ def test_reduced_solver_along_the_camera_pair_graph(hip_device, name):
         assert max(H.param_rel_err(pd, pg).values()) < 1e-8
 
 
+def test_camera_without_views_and_constant_poses_in_a_six_camera_rig(hip_device):
+    """k_solve_nd's plan leaves out a camera that has no views (no free columns: Ceres would not even see its blocks) and takes a
+    constant pose as a 7-column block wherever it sits: a ring of the cameras 0, 1, 2, 4, 5 of a 6-camera rig -- camera 3 is seen by
+    nobody -- with the poses of cameras 0 and 4 held constant, against the oracle and on both orders; the unseen camera's
+    parameters come back untouched."""
+    p = H.rig_with_pairs(6, [(0, 1), (1, 2), (2, 4), (4, 5), (5, 0)], frames_per_pair=8, seed=61)
+    assert np.bincount(p.view_camera, minlength=6)[3] == 0
+    p.cam_pose_constant[:] = 0
+    p.cam_pose_constant[[0, 4]] = 1
+    opts = dict(max_num_iterations=10)
+    pg, po, gs, os_ = _solve_both(p, **opts)
+    _cmp_trace(gs, os_)
+    assert max(H.param_rel_err(pg, po).values()) < 1e-6
+    assert np.array_equal(pg.cam_rt[3], p.cam_rt[3]) and np.array_equal(pg.intr[3], p.intr[3])
+    assert np.array_equal(pg.cam_rt[[0, 4]], p.cam_rt[[0, 4]])
+    pd = p.copy().normalised()
+    with api.Solver(pd) as s:
+        ds = s.solve(exec_flags=lib.EXEC_DENSE_REDUCED_ORDER, **opts)
+    _cmp_trace(ds, gs, rtol=1e-9)
+    assert max(H.param_rel_err(pd, pg).values()) < 1e-8
+
+
 def test_ring_of_four_along_the_graph_and_as_a_dense_block(hip_device):
     """BASELINE config 3 (4-camera ring, 500 views per camera) through k_solve_nd (9 phases along the ring) and through the dense
     k_solve_reduced (12 panels, the default up to 4 cameras): same trace and parameters to rounding, both equal to the oracle's."""
