@@ -995,6 +995,9 @@ static int enqueue_iteration(LmRun &run)
                 const size_t lds = std::max(s->lds_nd[v], n_bs ? s->lds_bs : (size_t)0);
                 const dim3 grid(1 + n_prod + n_bs);
                 if (two) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+#ifdef TSCM_ND_TWICE     // experiment: the same launch again (same inputs, same outputs): what a warm instruction cache / L2 would buy
+                if (two && !n_bs) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+#endif
                 else hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
             } else {
                 if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
