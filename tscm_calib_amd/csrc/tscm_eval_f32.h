@@ -4,36 +4,67 @@
 // what changes is the arithmetic type of the Jacobian:
 //   fp64  board -> camera transform, triple-sphere projection, residual and the cost r^T r
 //   fp32  every derivative (the 2 x 15 tile row of a corner), computed two at a time (u-row, v-row)
-//         with packed fp32 math, staged in a float LDS tile and contracted with
-//         v_mfma_f32_16x16x4_f32 (half the issue cycles of the fp64 MFMA); one view's Gram
-//         (<= 2 x 64 rows) accumulates in fp32, is converted once and everything downstream
-//         (records, camera tiles, Schur elimination, reduced solve) stays fp64.
+//         with packed fp32 math, staged in LDS as (u, v) PAIRS and contracted with
+//         v_mfma_f32_16x16x4_f32; one view's Gram (<= 2 x 64 rows) accumulates in fp32, is converted
+//         once and everything downstream (records, camera tiles, Schur elimination, reduced solve)
+//         stays fp64.
 // The fp32 MFMA returns rows 4*(lane>>4)+reg per lane, the fp64 one rows (lane>>4)+4*reg; feeding
 // the A operand with tile column pi(i) = (i>>2) + 4*(i&3) makes the fp32 result land exactly where
 // the fp64 epilogue expects it.
+//
+// On gfx950 the fp32 (and fp64) MFMAs run at the VECTOR rate and do not overlap with another wave's VALU work on the
+// same SIMD (tools/ubench_overlap.hip: MFMA waves + FMA waves on one SIMD take the SUM of their times, in every
+// combination of f32 / f64): the kernel's time is the sum of its instruction cycles, and the layout below is about
+// spending none on moving operands (round 4):
+//   * tile T[column c][row position p] of float2 (u-row entry, v-row entry): a corner writes its 15 entries as
+//     ds_write_b64 -- both row halves at once, no v-row copy pass, no v-rows waiting in registers;
+//   * the contraction index of the MFMA is free to permute: with K k-steps per pass, corner j sits at position
+//     KB (j / K) + j % K, so that lane (column, kq) finds ITS rows of all K k-steps -- positions KB kq .. KB kq + K - 1 --
+//     adjacent: K / 2 ds_read_b128 per operand and view instead of 2 x K ds_read_b32.  Boards of up to 56 corners
+//     (K = KB = 14 at compile time): the position is the lane itself, 58 positions per column -- 116 dwords = 4 * 29, the 16
+//     columns of one kq cover the 64 banks, and a workgroup's four tiles + ONE copy of the board points are 30.6 KB.
+//     Other boards: K = min(16, ceil(n_points / 4)) at run time, KB = 16, 66 positions per column;
+//   * the u- and v-row MFMAs alternate: two independent accumulators, so the 40-cycle dependent latency of the
+//     instruction (32 to issue) is not paid 2 K times per view.
+// Measured (round 4, config 4, same box, alternating): 46.0 -> 43.5 us per launch; five workgroups per CU (86 VGPRs and
+// the smaller tile allow it: make variant EXTRA="-DTSCM_F32_WGS=5 -DTSCM_EVAL_WAVES=5") give nothing -- the SIMD's one
+// pipe is busy, not waiting.
 #pragma once
 // (included from tscm_kernels.h inside namespace tscm)
 
-constexpr int kRP32 = 68;          // float pitch of the fp32 tile: 68 = 4 (mod 64) -> 16 columns x 4 k-rows hit 64 distinct banks
-constexpr int kTile32 = 16 * kRP32 * 4 / 8;   // the tile, in doubles (544): also covers the 512-double camera-tile exchange
+// tile geometry: KB row positions per kq block (corner j at position KB (j / K) + j % K: the identity when KB = K),
+// P2 positions per tile column with 2 P2 = 4 * odd dwords (the 16 columns of an operand fetch cover the 64 banks)
+template <int KS> struct F32Tile {
+    static constexpr int KB = KS ? KS : 16;
+    static constexpr int P2 = KS == 14 ? 58 : 66;
+    static constexpr int kDoubles = 16 * P2;        // per wave; also covers the 512-double camera-tile exchange
+    static_assert(4 * KB <= P2 && (2 * P2) % 8 == 4 && (KB * 8) % 16 == 0, "block starts are 16-byte aligned, columns 4 * odd dwords apart");
+};
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline int eval_f32_lds_doubles(int n_points) { return kTile32 + 2 * n_points; }
+// dynamic LDS of a workgroup, in doubles: the four waves' tiles, then ONE copy of the board points
+__host__ __device__ inline int eval_f32_lds_doubles(int n_points, bool ks14) { return 4 * (ks14 ? F32Tile<14>::kDoubles : F32Tile<0>::kDoubles) + 2 * n_points; }
 
-__global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState S, int cand)
+#ifndef TSCM_F32_WGS
+#define TSCM_F32_WGS 4
+#endif
+
+// KS: k-steps of a pass at compile time (14: boards of 53..56 corners, the usual 9 x 6 .. 7 x 8), or 0: min(16, ceil(n_points / 4)) at run time
+template <int KS>
+__global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem P, DevState S, int cand)
 {
     // the control block is read together with the static chunk tables (one memory round trip, not two);
     // the early exit is taken right before the first view
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lds_wave = eval_f32_lds_doubles(P.n_points);
+    constexpr int kP2 = F32Tile<KS>::P2, KB = F32Tile<KS>::KB, kTile32 = F32Tile<KS>::kDoubles;
+    constexpr int lds_wave = kTile32;
     double *lds = lds_all + (size_t)wave * lds_wave;
-    float *Fl = reinterpret_cast<float *>(lds);            // [16][kRP32]: the u-rows, then the v-rows
-    double *bxy = lds + kTile32;                            // board points
-    constexpr int RP = kRP32;
+    f2 *T2 = reinterpret_cast<f2 *>(lds);                   // [16][kP2] (u, v) pairs
+    double *bxy = lds_all + 4 * kTile32;                    // board points: one copy, written by every wave with the same values
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
     const int cam = P.chunk_cam[chunk];
@@ -45,13 +76,17 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
     double rr = 0.0;                               // this lane's share of r^T r, fp64
-#pragma unroll
-    for (int c = 0; c < 16; ++c) Fl[c * RP + lane] = 0.f;  // all 64 rows incl. the all-zero 16th tile column
+    for (int i = lane; i < kTile32; i += 64) lds[i] = 0.0;  // all positions incl. the all-zero 16th tile column and the ones no corner maps to
     int prev_nv = 0;
     double pf_u = 0.0, pf_v = 0.0;
     int warm = 0;
-    const float *fpB = Fl + col * RP + kq;                              // B operand: tile column col
-    const float *fpA = Fl + ((col >> 2) + 4 * (col & 3)) * RP + kq;     // A operand: tile column pi(col)
+    // k-steps of a pass (kernel-uniform) and this lane's row position as a corner; as an MFMA lane (column, kq): the rows
+    // of its K k-steps are positions KB kq .. KB kq + K - 1 of tile column col (B operand) and pi(col) (A operand)
+    const int K = KS ? KS : __builtin_amdgcn_readfirstlane(min(16, (P.n_points + 3) >> 2));
+    f2 *fw = T2 + (KB == KS ? lane : KB * (lane / K) + lane % K);         // (lanes >= 4 K never hold a corner)
+    typedef const f4 __attribute__((address_space(3))) *lds_f4;
+    const lds_f4 pB = (lds_f4)(T2 + col * kP2 + KB * kq);
+    const lds_f4 pA = (lds_f4)(T2 + ((col >> 2) + 4 * (col & 3)) * kP2 + KB * kq);
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
     const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
@@ -88,8 +123,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             const int j = c0 + lane;
             const bool valid = j < cnt;
-            float *fu = Fl + lane;
-            float fv[kTcols];
+            auto PUT = [&](int c, float u, float v) { fw[c * kP2] = f2{ u, v }; };
             if (valid) {
                 const double x = bxy[2 * j], y = bxy[2 * j + 1];
                 const double ou = c0 ? buf_load_f64(r_u, 8u * j, 8u * (unsigned)off) : pf_u, ov = c0 ? buf_load_f64(r_v, 8u * j, 8u * (unsigned)off) : pf_v;
@@ -135,36 +169,36 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
                 const f2 N0 = HM * (Xf * q) - (f2){ fk.x, 0.f };           // -d(u,v)/dX
                 const f2 N1 = HM * (Yf * q) - (f2){ 0.f, fk.y };           // -d(u,v)/dY
                 const f2 N2 = HM * kz;                                     // -d(u,v)/dZ
-                fu[tc_tc(0) * RP] = N0.x; fv[tc_tc(0)] = N0.y;
-                fu[tc_tc(1) * RP] = N1.x; fv[tc_tc(1)] = N1.y;
-                fu[tc_tc(2) * RP] = N2.x; fv[tc_tc(2)] = N2.y;
+                PUT(tc_tc(0), N0.x, N0.y);
+                PUT(tc_tc(1), N1.x, N1.y);
+                PUT(tc_tc(2), N2.x, N2.y);
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {                           // w_b: -A (x e_k0 + y e_k1)
                     const float h0 = xf * cs[9 + 6 * kk] + yf * cs[12 + 6 * kk];
                     const float h1 = xf * cs[10 + 6 * kk] + yf * cs[13 + 6 * kk];
                     const float h2 = xf * cs[11 + 6 * kk] + yf * cs[14 + 6 * kk];
                     const f2 w = N0 * h0 + N1 * h1 + N2 * h2;
-                    fu[(kTcWb + kk) * RP] = w.x; fv[kTcWb + kk] = w.y;
+                    PUT((kTcWb + kk), w.x, w.y);
                 }
                 {                                                          // w_c: -A (dR_c/dw_k Pw) = a_k . (Q' x n), both rows at once
                     const f2 c0 = N2 * Q1 - N1 * Q2, c1 = N0 * Q2 - N2 * Q0, c2 = N1 * Q0 - N0 * Q1;
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk) {
                         const f2 w = c0 * cf[12 + 3 * kk] + c1 * cf[13 + 3 * kk] + c2 * cf[14 + 3 * kk];
-                        fu[(kTcWc + kk) * RP] = w.x; fv[kTcWc + kk] = w.y;
+                        PUT((kTcWc + kk), w.x, w.y);
                     }
                 }
-                fu[kTcF * RP] = -mxf;  fv[kTcF] = -myf;
-                fu[kTcOne * RP] = -1.f; fv[kTcOne] = -1.f;
+                PUT(kTcF, -mxf, -myf);
+                PUT(kTcOne, -1.f, -1.f);
                 const float kxi = c3 * c2 * e1, klam = c3 * e2, kal = e3 * cf[46];
                 const f2 a = HM * kxi, b = HM * klam, c = HM * kal;
-                fu[kTcXi * RP] = a.x;  fv[kTcXi] = a.y;
-                fu[kTcLam * RP] = b.x; fv[kTcLam] = b.y;
-                fu[kTcAl * RP] = c.x;  fv[kTcAl] = c.y;
-                fu[kTcR * RP] = (float)ru; fv[kTcR] = (float)rv;
+                PUT(kTcXi, a.x, a.y);
+                PUT(kTcLam, b.x, b.y);
+                PUT(kTcAl, c.x, c.y);
+                PUT(kTcR, (float)ru, (float)rv);
             } else if (lane < prev_nv) {
 #pragma unroll
-                for (int c = 0; c < kTcols; ++c) fu[c * RP] = 0.f;
+                for (int c = 0; c < kTcols; ++c) PUT(c, 0.f, 0.f);
             }
             if (c0 == 0) {
                 // Prefetch of the next view, issued once the current view's observations have been consumed: the
@@ -182,38 +216,35 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram_f32(DevProblem P, DevState
             wave_lds_fence();
             const int nv = min(64, cnt - c0);
             prev_nv = nv;
-            const int ksteps = (nv + 3) >> 2;
             f4 aU = { 0.f, 0.f, 0.f, 0.f }, aV = { 0.f, 0.f, 0.f, 0.f };
             {
-                float a0 = fpA[0], b0 = fpB[0], a1 = fpA[4], b1 = fpB[4];
-                for (int t = 0; t < ksteps; t += 2) {
-                    const int tn = min(t + 2, 14);
-                    const float na0 = fpA[4 * tn], nb0 = fpB[4 * tn], na1 = fpA[4 * tn + 4], nb1 = fpB[4 * tn + 4];
-                    aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, aU, 0, 0, 0);
-                    aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, aU, 0, 0, 0);
-                    a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
-                }
-            }
-            wave_lds_fence();
-            if (valid) {
+                // rows of lanes without a corner are zero: all K k-steps run whatever the view's corner count
+                f4 A[4], B[4];
 #pragma unroll
-                for (int c = 0; c < kTcols; ++c) fu[c * RP] = fv[c];
-            }
-            wave_lds_fence();
-            {
-                float a0 = fpA[0], b0 = fpB[0], a1 = fpA[4], b1 = fpB[4];
-                for (int t = 0; t < ksteps; t += 2) {
-                    const int tn = min(t + 2, 14);
-                    const float na0 = fpA[4 * tn], nb0 = fpB[4 * tn], na1 = fpA[4 * tn + 4], nb1 = fpB[4 * tn + 4];
-                    aV = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, aV, 0, 0, 0);
-                    aV = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, aV, 0, 0, 0);
-                    a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+                for (int m = 0; m < 4; ++m) { A[m] = pA[m]; B[m] = pB[m]; }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const f4 a = A[m], b = B[m];
+                        if (h == 0) { A[m] = pA[4 + m]; B[m] = pB[4 + m]; }      // the second half's operands, behind their last use
+                        const int t = 8 * h + 2 * m;
+                        if (t < K) {
+                            aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, aU, 0, 0, 0);
+                            aV = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, aV, 0, 0, 0);
+                        }
+                        if (t + 1 < K) {
+                            aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, aU, 0, 0, 0);
+                            aV = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, aV, 0, 0, 0);
+                        }
+                    }
                 }
             }
             wave_lds_fence();
             // one pass (<= 64 corners) of fp32 accumulation, then fp64
 #pragma unroll
             for (int r = 0; r < 4; ++r) { accU[r] += (double)aU[r]; accV[r] += (double)aV[r]; }
+            if (KS) break;                   // (n_points <= 4 KS: one pass)
         }
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
         camU += accU; camV += accV;

@@ -364,7 +364,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if (4 * lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_eval_bytes)));
     int wgs_per_cu = 0;         // resident workgroups per CU (register- and LDS-limited)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void *>(rp == 58 ? k_eval_gram<58> : k_eval_gram<0>), 256, 4 * lds_eval_bytes));
+#ifdef TSCM_EVAL_WAVES          // occupancy experiments: chunk tables for this many waves per SIMD
+    const int waves_per_cu = 4 * TSCM_EVAL_WAVES;
+#else
     const int waves_per_cu = 4 * std::max(1, std::min(4, wgs_per_cu));
+#endif
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     const int target_chunks = std::max(64, prop.multiProcessorCount * waves_per_cu - 4 * C);
@@ -652,7 +656,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
 
     s->lds_eval = 4 * lds_eval_bytes;
-    s->lds_eval32 = 4 * sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points);
+    s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, rp == 58);
     s->lds_eval4 = 4 * sizeof(double) * (size_t)eval_gram4_lds_doubles(p->n_points);
 #ifdef TSCM_G4_LDS_PAD      // occupancy experiments (tools/wave_timeline.py): fewer workgroups per CU, same kernel
     s->lds_eval4 += TSCM_G4_LDS_PAD;
@@ -825,7 +829,8 @@ static int launch_eval(tscm_solver *s, int cand)
     if (int rc = timed_pair(s, 0, &e0, &e1)) return rc;
     const dim3 grid(P.n_chunks / 4);
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
-    if (s->f32_jacobian) launch_eval_kernel(k_eval_gram_f32, grid, s->lds_eval32, s, e0, e1, cand);
+    if (s->f32_jacobian && P.rp == 58) launch_eval_kernel(k_eval_gram_f32<14>, grid, s->lds_eval32, s, e0, e1, cand);
+    else if (s->f32_jacobian) launch_eval_kernel(k_eval_gram_f32<0>, grid, s->lds_eval32, s, e0, e1, cand);
     else if (P.rp == 58 && !s->gram16) launch_eval_kernel(k_eval_gram4, grid, s->lds_eval4, s, e0, e1, cand);
     else if (P.rp == 58) launch_eval_kernel(k_eval_gram<58>, grid, s->lds_eval, s, e0, e1, cand);
     else launch_eval_kernel(k_eval_gram<0>, grid, s->lds_eval, s, e0, e1, cand);
@@ -1126,7 +1131,8 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     for (size_t r = 0; r < run.m.size(); ++r) std::memset(&sums[r], 0, sizeof(tscm_summary));
     for (tscm_solver *s : run.m) {
         s->f32_jacobian = opt.jacobian_fp32 != 0;
-        if (s->f32_jacobian && s->lds_eval32 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
+        if (s->f32_jacobian && s->lds_eval32 > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(s->P.rp == 58 ? k_eval_gram_f32<14> : k_eval_gram_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
     }
 
     // control block (identical on every rank), counter of the fused T reduction, start point: one launch (k_begin_solve)
