@@ -1475,6 +1475,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch)
 {
     KTL(3);
+    PHASE_STAMP(tsk);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
     const bool extra = ctl != 0 && blockIdx.x == 0;        // the workgroup that writes the control step's results, and nothing else
@@ -1683,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
         S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] = (tiles[0][t][tid] + tiles[1][t][tid]) + (tiles[2][t][tid] + tiles[3][t][tid]);
 #ifdef TSCM_PHASE_PROFILE
     if (threadIdx.x == 0 && (cblk == 0 || cblk == 200))
-        printf("schur_gram wg %d: boards %d  E sums %lld  factor %lld  gram %lld  tiles %lld [10 ns]\n", (int)blockIdx.x, nbd, ts1 - ts0, ts2 - ts1, ts3 - ts2, wall_clock64() - ts3);
+        printf("schur_gram wg %d: boards %d  head %lld  E sums %lld  factor %lld  gram %lld  tiles %lld [10 ns]\n", (int)blockIdx.x, nbd, ts0 - tsk, ts1 - ts0, ts2 - ts1, ts3 - ts2, wall_clock64() - ts3);
 #endif
 }
 
