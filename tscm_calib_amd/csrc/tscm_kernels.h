@@ -2148,7 +2148,7 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 //            flat (every wave instruction 512 consecutive bytes) into LDS; 16 lanes per slot take their columns from there
 //   phase B  one lane per board: y_b = L^{-T} (z - L^{-1} S_b q_b);  delta_b = -s_b y_b;  candidate = x + delta
 //            (sum_v Y_v yhat = L^{-1} S_b sum_v W_v yhat: one forward substitution per board);  the candidate rotations
-//            R_c of the cameras are prepared by otherwise idle lanes
+//            R_c of the cameras are prepared by lanes of the second wave
 //   phase C  one lane per view of these boards: board rotation columns, t_b and R_c dR_b/dw of the candidate, staged in
 //            LDS and written as 256-byte records (vconst, see k_view_prep); workgroup 0 also writes the per-camera records
 // grid ceil(B / (NTH / 8)) x NTH, dynamic LDS BsGeom<NTH>::kLds doubles
@@ -2166,7 +2166,7 @@ template <int NTH> struct BsGeom {
     static constexpr int kLds = kBsTile * (kVFloatOff + 1) > kLdsA ? kBsTile * (kVFloatOff + 1) : kLdsA;     // dynamic LDS, doubles
     static_assert(kBoards * kFac == 7 * NTH, "the factor records are 7 doubles per thread");
     static_assert(kBoards * kFac <= kBsRound * kRecW, "the factor records re-use the W area");
-    static_assert(kBoards + kMaxCam <= NTH, "lane roles of phase B");
+    static_assert(kBoards <= 64 && 64 + kMaxCam <= NTH, "lane roles of phase B: the boards in wave 0, the cameras from wave 1 on");
 };
 
 // WAIT: the workgroup runs inside the reduced solve's launch (k_solve_reduced<..., true>, one GPU).  Everything that does
@@ -2178,6 +2178,10 @@ template <int NTH, bool WAIT>
 __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState &S, int with_floats, const int blk, const int nblk, const int epoch, const int t_need)
 {
     constexpr int kBsBoards = BsGeom<NTH>::kBoards, kBsThreads = NTH, kLoads = BsGeom<NTH>::kLoads;
+#ifndef TSCM_BS_CAM_LANE0
+#define TSCM_BS_CAM_LANE0 64
+#endif
+    constexpr int kBsCamLane0 = TSCM_BS_CAM_LANE0;
     // head: control block and slot range in one round trip
     const int b0 = blk * kBsBoards;
     const int nbl = min(kBsBoards, P.B - b0);
@@ -2301,7 +2305,8 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
         __syncthreads();
     }
     PHASE_STAMP(ts1);
-    // ---- phase B: lanes 0 .. nbl-1 one board each; lanes 32 .. 32+C-1 the candidate camera rotations ----------------
+    // ---- phase B: lanes 0 .. nbl-1 one board each; lanes 64 .. 64+C-1 the candidate camera rotations -- in the SECOND
+    //      wave: as lanes of the first they ran after the board solves (a wave executes both sides of a branch) -----------
     double mb = 0.0, ss = 0.0;
     if (t < nbl) {
         const int b = b0 + t;
@@ -2337,8 +2342,8 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
                 s_new[t][k] = xn;
             }
         }
-    } else if (t >= kBsBoards && t < kBsBoards + P.C) {
-        const int m = t - kBsBoards;
+    } else if (t >= kBsCamLane0 && t < kBsCamLane0 + P.C) {
+        const int m = t - kBsCamLane0;
         double crt[3], Rc[9], dRc[27];
         double crt6[6];
 #pragma unroll
