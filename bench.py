@@ -314,22 +314,30 @@ def main():
         full = synth.make_problem(4, 8, 123)
         api = lib = None
         Solver = _StubSolver
+        device, exchange, n_dev = local_rank, "stub", world
     else:
         from tscm_calib_amd import api, lib
         full = synth.make_config(args.config, poses_fixed=args.poses_fixed)
         Solver = api.Solver
-        if lib.lib().tscm_device_count() <= local_rank:
-            raise SystemExit(f"rank {rank}: HIP device {local_rank} does not exist ({lib.lib().tscm_device_count()} visible): "
-                             f"--gpus {world} needs {world} GPUs (one process per GPU; RCCL refuses two ranks on one device)")
+        n_dev = lib.lib().tscm_device_count()
+        exchange = os.environ.get("TSCM_BENCH_EXCHANGE", "rccl" if n_dev >= world else "").lower()
+        if n_dev <= local_rank and exchange != "ipc":
+            raise SystemExit(f"rank {rank}: HIP device {local_rank} does not exist ({n_dev} visible): "
+                             f"--gpus {world} needs {world} GPUs (one process per GPU; RCCL refuses two ranks on one device). "
+                             f"TSCM_BENCH_EXCHANGE=ipc runs the {world} rank processes on the visible device(s) with the library's IPC exchange")
+        device = local_rank % max(1, n_dev)
 
     t_create = time.perf_counter()
-    solver = Solver(full, device=local_rank, rank=rank, world=world)          # H2D of this rank's observations + layout build
+    solver = Solver(full, device=device, rank=rank, world=world)          # H2D of this rank's observations + layout build
     t_create = time.perf_counter() - t_create
     comm = None
     rccl_ranks = world if stub else 1
     if multi and not stub:
-        uid = chan.bcast(api.Comm.unique_id() if rank == 0 else None)
-        comm = api.Comm(uid, rank, world, local_rank)
+        if exchange == "ipc":
+            comm = api.Comm.ipc(rank, world, device, chan.allgather_bytes, n_cameras=full.n_cameras)
+        else:
+            uid = chan.bcast(api.Comm.unique_id() if rank == 0 else None)
+            comm = api.Comm(uid, rank, world, device)
         solver.set_comm(comm)
         rccl_ranks = comm.backend_ranks()
         # RCCL writes its version banner to the C stdout buffer at communicator creation; push it out now so that the
@@ -341,7 +349,7 @@ def main():
     def barrier():
         # device fence (the job of torch.cuda.synchronize() in the contract) + process barrier
         if not stub:
-            lib.check(lib.lib().tscm_device_synchronize(local_rank))
+            lib.check(lib.lib().tscm_device_synchronize(device))
         if chan:
             chan.barrier()
 
@@ -352,10 +360,10 @@ def main():
     if not stub:
         import ctypes
         pk = (ctypes.c_double * 3)()
-        lib.check(lib.lib().tscm_device_peak_fp64_ex(local_rank, pk))
+        lib.check(lib.lib().tscm_device_peak_fp64_ex(device, pk))
         pk32 = ctypes.c_double(0.0)
         if args.jacobian_fp32:
-            lib.check(lib.lib().tscm_device_peak_fp32_mfma(local_rank, ctypes.byref(pk32)))
+            lib.check(lib.lib().tscm_device_peak_fp32_mfma(device, ctypes.byref(pk32)))
     # natural solve (reference options, termination tests on): untimed, doubles as warmup
     extra = dict(jacobian_fp32=1) if args.jacobian_fp32 else {}
     if args.exec_flags:
@@ -462,7 +470,9 @@ def main():
                                    f"{full.meta.get('views_per_cam')} views/cam, {full.n_boards} frames, "
                                    f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta.get('seed')})"
                                    + (", all board poses constant" if args.poses_fixed else ""),
-                       "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)"},
+                       "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)" if exchange != "ipc" or n_dev >= world
+                                      else f"frames sharded over {world} rank processes on {n_dev} GPU(s) (IPC exchange: a run of the multi-process path, not a scaling measurement)"},
+            "exchange": exchange if multi else None, "n_devices": None if stub else min(world, n_dev),
             "natural_solve": {"termination": natural["message"], "iterations": natural["num_iterations"] - 1,
                               "rmse_px": natural["rmse"], "seconds": natural["seconds_total"],
                               "device_seconds": natural["seconds_solve"],
@@ -479,7 +489,7 @@ def main():
             out["allreduce_ms"] = {
                 "T": max(r["allreduce_T_us"] for r in per_rank) * 1e-3, "H_stage": max(r["allreduce_H_us"] for r in per_rank) * 1e-3,
                 "per_step": max(r["allreduce_T_us"] + r["allreduce_H_us"] for r in per_rank) * 1e-3,
-                "timed_every": stride, "note": "HIP events on the solver stream around ncclAllReduce, max over ranks of each rank's mean",
+                "timed_every": stride, "note": "HIP events on the solver stream around the all-reduce (ncclAllReduce, or the IPC back-end's kernel: the wait for the slowest peer included), max over ranks of each rank's mean",
             }
             out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline and not stub:

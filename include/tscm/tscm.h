@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TSCM_ABI_VERSION 4   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
+#define TSCM_ABI_VERSION 5   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
                              /*    zero-initialised structs keep their meaning); 4: unknown exec_flags bits are  */
                              /*    refused, TSCM_EXEC_DENSE_REDUCED_ORDER, the fault injection of the tests is   */
                              /*    an entry point of its own (tscm_solver_debug_withhold_handoff), no option     */
@@ -292,6 +292,15 @@ int tscm_solver_create_sharded(const tscm_problem *problem, int device, int rank
 int tscm_comm_unique_id(unsigned char id[TSCM_UNIQUE_ID_BYTES]);
 int tscm_comm_create(const unsigned char id[TSCM_UNIQUE_ID_BYTES], int rank, int world, int device, tscm_comm **out);
 int tscm_comm_create_local(int world, int device, tscm_comm **out /* [world] */);
+/* IPC  one process per rank like RCCL; the exchange is the library's own one-shot all-reduce over buffers the ranks map
+ *      from each other (hipIpcMemHandle).  Ranks MAY share a device (RCCL refuses that): the multi-process path on a
+ *      one-GPU box.  Every rank calls tscm_comm_ipc_open (max_doubles >= 256 * max(camera-pair blocks, cameras) + 8 +
+ *      world: api.Comm.ipc computes it), the 64-byte handles are all-gathered by the caller (socket, file, MPI ...),
+ *      every rank calls tscm_comm_ipc_connect with all of them in rank order; then tscm_solver_set_comm as with RCCL.
+ *      Exercised between processes on one device; RCCL is the production path across devices. */
+#define TSCM_IPC_HANDLE_BYTES 64
+int tscm_comm_ipc_open(int rank, int world, int device, size_t max_doubles, tscm_comm **out, unsigned char handle[TSCM_IPC_HANDLE_BYTES]);
+int tscm_comm_ipc_connect(tscm_comm *c, const unsigned char *handles /* [world][TSCM_IPC_HANDLE_BYTES] */);
 void tscm_comm_destroy(tscm_comm *c);
 /* rank / world the communicator was created with and the number of ranks the back-end itself reports
  * (ncclCommCount for RCCL, the group size for LOCAL); any output may be NULL. */

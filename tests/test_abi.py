@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = lib.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.tscm_abi_version() == 4
+    assert L.tscm_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -120,9 +120,10 @@ def _chan_worker(rank, world, port, q):
     ch.barrier()
     mx = ch.allreduce_max(10.0 + rank)
     g = ch.gather({"rank": rank})
+    ag = ch.allgather_bytes(bytes([rank]) * 64)          # (the IPC back-end's memory handles travel like this)
     ch.barrier()
     ch.close()
-    q.put((rank, uid, mx, g))
+    q.put((rank, uid, mx, g, ag))
 
 
 def test_side_channel_collectives_world3():
@@ -136,8 +137,9 @@ def test_side_channel_collectives_world3():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for rank, uid, mx, g in res:
+    for rank, uid, mx, g, ag in res:
         assert uid == bytes(range(128)) and mx == 12.0
+        assert ag == [bytes([r]) * 64 for r in range(3)]
         assert (g == [{"rank": 0}, {"rank": 1}, {"rank": 2}]) if rank == 0 else (g is None)
 
 

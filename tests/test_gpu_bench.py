@@ -53,3 +53,32 @@ def test_more_ranks_than_gpus_fails_loudly(hip_device):
     assert out.returncode != 0
     assert "needs" in out.stderr and "GPUs" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_two_rank_processes_on_one_device_over_the_ipc_exchange(hip_device):
+    """`bench.py --gpus 2` end to end -- launcher, side channel, communicator, barriers, max over ranks, rank 0's JSON line -- with
+    both rank processes on THIS device: TSCM_BENCH_EXCHANGE=ipc selects the library's IPC exchange back-end (RCCL refuses two
+    ranks on one device).  Same natural solve as the plain run; the line says what it is."""
+    plain = _run({})
+    two = _run({"TSCM_BENCH_EXCHANGE": "ipc"}, "--gpus", "2")
+    assert two["n_gpus"] == 2 and two["exchange"] == "ipc" and two["rccl_ranks"] == 2
+    assert "rank processes on" in two["config"]["parallelism"]
+    assert len(two["per_rank"]) == 2 and len(two["corners_per_rank"]) == 2
+    assert two["natural_solve"]["iterations"] == plain["natural_solve"]["iterations"]
+    assert abs(two["natural_solve"]["rmse_px"] - plain["natural_solve"]["rmse_px"]) < 1e-9
+    assert two["value"] > 0
+
+
+def test_ipc_rank_processes_reproduce_the_local_group_bit_for_bit(hip_device):
+    """tools/ipc_check.py: 2 and 4 rank PROCESSES on this device (rendezvous, handle exchange, hipIpcOpenMemHandle, arrival
+    flags between kernels of different processes, the board gather through the communicator) against the same shards in one
+    process through the LOCAL group: iteration log and final parameters, bit for bit."""
+    tool = os.path.join(os.path.dirname(BENCH), "tools", "ipc_check.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, tool, "--world", "2,4", "--config", "3", "--iterations", "10"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [l["world"] for l in lines] == [2, 4]
+    for l in lines:
+        assert l["identical"] and l["iterations"] == 10
+        assert set(l["fingerprint_ipc_ranks"]) == {l["fingerprint_local_group"]}

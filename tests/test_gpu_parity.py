@@ -26,7 +26,7 @@ def _cmp_trace(gs, os_, rtol=1e-6):
 
 def test_native_library_is_loaded(hip_device):
     from tscm_calib_amd import lib
-    assert lib.lib().tscm_abi_version() == 4
+    assert lib.lib().tscm_abi_version() == 5
     assert lib.lib().tscm_device_count() >= 1
 
 
@@ -458,6 +458,26 @@ def test_rccl_code_path_single_rank(hip_device):
     with api.Solver(ref) as s:
         rs = s.solve()
     comm = api.Comm(api.Comm.unique_id(), 0, 1, 0)
+    q = p.copy().normalised()
+    with api.Solver(q) as s:
+        s.set_comm(comm)
+        qs = s.solve(exec_flags=lib.EXEC_KEEP_SINGLE_RANK_COMM)
+        s.set_comm(None)
+    comm.close()
+    assert qs["num_iterations"] == rs["num_iterations"] and qs["message"] == rs["message"]
+    assert np.array_equal(q.intr, ref.intr) and np.array_equal(q.cam_rt, ref.cam_rt) and np.array_equal(q.board_rt, ref.board_rt)
+
+
+def test_ipc_exchange_code_path_single_rank(hip_device):
+    """The IPC exchange back-end (tscm_comm_ipc_open / _connect, k_ipc_allreduce) on a one-rank communicator in this
+    process: the two all-reduces of every iteration and the board gather run through it (TSCM_EXEC_KEEP_SINGLE_RANK_COMM) and
+    must reproduce the single-GPU path bit for bit.  Several rank PROCESSES on this device: tests/test_gpu_bench.py."""
+    p = H.small_rig(4, 10, seed=33)
+    ref = p.copy().normalised()
+    with api.Solver(ref) as s:
+        rs = s.solve()
+    comm = api.Comm.ipc(0, 1, 0, lambda h: [h], n_cameras=4)
+    assert comm.backend_ranks() == 1
     q = p.copy().normalised()
     with api.Solver(q) as s:
         s.set_comm(comm)

@@ -107,7 +107,8 @@ class Solver:
 
 
 class Comm:
-    """RCCL communicator (one per process/GPU)."""
+    """Communicator of a frame-sharded solve: RCCL (one process per GPU: the constructor), the in-process group
+    (`local_group`), or the IPC back-end (`ipc`: one process per rank, ranks may share a device)."""
 
     def __init__(self, unique_id: bytes | None, rank: int, world: int, device: int, _handle=None):
         self._h = C.c_void_p()
@@ -124,6 +125,24 @@ class Comm:
         hs = (C.c_void_p * world)()
         _l.check(_l.lib().tscm_comm_create_local(world, device, hs))
         return [Comm(None, r, world, device, _handle=C.c_void_p(hs[r])) for r in range(world)]
+
+    @staticmethod
+    def ipc(rank: int, world: int, device: int, allgather, n_cameras: int = 32) -> "Comm":
+        """Communicator of the IPC back-end (tscm_comm_ipc_open / _connect): one process per rank, the ranks may
+        share a device.  `allgather(bytes) -> list[bytes]` is the caller's side channel (every rank calls it once, with
+        its 64-byte handle; it returns all ranks' handles in rank order).  `n_cameras`: upper bound of the rigs this
+        communicator will serve (sizes the exchange slots: 256 doubles per camera-pair block)."""
+        h = C.c_void_p()
+        mine = (C.c_ubyte * _l.IPC_HANDLE_BYTES)()
+        max_doubles = 256 * max(n_cameras * (n_cameras + 1) // 2, n_cameras) + 8 + world
+        _l.check(_l.lib().tscm_comm_ipc_open(rank, world, device, max_doubles, C.byref(h), mine))
+        c = Comm(None, rank, world, device, _handle=h)
+        handles = allgather(bytes(mine))
+        if len(handles) != world or any(len(x) != _l.IPC_HANDLE_BYTES for x in handles):
+            raise RuntimeError("allgather must return one 64-byte handle per rank")
+        buf = (C.c_ubyte * (_l.IPC_HANDLE_BYTES * world)).from_buffer_copy(b"".join(handles))
+        _l.check(_l.lib().tscm_comm_ipc_connect(c._h, buf))
+        return c
 
     def backend_ranks(self) -> int:
         """Number of ranks the exchange back-end itself reports (ncclCommCount for RCCL)."""

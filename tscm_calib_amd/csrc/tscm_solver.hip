@@ -56,9 +56,33 @@ struct tscm_local_group {
     hipStream_t stream = nullptr;
     double **d_ptrs = nullptr;           // [world] device array of the members' exchange buffers (rewritten per exchange)
 };
+// IPC: one process per rank like RCCL, but the exchange is this library's own one-shot all-reduce over memory the ranks
+// map from each other (hipIpcMemHandle: the same device, or peers over xGMI).  Every rank owns a buffer of
+// 2 (parity) x world (source rank) slots of max_doubles doubles and 2 x world arrival flags; an exchange is ONE
+// single-workgroup kernel per rank: store my values into my slot of every rank's buffer, release, raise my flag there;
+// wait for the world flags of my own buffer; sum the slots in rank order (the bits of the LOCAL backend, on every
+// rank).  4 us where an RCCL all-reduce of 16-32 KB takes 15-25 -- and the only back-end that can put several rank
+// PROCESSES on one device, which is how the multi-process path runs on a one-GPU box (tools/ipc_check.py,
+// `bench.py --gpus N` with fewer devices than ranks).  Exercised between processes on ONE device only (no
+// multi-GPU box in reach): across devices the arrival flags would want fine-grained memory -- RCCL stays the default.
+constexpr int kIpcMaxWorld = 16;
+struct IpcPeers { double *base[kIpcMaxWorld]; };
+struct tscm_ipc {
+    int world = 0, rank = 0;
+    size_t max_doubles = 0;             // per slot
+    void *own = nullptr;                // this rank's buffer (hipMalloc)
+    void *mapped[kIpcMaxWorld] = {};    // the peers' buffers as mapped here (own at [rank])
+    bool connected = false;
+    long long count = 0;                // exchanges so far: parity and flag value of the next one
+    int *d_fault = nullptr;             // raised by a kernel whose peers did not arrive within the bound
+    size_t slot_doubles() const { return max_doubles; }
+    size_t flags_offset() const { return 2 * (size_t)world * max_doubles; }        // in doubles (flags are 8-byte words)
+    size_t total_bytes() const { return 8 * (flags_offset() + 2 * (size_t)world); }
+};
 struct tscm_comm {
     ncclComm_t comm = nullptr;
     tscm_local_group *group = nullptr;   // LOCAL backend
+    tscm_ipc *ipc = nullptr;             // IPC backend
     int rank = 0, world = 1, device = 0;
 };
 
@@ -887,6 +911,71 @@ __global__ void k_xchg_sum(double *const *bufs, int world, size_t n)
     for (int r = 0; r < world; ++r) bufs[r][i] = a;
 }
 
+// the IPC backend's all-reduce: one workgroup of 1024 threads per rank (n <= max_doubles)
+constexpr long long kIpcTimeoutTicks = 1000000000;      // 10 s of s_memrealtime (100 MHz): the start-up skew between rank processes (code-object loads of a first launch) included
+__global__ __launch_bounds__(1024) void k_ipc_allreduce(double *buf, size_t n, IpcPeers peers, int rank, int world, size_t max_doubles, long long epoch, int *fault)
+{
+    const int parity = (int)(epoch & 1);
+    const size_t slot = ((size_t)parity * world + rank) * max_doubles, flags = 2 * (size_t)world * max_doubles;
+    for (int p = 0; p < world; ++p) {
+        double *dst = peers.base[p] + slot;
+        for (size_t i = threadIdx.x; i < n; i += 1024) __builtin_nontemporal_store(buf[i], dst + i);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // (system scope: my stores are visible wherever the flag is)
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        long long *f = reinterpret_cast<long long *>(peers.base[threadIdx.x] + flags) + (size_t)parity * world + rank;
+        __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __shared__ int s_late;
+    if (threadIdx.x == 0) s_late = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        const long long *f = reinterpret_cast<const long long *>(peers.base[rank] + flags) + (size_t)parity * world + threadIdx.x;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > kIpcTimeoutTicks) { s_late = 1; break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (s_late) { if (threadIdx.x == 0) __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    const double *mine = peers.base[rank] + (size_t)parity * world * max_doubles;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        double a = 0.0;
+        for (int r = 0; r < world; ++r) a += __builtin_nontemporal_load(mine + (size_t)r * max_doubles + i);     // rank order: every rank receives the same bits
+        buf[i] = a;
+    }
+}
+
+// sum all-reduce of n doubles (in place) over the ranks of a multi-process communicator, on `stream`
+static int comm_allreduce(tscm_comm *c, double *buf, size_t n, hipStream_t stream)
+{
+    if (c->ipc) {
+        tscm_ipc *x = c->ipc;
+        if (!x->connected) return fail(TSCM_E_INVALID, "tscm_comm_ipc_connect has not been called");
+        IpcPeers peers{};
+        for (int r = 0; r < x->world; ++r) peers.base[r] = static_cast<double *>(x->mapped[r]);
+        for (size_t off = 0; off < n; off += x->max_doubles) {
+            const size_t m = std::min(x->max_doubles, n - off);
+            hipLaunchKernelGGL(k_ipc_allreduce, dim3(1), dim3(1024), 0, stream, buf + off, m, peers, x->rank, x->world, x->max_doubles, ++x->count, x->d_fault);
+        }
+        return 0;
+    }
+    NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, c->comm, stream));
+    return 0;
+}
+// after a synchronisation: did an IPC exchange give up on a peer?
+static int comm_check(tscm_comm *c)
+{
+    if (!c || !c->ipc) return 0;
+    int f = 0;
+    HIP_TRY(hipMemcpy(&f, c->ipc->d_fault, sizeof(int), hipMemcpyDeviceToHost));
+    if (f) return fail(TSCM_E_RCCL, "IPC exchange: a peer rank did not arrive within the bound (failed or gone)");
+    return 0;
+}
+
 struct LmRun {
     std::vector<tscm_solver *> m;
     bool separate_control() const { return m[0]->comm != nullptr; }
@@ -908,7 +997,7 @@ static int exchange(LmRun &run, bool t_buffer)
     }
     double *buf = t_buffer ? s0->S.T : s0->S.H_stage;
     if (int rc = timed_begin(s0, t_buffer ? 1 : 2, s0->stream, &e1)) return rc;
-    NCCL_TRY(ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, s0->comm->comm, s0->stream));
+    if (int rc = comm_allreduce(s0->comm, buf, n, s0->stream)) return rc;
     if (e1) HIP_TRY(hipEventRecord(e1, s0->stream));
     return 0;
 }
@@ -1118,7 +1207,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         s->graph_order = (opt.exec_flags & TSCM_EXEC_GRAPH_REDUCED_ORDER) != 0 || (s->solve_variant == 0 && s->nd);
         s->t_epoch = 0;
     }
-    if (s0->comm && !s0->comm->group && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
+    if (s0->comm && !s0->comm->group && !s0->comm->ipc && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
     if (s0->comm && s0->comm->group) {
         // a local group runs on ONE stream: lock step by stream order, no events
         tscm_local_group *g = s0->comm->group;
@@ -1189,6 +1278,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     }
     if ((rc = sync_stream(s0))) return rc;
     for (tscm_solver *s : run.m) if (s->stream != s0->stream) HIP_TRY(hipStreamSynchronize(s->stream));
+    if ((rc = comm_check(s0->comm))) return rc;
     const double t1 = wall();
     HIP_TRY(hipGetLastError());
     for (size_t r = 0; r < run.m.size(); ++r) {
@@ -1278,10 +1368,10 @@ extern "C" int tscm_solver_gather_boards(tscm_solver *s, double *board_rt)
         if (int rc = tscm_solver_download_params(s, nullptr, nullptr, mine.data())) return rc;     // owned boards at their own positions
         HIP_TRY(hipMemcpy(full, mine.data(), n * sizeof(double), hipMemcpyHostToDevice));
     }
-    NCCL_TRY(ncclAllReduce(full, full, n, ncclDouble, ncclSum, s->comm_reg->comm, s->stream));
+    if (int rc = comm_allreduce(s->comm_reg, full, n, s->stream)) return rc;
     HIP_TRY(hipMemcpyAsync(board_rt, full, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return 0;
+    return comm_check(s->comm_reg);
 }
 
 extern "C" int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *sum)
@@ -1560,13 +1650,57 @@ extern "C" int tscm_comm_create_local(int world, int device, tscm_comm **out)
     return 0;
 }
 
+static_assert(sizeof(hipIpcMemHandle_t) <= TSCM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t larger than the ABI buffer");
+
+extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_doubles, tscm_comm **out, unsigned char handle[TSCM_IPC_HANDLE_BYTES])
+{
+    if (!out || !handle || world < 1 || world > kIpcMaxWorld || rank < 0 || rank >= world || max_doubles == 0) return fail(TSCM_E_INVALID, "bad communicator arguments (IPC: up to 16 ranks)");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<tscm_comm> c(new tscm_comm);
+    std::unique_ptr<tscm_ipc> x(new tscm_ipc);
+    c->rank = rank; c->world = world; c->device = device;
+    x->rank = rank; x->world = world; x->max_doubles = (max_doubles + 1) & ~(size_t)1;
+    if (hipMalloc(&x->own, x->total_bytes()) != hipSuccess) return fail(TSCM_E_NOMEM, "hipMalloc of the exchange buffer failed");
+    if (hipMalloc(reinterpret_cast<void **>(&x->d_fault), sizeof(int)) != hipSuccess) { (void)hipFree(x->own); return fail(TSCM_E_NOMEM, "hipMalloc failed"); }
+    HIP_TRY(hipMemset(x->own, 0, x->total_bytes()));
+    HIP_TRY(hipMemset(x->d_fault, 0, sizeof(int)));
+    HIP_TRY(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, x->own));
+    std::memset(handle, 0, TSCM_IPC_HANDLE_BYTES);
+    std::memcpy(handle, &h, sizeof(h));
+    x->mapped[rank] = x->own;
+    c->ipc = x.release();
+    *out = c.release();
+    return 0;
+}
+
+extern "C" int tscm_comm_ipc_connect(tscm_comm *c, const unsigned char *handles)
+{
+    if (!c || !c->ipc || !handles) return fail(TSCM_E_INVALID, "not an IPC communicator");
+    tscm_ipc *x = c->ipc;
+    if (x->connected) return fail(TSCM_E_INVALID, "already connected");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int r = 0; r < x->world; ++r) {
+        if (r == x->rank) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)TSCM_IPC_HANDLE_BYTES * r, sizeof(h));
+        HIP_TRY(hipIpcOpenMemHandle(&x->mapped[r], h, hipIpcMemLazyEnablePeerAccess));
+    }
+    x->connected = true;
+    return 0;
+}
+
 extern "C" int tscm_comm_info(const tscm_comm *c, int *rank, int *world, int *backend_ranks)
 {
     if (!c) return fail(TSCM_E_INVALID, "communicator is NULL");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
     if (backend_ranks) {
-        int n = c->group ? c->group->world : 0;
+        int n = c->group ? c->group->world : c->ipc && c->ipc->connected ? c->ipc->world : 0;
         if (c->comm) NCCL_TRY(ncclCommCount(c->comm, &n));      // what RCCL itself reports for the communicator
         *backend_ranks = n;
     }
@@ -1577,6 +1711,14 @@ extern "C" void tscm_comm_destroy(tscm_comm *c)
 {
     if (!c) return;
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->ipc) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->mapped[r]) (void)hipIpcCloseMemHandle(c->ipc->mapped[r]);
+        (void)hipFree(c->ipc->own);
+        (void)hipFree(c->ipc->d_fault);
+        delete c->ipc;
+    }
     if (c->group && --c->group->refs == 0) {
         (void)hipSetDevice(c->group->device);
         (void)hipStreamSynchronize(c->group->stream);

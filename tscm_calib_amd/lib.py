@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libtscm_hip.so")
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 MAX_ITERATIONS = 255
 # tscm_options.exec_flags (tscm.h)
 EXEC_SEPARATE_T_REDUCE = 1
@@ -117,7 +118,7 @@ EXPORTS = [
     "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
     "tscm_reprojection_error", "tscm_comm_unique_id", "tscm_comm_create", "tscm_comm_destroy",
-    "tscm_shard_frames", "tscm_solver_create_sharded", "tscm_comm_create_local", "tscm_solver_solve_group",
+    "tscm_shard_frames", "tscm_solver_create_sharded", "tscm_comm_create_local", "tscm_comm_ipc_open", "tscm_comm_ipc_connect", "tscm_solver_solve_group",
     "tscm_solver_gather_boards", "tscm_comm_info", "tscm_rig_init", "tscm_yaml_format", "tscm_yaml_write", "tscm_yaml_parse",
     "tscm_yaml_read", "tscm_build_maps", "tscm_estimate_focal", "tscm_poses_from_r1r2t",
     "tscm_estimate_extrinsic", "tscm_corners_write", "tscm_corners_read", "tscm_corners_free",
@@ -160,6 +161,8 @@ def lib():
     L.tscm_solver_create.argtypes = [C.POINTER(CProblem), C.c_int, C.POINTER(vp)]
     L.tscm_solver_create_sharded.argtypes = [C.POINTER(CProblem), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.tscm_comm_create_local.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.tscm_comm_ipc_open.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_ubyte)]
+    L.tscm_comm_ipc_connect.argtypes = [vp, C.POINTER(C.c_ubyte)]
     L.tscm_solver_solve_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(COptions), C.POINTER(CSummary), C.c_int]
     L.tscm_solver_gather_boards.argtypes = [vp, dp]
     L.tscm_comm_info.argtypes = [vp, ip, ip, ip]

@@ -147,6 +147,12 @@ class SideChannel:
             return payload
         return _recv(self._hub)
 
+    def allgather_bytes(self, payload: bytes) -> list[bytes]:
+        """Bytes of every rank to everyone, in rank order (the IPC back-end's memory handles)."""
+        vals = self.gather(payload.hex())
+        out = self.bcast(json.dumps(vals).encode() if self.rank == 0 else None)
+        return [bytes.fromhex(x) for x in json.loads(out.decode())]
+
     def barrier(self) -> None:
         self.gather(0)
         self.bcast(b"go")
