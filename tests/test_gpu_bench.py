@@ -82,3 +82,23 @@ def test_ipc_rank_processes_reproduce_the_local_group_bit_for_bit(hip_device):
     for l in lines:
         assert l["identical"] and l["iterations"] == 10
         assert set(l["fingerprint_ipc_ranks"]) == {l["fingerprint_local_group"]}
+
+
+def test_the_drivers_torchrun_command_with_two_ranks_on_this_device(hip_device):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`
+    -- the command the driver uses for N > 1 -- with both ranks on this device over the IPC exchange: one JSON line, from rank 0."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TSCM_BENCH_EXCHANGE"] = "ipc"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), BENCH, "--gpus", "2", "--config", "3", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["exchange"] == "ipc" and len(d["per_rank"]) == 2
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-6
