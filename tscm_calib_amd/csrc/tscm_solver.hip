@@ -1665,11 +1665,17 @@ extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_do
     x->rank = rank; x->world = world; x->max_doubles = (max_doubles + 1) & ~(size_t)1;
     if (hipMalloc(&x->own, x->total_bytes()) != hipSuccess) return fail(TSCM_E_NOMEM, "hipMalloc of the exchange buffer failed");
     if (hipMalloc(reinterpret_cast<void **>(&x->d_fault), sizeof(int)) != hipSuccess) { (void)hipFree(x->own); return fail(TSCM_E_NOMEM, "hipMalloc failed"); }
-    HIP_TRY(hipMemset(x->own, 0, x->total_bytes()));
-    HIP_TRY(hipMemset(x->d_fault, 0, sizeof(int)));
-    HIP_TRY(hipDeviceSynchronize());
     hipIpcMemHandle_t h;
-    HIP_TRY(hipIpcGetMemHandle(&h, x->own));
+    {
+        hipError_t e = hipMemset(x->own, 0, x->total_bytes());
+        if (e == hipSuccess) e = hipMemset(x->d_fault, 0, sizeof(int));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h, x->own);
+        if (e != hipSuccess) {
+            (void)hipFree(x->own); (void)hipFree(x->d_fault);
+            return fail(TSCM_E_HIP, std::string("IPC exchange buffer: ") + hipGetErrorString(e) + " (hipIpcGetMemHandle needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC)");
+        }
+    }
     std::memset(handle, 0, TSCM_IPC_HANDLE_BYTES);
     std::memcpy(handle, &h, sizeof(h));
     x->mapped[rank] = x->own;
