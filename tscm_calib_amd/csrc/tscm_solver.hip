@@ -915,6 +915,8 @@ __global__ void k_xchg_sum(double *const *bufs, int world, size_t n)
 constexpr long long kIpcTimeoutTicks = 1000000000;      // 10 s of s_memrealtime (100 MHz): the start-up skew between rank processes (code-object loads of a first launch) included
 __global__ __launch_bounds__(1024) void k_ipc_allreduce(double *buf, size_t n, IpcPeers peers, int rank, int world, size_t max_doubles, long long epoch, int *fault)
 {
+    // (a peer that has not arrived once is gone: the exchanges still enqueued behind the failed one do not wait for it again)
+    if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int parity = (int)(epoch & 1);
     const size_t slot = ((size_t)parity * world + rank) * max_doubles, flags = 2 * (size_t)world * max_doubles;
     for (int p = 0; p < world; ++p) {
