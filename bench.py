@@ -27,6 +27,9 @@ ncclUniqueId, the barriers and the max-over-ranks travel over a TCP side channel
 the only HIP runtime and RCCL in the process are the ones libtscm_hip.so links.  (Under a launcher whose ranks do NOT share a
 parent process -- a wrapper shell per rank, several nodes -- set TSCM_RDZV_NONCE to one value for all ranks of the launch: without it the
 side channel's handshake token contains the parent's process id, which keeps stale ranks of an earlier launch out.)
+TSCM_BENCH_EXCHANGE=ipc replaces RCCL by the library's IPC exchange back-end (tscm_comm_ipc_open): the rank processes may then
+share a device (rank r on device r mod n_devices) -- the multi-process path on a one-GPU box; the line says "exchange": "ipc" and
+that it is not a scaling measurement.  Without it, more ranks than devices is an error.
 
 Before anything is timed (all of it untimed, none of it skipping work inside the timed region): the device's fp64
 ceilings are measured (three dense kernels, ~70 ms: they are part of the roofline block anyway and leave the device
