@@ -334,7 +334,9 @@ def main():
     solver = Solver(full, device=device, rank=rank, world=world)          # H2D of this rank's observations + layout build
     t_create = time.perf_counter() - t_create
     comm = None
-    rccl_ranks = world if stub else 1
+    # rccl_ranks: what ncclCommCount reports -- 0 unless RCCL carries the exchange (no communicator on one GPU, none under
+    # TSCM_BENCH_EXCHANGE=ipc); exchange_ranks: the ranks of the exchange whatever the back-end
+    rccl_ranks, exchange_ranks = 0, (world if stub else 1)
     if multi and not stub:
         if exchange == "ipc":
             comm = api.Comm.ipc(rank, world, device, chan.allgather_bytes, n_cameras=full.n_cameras)
@@ -342,7 +344,8 @@ def main():
             uid = chan.bcast(api.Comm.unique_id() if rank == 0 else None)
             comm = api.Comm(uid, rank, world, device)
         solver.set_comm(comm)
-        rccl_ranks = comm.backend_ranks()
+        exchange_ranks = comm.backend_ranks()
+        rccl_ranks = exchange_ranks if exchange == "rccl" else 0
         # RCCL writes its version banner to the C stdout buffer at communicator creation; push it out now so that the
         # JSON line stays the LAST line of this program's output
         import ctypes
@@ -419,6 +422,10 @@ def main():
             "iteration0_evals_in_timed_region": math.ceil(args.steps / ITERS_PER_SOLVE),
             "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
             "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+            # the whole STEP against the same peak: the algorithmic flop of one LM iteration of the whole job (one fused
+            # evaluation of every corner; the Schur / solve / back-substitution launches add < 1 % and are not counted)
+            # over the wall time of a step on all N GPUs -- LM iterations/s follows this figure, not the kernel's `frac`
+            "iteration_frac": (full.n_corners * FLOP_PER_CORNER / (elapsed / args.steps) / 1e12) / (peak * world) if elapsed > 0 else 0.0,
         }
         if not stub and args.jacobian_fp32:
             # fp32-Jacobian tier: the contraction (836 flop per corner) runs on v_mfma_f32_16x16x4, the projection and
@@ -468,7 +475,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64 (fp32 Jacobian + fp32 MFMA contraction)" if args.jacobian_fp32 else "f64",
             "data": "synthetic",
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks, "exchange_ranks": exchange_ranks,
             "config": {"workload": f"BASELINE config {args.config}: {full.n_cameras} cams x "
                                    f"{full.meta.get('views_per_cam')} views/cam, {full.n_boards} frames, "
                                    f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta.get('seed')})"

@@ -75,8 +75,12 @@ int main(int argc, char **argv)
     }
     int n_bids = 0;
     for (int a = 0; a < C; ++a) for (int b = a; b < C; ++b) if (pair[a * C + b]) bid_of[a * C + b] = n_bids++;
-    NdPlan pl;
-    if (!nd_build_plan(C, ncols.data(), col0.data(), pair.data(), bid_of.data(), dense_only, pl)) { std::printf("{\"ok\": false, \"reason\": \"does not fit\"}\n"); return 0; }
+    // the two plans exactly as tscm_solver_create builds them (graph order with the dense plan as its fall-back)
+    NdPlan plans[2];
+    bool fell_back = false;
+    if (!nd_build_plans(C, ncols.data(), col0.data(), pair.data(), bid_of.data(), plans, &fell_back)) { std::printf("{\"ok\": false, \"reason\": \"does not fit\"}\n"); return 0; }
+    const NdPlan &pl = plans[dense_only ? 1 : 0];
+    fell_back = fell_back && !dense_only;
     // ---- a random SPD system on the padded columns with exactly this block structure ------------------------------------------
     const int n_pad = 16 * C;
     std::vector<double> A((size_t)n_pad * n_pad, 0.0), b(n_pad, 0.0);
@@ -243,8 +247,8 @@ int main(int argc, char **argv)
     for (int i = 0; i < 4 * NP; ++i) { const int pc = pl.pcol[i]; if (pc >= 0) { err = std::max(err, std::fabs(w[i] - x_ref[pc])); ref = std::max(ref, std::fabs(x_ref[pc])); } }
     int covered = 0;
     for (int i = 0; i < 4 * NP; ++i) if (pl.pcol[i] >= 0) ++covered;
-    std::printf("{\"ok\": %s, \"NP\": %d, \"phases\": %d, \"tiles\": %d, \"tpt\": %d, \"max_slots\": %d, \"n_lt\": %d, \"dense\": %s, \"free_cols\": %d, \"covered\": %d, \"rel_err\": %.3e, \"lds_bytes\": %zu, \"levels\": \"",
-                (!fail && covered == nf) ? "true" : "false", NP, pl.n_phases, nt, pl.tpt, pl.max_slots, pl.n_lt, pl.dense ? "true" : "false", nf, covered, ref > 0 ? err / ref : err, pl.lds_doubles * 8);
+    std::printf("{\"ok\": %s, \"NP\": %d, \"phases\": %d, \"tiles\": %d, \"tpt\": %d, \"max_slots\": %d, \"n_lt\": %d, \"dense\": %s, \"free_cols\": %d, \"covered\": %d, \"rel_err\": %.3e, \"lds_bytes\": %zu, \"fell_back\": %s, \"levels\": \"",
+                (!fail && covered == nf) ? "true" : "false", NP, pl.n_phases, nt, pl.tpt, pl.max_slots, pl.n_lt, pl.dense ? "true" : "false", nf, covered, ref > 0 ? err / ref : err, pl.lds_doubles * 8, fell_back ? "true" : "false");
     for (size_t l = 0; l < pl.levels.size(); ++l) { std::printf("%s", l ? "|" : ""); for (size_t i = 0; i < pl.levels[l].size(); ++i) std::printf("%s%d", i ? "," : "", pl.levels[l][i]); }
     std::printf("\"}\n");
     return 0;

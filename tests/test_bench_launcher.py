@@ -36,7 +36,11 @@ def test_bench_spawns_its_own_ranks():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 20 and d["scaling"] == "strong"
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "strong"
+    # the line says what carried the exchange: the stub has no RCCL in it (rccl_ranks = ncclCommCount, nothing else)
+    assert d["exchange_ranks"] == 2 and d["rccl_ranks"] == 0 and d["exchange"] == "stub"
+    # ... and what the whole step achieves against the peak next to the dominant kernel's own fraction
+    assert {"frac", "iteration_frac"} <= set(d["roofline"]) and 0 < d["roofline"]["iteration_frac"] < 1
     # the N > 1 line explains itself: what each rank had, what it computed, what the two collectives cost
     assert len(d["corners_per_rank"]) == 2 and sum(d["corners_per_rank"]) > 0
     assert len(d["rank_compute_us"]) == 2 and {"T", "H_stage", "per_step", "timed_every"} <= set(d["allreduce_ms"])

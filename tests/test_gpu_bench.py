@@ -30,7 +30,9 @@ def test_spawned_single_rank_matches_the_plain_run(hip_device):
     plain = _run({})
     dist = _run({"TSCM_BENCH_FORCE_DIST": "1"}, "--gpus", "1")
     assert plain["n_gpus"] == 1 and dist["n_gpus"] == 1
-    assert dist["rccl_ranks"] == 1                                  # ncclCommCount of the communicator the rank created
+    assert dist["rccl_ranks"] == 1 and dist["exchange_ranks"] == 1      # ncclCommCount of the communicator the rank created
+    assert plain["rccl_ranks"] == 0 and plain["exchange"] is None      # no communicator, no RCCL in the exchange
+    assert 0 < plain["roofline"]["iteration_frac"] < plain["roofline"]["frac"]
     for d in (plain, dist):
         r = d["roofline"]
         assert r["launches"] > 0 and r["avg_launch_ms"] > 0
@@ -61,7 +63,8 @@ def test_two_rank_processes_on_one_device_over_the_ipc_exchange(hip_device):
     ranks on one device).  Same natural solve as the plain run; the line says what it is."""
     plain = _run({})
     two = _run({"TSCM_BENCH_EXCHANGE": "ipc"}, "--gpus", "2")
-    assert two["n_gpus"] == 2 and two["exchange"] == "ipc" and two["rccl_ranks"] == 2
+    assert two["n_gpus"] == 2 and two["exchange"] == "ipc" and two["exchange_ranks"] == 2
+    assert two["rccl_ranks"] == 0                                   # RCCL carried nothing in this run: the line must not say it saw 2 ranks
     assert "rank processes on" in two["config"]["parallelism"]
     assert len(two["per_rank"]) == 2 and len(two["corners_per_rank"]) == 2
     assert two["natural_solve"]["iterations"] == plain["natural_solve"]["iterations"]

@@ -404,6 +404,24 @@ def test_reduced_solver_along_the_camera_pair_graph(hip_device, name):
         assert max(H.param_rel_err(pd, pg).values()) < 1e-8
 
 
+def test_eight_free_cameras_on_a_dense_incomplete_graph_take_the_dense_plan(hip_device):
+    """8 cameras, NO constant pose (legal API: gauge left to the LM damping), every camera pair but (0, 1) shares a board: the
+    graph plan's panel padding does not fit k_solve_nd's tile budget, the dense packing of the same 104 columns does
+    (tests/test_nd_plan.py) -- the solver must be created on the dense plan (round 4 refused the rig) and agree with the oracle
+    and with the explicitly dense order."""
+    pairs = [(a, b) for a in range(8) for b in range(a + 1, 8) if (a, b) != (0, 1)]
+    p = H.rig_with_pairs(8, pairs, frames_per_pair=2, seed=77)
+    p.cam_pose_constant[:] = 0
+    opts = dict(max_num_iterations=8)
+    pg, po, gs, os_ = _solve_both(p, **opts)
+    _cmp_trace(gs, os_, rtol=1e-5)
+    assert abs(gs["final_cost"] - os_["final_cost"]) <= 1e-5 * os_["final_cost"]
+    pd = p.copy().normalised()
+    with api.Solver(pd) as s:
+        ds = s.solve(exec_flags=lib.EXEC_DENSE_REDUCED_ORDER, **opts)
+    _cmp_trace(ds, gs, rtol=1e-9)
+
+
 def test_camera_without_views_and_constant_poses_in_a_six_camera_rig(hip_device):
     """k_solve_nd's plan leaves out a camera that has no views (no free columns: Ceres would not even see its blocks) and takes a
     constant pose as a 7-column block wherever it sits: a ring of the cameras 0, 1, 2, 4, 5 of a 6-camera rig -- camera 3 is seen by

@@ -34,12 +34,69 @@ def record(config):
             names = ["geometry", "MFMA u-rows", "v-row copy", "MFMA v-rows", "epilogue"]
             print("shader clocks per view and wave (mean over the waves, k_eval_gram4): " +
                   ", ".join(f"{nm} {ph[:, k].mean() / nv:.0f}" for k, nm in enumerate(names)) + f"; total {ph.sum(axis=1).mean() / nv:.0f}")
+        if hasattr(lib.lib(), "tscm_debug_wave_views"):
+            tv = np.zeros(32 * 8192, dtype=np.int64)
+            w = lib.lib().tscm_debug_wave_views(tv.ctypes.data_as(ctypes.c_void_p), 8192)
+            if w > 0:
+                fixed_cost(buf.reshape(-1, 4)[:n], tv[:w * 8192].reshape(-1, w)[:n])
     rows = []
     for w in range(n):
         hw, xcc, t0, t1 = (int(x) for x in buf[4 * w:4 * w + 4])
         if t1 > 0:
             rows.append((w // 4, w % 4, hw, xcc, t0, t1))
     return rows
+
+
+def fixed_cost(tl, tv):
+    """Where the time of a launch goes that is not per-view work (k_eval_gram4, -DTSCM_WAVE_TIMELINE): per wave the head
+    (start -> view loop -> first MFMA), every view's duration by its position in the chunk, the tail (last record stored ->
+    end of the loop -> camera tile handed on), and per SIMD the number of waves still in their view loop over the last
+    microseconds of the launch.  All stamps s_memrealtime (10 ns)."""
+    import numpy as np
+    ok = (tl[:, 3] > 0) & (tv[:, 0] > 0)
+    tl, tv = tl[ok], tv[ok]
+    t0 = tl[:, 2].min()
+    us = lambda a: (a - t0) / 100.0
+    start, loop, mfma1, end2, lastrec, end1 = us(tl[:, 2]), us(tv[:, 0]), us(tv[:, 1]), us(tv[:, 2]), us(tv[:, 3]), us(tl[:, 3])
+    views = tv[:, 4:]
+    nv = (views > 0).sum(axis=1)
+    def q(a):
+        return f"mean {a.mean():6.2f}  p10 {np.percentile(a, 10):6.2f}  median {np.median(a):6.2f}  p90 {np.percentile(a, 90):6.2f}  max {a.max():6.2f}"
+    print(f"fixed cost of the launch, {len(tl)} waves, views per wave {nv.min()}..{nv.max()}   [us]")
+    print(f"  kernel: first wave start 0.00, last wave start {start.max():.2f}, last view loop end {end1.max():.2f}, last wave end {end2.max():.2f}")
+    print(f"  wave start                          {q(start)}")
+    print(f"  head: start -> view loop            {q(loop - start)}")
+    print(f"  head: view loop -> first MFMA       {q(mfma1 - loop)}")
+    print(f"  first MFMA at                       {q(mfma1)}")
+    nmax = int(nv.max())
+    for i in range(nmax):
+        have = nv > i
+        nxt = np.where(nv > i + 1, views[:, min(i + 1, views.shape[1] - 1)], tl[:, 3])
+        if i + 1 >= views.shape[1]:
+            break
+        d = (nxt[have] - views[have, i]) / 100.0
+        print(f"  view {i:2d} duration ({have.sum():4d} waves)      {q(d)}")
+    print(f"  last record stored at               {q(lastrec)}")
+    print(f"  view loop ends at                   {q(end1)}")
+    print(f"  tail: loop end -> tile handed on    {q(end2 - end1)}")
+    print(f"  wave: in the view loop              {q(end1 - loop)}")
+    print(f"  wave: whole                         {q(end2 - start)}")
+    # waves of a SIMD still in their view loop, against time
+    import collections
+    simd = collections.defaultdict(list)
+    for i in range(len(tl)):
+        hw, xcc = int(tl[i, 0]), int(tl[i, 1])
+        simd[(xcc & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3)].append(i)
+    tend = end1.max()
+    print("  waves of a SIMD still in their view loop (mean over the SIMDs in use; a full SIMD holds 4):")
+    for dt in (10, 8, 6, 5, 4, 3, 2, 1.5, 1, 0.5):
+        t = tend - dt
+        cnt = [sum(1 for i in v if loop[i] <= t < end1[i]) for v in simd.values()]
+        print(f"    {dt:4.1f} us before the last loop end: {np.mean(cnt):.2f}   (SIMDs with 0/1/2/3/4: {[cnt.count(k) for k in range(5)]})")
+    print("  ... and from the start:")
+    for t in (0.5, 1, 1.5, 2, 3, 4, 5, 6, 8):
+        cnt = [sum(1 for i in v if mfma1[i] <= t) for v in simd.values()]
+        print(f"    {t:4.1f} us after the first wave start: waves past their first geometry {np.mean(cnt):.2f} per SIMD")
 
 
 def main():

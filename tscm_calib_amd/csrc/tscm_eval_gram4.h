@@ -115,6 +115,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     const long long tl_t0 = wall_clock64();
     const int tl_iter = S.ctrl->iteration;
     long long tl_ph[5] = { 0, 0, 0, 0, 0 };      // shader clocks per phase, summed over the chunk: geometry, MFMA u, copy, MFMA v, epilogue
+    // wall-clock stamps (10 ns) of this wave: [0] view loop reached, [1] first MFMA, [2] the wave's very end (camera tile handed
+    // on; written at the end of the kernel), [3] last record stored, [4 + i] start of view i (i < kTlViews)
+    long long tl_w[4] = { 0, 0, 0, 0 };
+    int tl_nv = 0;
 #define TL_STAMP(var) const long long var = (long long)__builtin_readcyclecounter()
 #define TL_ADD(k, a, b) tl_ph[k] += (b) - (a)
 #else
@@ -179,6 +183,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         if (b == 2 && i == 3 && j < 3) o6 = W(7, 3 + j);
     }
     int off_next = vb < ve ? P.view_obs[vb] : 0;
+#ifdef TSCM_WAVE_TIMELINE
+    tl_w[0] = wall_clock64();
+    const bool tl_on = lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves;
+#endif
     for (int vbase = vb; vbase < ve; vbase += 64) {
     const int vend = min(ve, vbase + 64);
     int m_cnt = 0, m_slot = 0;
@@ -196,6 +204,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));      // priority by progress: see k_eval_gram
 #endif
         TL_STAMP(ts0);
+#ifdef TSCM_WAVE_TIMELINE
+        if (tl_on && tl_nv < kTlViews) g_tlv[(size_t)(4 + kTlViews) * chunk + 4 + tl_nv] = wall_clock64();
+        ++tl_nv;
+#endif
         const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * ((ablate & 8) ? vb : view));      // (ablate 8: every view reads the chunk's first constant record: scalar-cache hits)
         auto VC = [&](int k) { return vcs[k]; };
         const bool valid = lane < cnt;
@@ -222,6 +234,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         prev_nv = cnt;
         wave_lds_fence();
         TL_STAMP(ts1);
+#ifdef TSCM_WAVE_TIMELINE
+        if (tl_nv == 1) tl_w[1] = wall_clock64();
+#endif
         double accU[3] = { 0.0, 0.0, 0.0 }, accV[3] = { 0.0, 0.0, 0.0 };
         if (!(ablate & 1)) gram4_full(aN, aR, aB, accU);
         wave_lds_fence();
@@ -259,6 +274,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         }
 #ifdef TSCM_WAVE_TIMELINE
         { TL_STAMP(ts5); TL_ADD(0, ts0, ts1); TL_ADD(1, ts1, ts2); TL_ADD(2, ts2, ts3); TL_ADD(3, ts3, ts4); TL_ADD(4, ts4, ts5); }
+        if (view + 1 == ve) tl_w[3] = wall_clock64();
 #endif
     }
     }   // block of <= 64 views
@@ -269,6 +285,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         g_timeline[4 * chunk + 2] = tl_t0;
         g_timeline[4 * chunk + 3] = wall_clock64();
         for (int k = 0; k < 5; ++k) g_phase[5 * chunk + k] = tl_ph[k];
+        for (int k = 0; k < 4; ++k) g_tlv[(size_t)(4 + kTlViews) * chunk + k] = tl_w[k];
     }
 #endif
     // the camera tile leaves in the 16x16 layout and column numbering of k_eval_gram (both triangles: every entry is
@@ -288,4 +305,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         part[t] = (lds_all[t] + lds_all[st + t]) + (lds_all[2 * st + t] + lds_all[3 * st + t]);
         part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
     }
+#ifdef TSCM_WAVE_TIMELINE
+    if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) g_tlv[(size_t)(4 + kTlViews) * chunk + 2] = wall_clock64();     // [2]: the wave's very end (camera tile handed on)
+#endif
 }

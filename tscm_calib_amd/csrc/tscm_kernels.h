@@ -588,6 +588,8 @@ __device__ __forceinline__ void corner_geometry(double x, double y, double ou, d
 constexpr int kTimelineWaves = 8192;
 __device__ long long g_timeline[4 * kTimelineWaves];     // per wave of k_eval_gram: HW_ID, XCC_ID, start, end (10 ns ticks)
 __device__ long long g_phase[5 * kTimelineWaves];        // per wave of k_eval_gram4: shader clocks per phase, summed over its views
+constexpr int kTlViews = 12;
+__device__ long long g_tlv[(4 + kTlViews) * kTimelineWaves];   // per wave of k_eval_gram4: wall-clock stamps of its head, tail and views (see there)
 // per workgroup of the six kernels of an LM iteration (iteration 5): start, end of its thread 0 in 10 ns ticks
 // (tscm_debug_kernel_timeline, tools/kernel_timeline.py: launch gaps, dispatch ramps and tails between the kernels)
 constexpr int kKtlKernels = 6, kKtlGroups = 2048;

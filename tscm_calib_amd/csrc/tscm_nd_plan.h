@@ -310,4 +310,16 @@ inline bool nd_build_plan(int C, const int *ncols, const int *col0, const unsign
     return true;
 }
 
+// The two plans a solver keeps: [0] along the camera-pair graph, [1] the whole system as one dense block.  The graph plan pads
+// every camera block to whole panels, so a dense but incomplete pair graph of 8 free cameras can exceed the tile budget that
+// the dense packing of the same system meets: such a graph is solved on the dense plan (fell_back).  False only if the dense
+// plan does not fit either.
+inline bool nd_build_plans(int C, const int *ncols, const int *col0, const unsigned char *pair, const int *bid_of, NdPlan (&pl)[2], bool *fell_back = nullptr)
+{
+    if (fell_back) *fell_back = false;
+    if (!nd_build_plan(C, ncols, col0, pair, bid_of, /*dense_only=*/true, pl[1])) return false;
+    if (!nd_build_plan(C, ncols, col0, pair, bid_of, /*dense_only=*/false, pl[0])) { pl[0] = pl[1]; if (fell_back) *fell_back = true; }
+    return true;
+}
+
 }  // namespace tscm

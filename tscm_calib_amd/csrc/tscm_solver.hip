@@ -704,9 +704,12 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if (s->solve_variant <= 1) {
         int ncols[kMaxCamLds], col0[kMaxCamLds];
         for (int m = 0; m < C; ++m) { ncols[m] = cam_active[m] ? (cam_const[m] ? kFA - 6 : kFA) : 0; col0[m] = 16 * m + (cam_const[m] ? 6 : 0); }
+        // two plans: [0] along the camera-pair graph, [1] the whole system as one dense block.  A graph whose per-camera panel
+        // padding does not fit the tile budget (dense but incomplete pair graphs of 8 free cameras) is solved on the dense plan;
+        // only a system that fits neither is refused
+        if (!nd_build_plans(C, ncols, col0, pair_present.data(), bid_of.data(), s->plan))
+            return fail(TSCM_E_UNSUPPORTED, "internal error: the reduced system does not fit the register/LDS solver");
         for (int v = 0; v < 2; ++v) {
-            if (!nd_build_plan(C, ncols, col0, pair_present.data(), bid_of.data(), /*dense_only=*/v == 1, s->plan[v]))
-                return fail(TSCM_E_UNSUPPORTED, "internal error: the reduced system does not fit the register/LDS solver");
             const NdPlan &pl = s->plan[v];
             // (host replica check: the plan's columns are exactly the free columns)
             std::vector<int> cols;
@@ -725,17 +728,24 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
             if ((rc = dev_upload(s, &s->d_nd_tab[v], pl.tab))) return rc;
             if ((rc = dev_upload(s, &s->d_nd_bs[v], pl.bs_tab))) return rc;
             s->lds_nd[v] = sizeof(double) * pl.lds_doubles;
+        }
+        {
+            // ONE dynamic-LDS bound for the four instantiations (either plan may be launched, with or without riders), set
+            // before the occupancy queries that depend on it
+            const size_t lds_max = std::max(std::max(s->lds_nd[0], s->lds_nd[1]), s->lds_bs);
+            if (lds_max > 64 * 1024) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+            }
+        }
+        for (int v = 0; v < 2; ++v) {
             // workgroups of the fused launch that are resident at once: the back-substitution workgroups that ride in it WAIT
             // for the solver workgroup, so only as many are put there as fit the chip next to it (and the T producers)
             const size_t lds = std::max(s->lds_nd[v], s->lds_bs);
-            if (lds > 64 * 1024) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_nd<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            }
             int per_cu = 0;
-            if (pl.tpt == 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<1, true>), kNdThreads, lds));
+            if (s->plan[v].tpt == 1) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<1, true>), kNdThreads, lds));
             else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_nd<2, true>), kNdThreads, lds));
             s->nd_resident[v] = per_cu * prop.multiProcessorCount;
         }
@@ -1090,11 +1100,11 @@ static int enqueue_iteration(LmRun &run)
             if (n_prod || n_bs) {
                 const size_t lds = std::max(s->lds_nd[v], n_bs ? s->lds_bs : (size_t)0);
                 const dim3 grid(1 + n_prod + n_bs);
-                if (two) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
-#ifdef TSCM_ND_TWICE     // experiment: the same launch again (same inputs, same outputs): what a warm instruction cache / L2 would buy
-                if (two && !n_bs) hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
-#endif
-                else hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                if (two) {
+                    hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                } else {
+                    hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                }
             } else {
                 if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
                 else hipLaunchKernelGGL((k_solve_nd<1, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
@@ -1768,6 +1778,13 @@ extern "C" int tscm_debug_control_stamps(long long *out)
     if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_ktlx), sizeof(long long) * 32) != hipSuccess) return TSCM_E_HIP;
     return 32;
+}
+extern "C" int tscm_debug_wave_views(long long *out, int max_waves)
+{
+    const int n = std::min(max_waves, tscm::kTimelineWaves);
+    if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_tlv), sizeof(long long) * (4 + tscm::kTlViews) * (size_t)n) != hipSuccess) return TSCM_E_HIP;
+    return 4 + tscm::kTlViews;
 }
 extern "C" int tscm_debug_wave_phases(long long *out, int max_waves)
 {
