@@ -3,7 +3,8 @@
 libtscm_hip.so (before / after a change that must not move a bit -- layout changes, scheduling changes) and compare the
 lines.  Per problem: iterations, accept/reject pattern, SHA-256 of the per-iteration costs and of the final parameters.
 
-    python tools/regress_bits.py            (GPU box)"""
+    python tools/regress_bits.py            (GPU box)
+    python tools/regress_bits.py --check    ... and compare with tools/regress_bits.expected: exit code 1 and the differing lines on a mismatch"""
 import hashlib
 import os
 import sys
@@ -28,7 +29,13 @@ def run(name, p, **opts):
     its = s["iterations"]
     pattern = "".join("A" if it["step_is_successful"] else ("r" if it["step_is_valid"] else "x") for it in its[1:])
     costs = [it["cost"] for it in its] + [s["final_cost"]]
-    print(f"{name:28s} it {s['num_iterations']:3d} {pattern:52s} costs {fp(costs)} params {fp(p.intr, p.cam_rt, p.board_rt)}", flush=True)
+    line = f"{name:28s} it {s['num_iterations']:3d} {pattern:52s} costs {fp(costs)} params {fp(p.intr, p.cam_rt, p.board_rt)}"
+    LINES.append(line)
+    if "--check" not in sys.argv:
+        print(line, flush=True)
+
+
+LINES = []
 
 
 def main():
@@ -47,6 +54,13 @@ def main():
     run("mixed visibility forced", helpers.mixed_visibility_rig(seed=9), **forced)
     run("rig 12 cams", helpers.small_rig(12, 8, 3))
     run("config3 fp32 jacobian", synth.make_config(3), jacobian_fp32=1)
+    if "--check" in sys.argv:
+        want = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "regress_bits.expected")).read().splitlines()
+        bad = [(a, b) for a, b in zip(LINES, want) if a.rstrip() != b.rstrip()]
+        for a, b in bad:
+            print("got      " + a + "\nexpected " + b)
+        print(f"regress_bits: {len(LINES) - len(bad)} of {len(want)} fingerprints as expected")
+        sys.exit(1 if bad or len(LINES) != len(want) else 0)
 
 
 if __name__ == "__main__":

@@ -88,7 +88,7 @@ __device__ __forceinline__ void gram4_prime(unsigned aN, unsigned aR, unsigned a
 }
 __device__ __forceinline__ void gram4_full(unsigned aN, unsigned aR, unsigned aB, double (&acc)[3])
 {
-    constexpr int D = 2;
+    constexpr int D = 2;      // (round 5: 1, 2, 3 and 4 k-steps ahead measure the same to 0.1 us -- the MFMA phases do not wait for the LDS)
     double n[kG4KS], r[kG4KS], b[kG4KS];
     gram4_prime<kG4KS, D>(aN, aR, aB, n, r, b);
     gram4_steps<kG4KS, D>(aN, aR, aB, n, r, b, acc);
@@ -133,9 +133,18 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     double *bxy = lds + kG4Tile;
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
-    const int cam = P.chunk_cam[chunk];
-    for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
-    const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
+    // Head in TWO dependent round trips (round 5; it was six: control block | board points, twice | view range | camera
+    // constants | view metadata | observations -- 7 us from a wave's start to its first MFMA, with every wave of the chip in
+    // the same place at the same time).  Trip 1, scalar: the control block and the chunk's 16-byte descriptor; vector: the
+    // lane's board point.  Trip 2, everything that hangs on the descriptor at once: R_c, the metadata of the chunk's first
+    // 64 views, the first view's observations (all 64 lanes: a lane without a corner reads the next view's value or, past
+    // the end, zero, and never uses it), and one dword of every 64-byte line of the first view's and of the camera's
+    // constants through the SCALAR cache, so that the geometry's scalar loads hit there.
+    const v4i cd = *(const v4i __attribute__((address_space(4))) *)(const void *)(P.chunk_desc + chunk);
+    const int cam = cd[0], vb = cd[1], ve = cd[2];
+    const d2 my_xy = *reinterpret_cast<const d2 *>(P.board_xy + 2 * min(lane, P.n_points - 1));
+    double *const cc_buf[2] = { S.cconst[0], S.cconst[1] };
+    double *const rec_buf[2] = { S.rec[0], S.rec[1] };
     double camU[3] = { 0.0, 0.0, 0.0 }, camV[3] = { 0.0, 0.0, 0.0 };
     for (int i = lane; i < kG4Tile; i += 64) Fl[i] = 0.0;     // rows of lanes without a corner, the zero column, the padding
     int prev_nv = 0;
@@ -143,11 +152,21 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     int warm = 0;
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
-    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
-    const cptr4 ccs = (cptr4)(S.cconst[tgt] + kCStride * cam);
+    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(tgt ? rec_buf[1] : rec_buf[0], sizeof(double) * (size_t)kRec * P.V);
+    const cptr4 ccs = (cptr4)((tgt ? cc_buf[1] : cc_buf[0]) + kCStride * cam);
     auto CC = [&](int k) { return ccs[k]; };
     const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
     const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
+    int off_next = cd[3];
+    int m_cnt0 = 0, m_slot0 = 0;
+    if (vb + lane < min(ve, vb + 64)) { m_cnt0 = P.view_count[vb + lane]; m_slot0 = P.view_slot[vb + lane]; }
+    if (vb < ve) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
+    // the scalar cache's lines of the first view's 27 constants (4 lines) and of the camera's 48 (6 lines); retired in front of the loop
+    typedef const int __attribute__((address_space(4))) *cptr4i;
+    const cptr4i vc0 = (cptr4i)(S.vconst + (size_t)kVStride * min(vb, P.V - 1)), cc0 = (cptr4i)ccs;
+    // (as dwords on purpose: the same words loaded as doubles are merged with the geometry's own loads of them, which moves
+    // contraction decisions in the geometry and with them the last bits of 8 of the 13 fingerprints of tools/regress_bits.py)
+    const int kw0 = vc0[0], kw1 = vc0[16], kw2 = vc0[32], kw3 = vc0[48], kw4 = cc0[16], kw5 = cc0[32], kw6 = cc0[48], kw7 = cc0[64], kw8 = cc0[80];
     // ---- lane roles ------------------------------------------------------------------------------------------------
     // as a corner: row (t, k) of the tile
     double *fu_lo = Fl + (lane >> 2) * kG4Stride + (lane & 3), *fu_hi = Fl + (lane >> 2) * kG4Stride + ((lane & 3) ^ 2);
@@ -182,7 +201,8 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         if (b == 0 && j == 3 && i < 3) o6 = W(7, i);                         // ... fy
         if (b == 2 && i == 3 && j < 3) o6 = W(7, 3 + j);
     }
-    int off_next = vb < ve ? P.view_obs[vb] : 0;
+    if (lane < P.n_points) *reinterpret_cast<d2 *>(bxy + 2 * lane) = my_xy;
+    asm volatile("" :: "s"(kw0), "s"(kw1), "s"(kw2), "s"(kw3), "s"(kw4), "s"(kw5), "s"(kw6), "s"(kw7), "s"(kw8));
 #ifdef TSCM_WAVE_TIMELINE
     tl_w[0] = wall_clock64();
     const bool tl_on = lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves;
@@ -190,18 +210,24 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     for (int vbase = vb; vbase < ve; vbase += 64) {
     const int vend = min(ve, vbase + 64);
     int m_cnt = 0, m_slot = 0;
-    if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
-    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));
-    {
-        const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
-        if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
+    if (vbase == vb) { m_cnt = m_cnt0; m_slot = m_slot0; }
+    else {
+        if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
+        pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next);
     }
+    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));
     for (int view = vbase; view < vend; ++view) {
         const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
         off_next += cnt;
         wave_lds_fence();                       // the previous view's MFMA phase has finished with the tile
 #if TSCM_PRIO
-        set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));      // priority by progress: see k_eval_gram
+        // priority by progress: see k_eval_gram.  Short chunks (round 5): the last three views step down 3 | 2 | 1 (geometry), 0 (the
+        // rest of the last view), so that the four waves of a SIMD -- served oldest first among equals -- enter the last
+        // equal-priority stretch half a view apart, not a view and a quarter: -0.4 us at 10 views per wave; at 40 the stretch is a
+        // twentieth of the chunk either way and the wrap of the levels in front of it costs more than it brings (+1.6 us)
+        const int left = ve - 1 - view;
+        const bool tail_steps = left <= 2 && ve - vb <= 16;
+        set_prio(tail_steps ? left + 1 : 3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));
 #endif
         TL_STAMP(ts0);
 #ifdef TSCM_WAVE_TIMELINE
@@ -233,6 +259,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         }
         prev_nv = cnt;
         wave_lds_fence();
+#if TSCM_PRIO
+        if (tail_steps && left == 0) set_prio(0);
+#endif
         TL_STAMP(ts1);
 #ifdef TSCM_WAVE_TIMELINE
         if (tl_nv == 1) tl_w[1] = wall_clock64();

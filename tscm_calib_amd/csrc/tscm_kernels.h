@@ -178,6 +178,7 @@ struct DevProblem {
     const int *view_cam, *view_board, *view_obs, *view_count;
     const double *obs_u, *obs_v;
     const int *chunk_vb, *chunk_ve, *chunk_cam, *cam_chunk_ptr;
+    const int4 *chunk_desc;            // per chunk of the Gram kernels: camera, first view, end view, observation offset of the first view
     const int *bv_ptr;                 // board -> range of view SLOTS (records are stored board-major)
     const int *view_slot, *slot_cam;   // device view -> slot ; slot -> camera
     const int *slot_view, *slot_board; // slot -> device view ; slot -> board

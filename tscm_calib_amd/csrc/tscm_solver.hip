@@ -541,6 +541,13 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.chunk_vb, chunk_vb))) return rc;
     if ((rc = dev_upload(s, &P.chunk_ve, chunk_ve))) return rc;
     if ((rc = dev_upload(s, &P.chunk_cam, chunk_cam))) return rc;
+    {
+        // the same per chunk in ONE 16-byte record (+ the observation offset of its first view): the head of k_eval_gram4 is
+        // control block + descriptor, then the data
+        std::vector<int4> cd(chunk_vb.size());
+        for (size_t q = 0; q < cd.size(); ++q) cd[q] = make_int4(chunk_cam[q], chunk_vb[q], chunk_ve[q], chunk_vb[q] < V ? view_obs[chunk_vb[q]] : 0);
+        if ((rc = dev_upload(s, &P.chunk_desc, cd))) return rc;
+    }
     if ((rc = dev_upload(s, &P.cam_chunk_ptr, cam_chunk_ptr))) return rc;
     for (int q = 0; q <= kMaxCamLds; ++q) P.cam_wg[q] = cam_chunk_ptr[std::min(q, C)];
     if ((rc = dev_upload(s, &P.bv_ptr, bv_ptr))) return rc;
