@@ -69,8 +69,11 @@ HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
 CPU_BASELINE_ITERS = 8
-EVENT_STRIDE_MAX = 8                 # an event pair holds the stream for a few microseconds: long runs time every 8th launch
-MIN_TIMED_LAUNCHES = 8               # ... short runs time more of them, so that at least this many are measured
+EVENT_STRIDE_MAX = 8                 # an event pair holds the stream for ~11 us (6.4 in front of the launch, 4.6 behind it: kernel
+                                     # trace of the driver's command, profiles/r05_eval_fixed_cost.txt): long runs time every 8th launch
+MIN_TIMED_LAUNCHES = 4               # ... short runs time more of them, so that at least this many are measured.  (8 until round 5:
+                                     # at --steps 20 that was every second launch, 11 pairs = 6 us per step of measurement inside the
+                                     # timed region; the kernel's duration varies by +-0.3 us from launch to launch, 4-5 samples carry it)
 
 
 def event_stride(steps: int) -> int:

@@ -66,7 +66,7 @@ constexpr int kMaxLog = 256;
 
 // phase stamps of the fused kernels (make PHASES=1: -DTSCM_PHASE_PROFILE; s_memrealtime, 10 ns ticks; one line per
 // launch from workgroups 0 and 200 -- profiling builds only)
-#ifdef TSCM_PHASE_PROFILE
+#if defined(TSCM_PHASE_PROFILE) || defined(TSCM_WAVE_TIMELINE)
 #define PHASE_STAMP(var) const long long var = wall_clock64()
 #else
 #define PHASE_STAMP(var)
@@ -335,20 +335,20 @@ __device__ __forceinline__ void handoff_store(double *p, double v) { __hip_atomi
 __device__ __forceinline__ double handoff_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // the per-camera record of the evaluation target (doubles, then the same values as floats)
-__device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m)
+__device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m, const double *cam_rt, const double *intr)
 {
     double crt[3], Rc[9], a[9], wsm[3];
-    for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
+    for (int k = 0; k < 3; ++k) crt[k] = cam_rt[6 * m + k];
     const int small = camera_rotation_constants(crt, Rc, a, wsm);
     double *o = S.cconst[tgt] + kCStride * m;
     for (int k = 0; k < 9; ++k) o[k] = Rc[k];
-    for (int k = 0; k < 3; ++k) o[9 + k] = S.cam_rt[tgt][6 * m + 3 + k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = cam_rt[6 * m + 3 + k];
     for (int k = 0; k < 9; ++k) o[12 + k] = a[k];
     for (int k = 0; k < 3; ++k) o[21 + k] = wsm[k];
     o[24] = small ? 1.0 : 0.0;
     for (int k = 25; k < 39; ++k) o[k] = 0.0;
     double I[7];
-    for (int k = 0; k < 7; ++k) I[k] = S.intr[tgt][9 * m + k];
+    for (int k = 0; k < 7; ++k) I[k] = intr[9 * m + k];
     for (int k = 0; k < 6; ++k) o[39 + k] = I[k];
     const double oma = 1.0 - I[6];
     o[45] = I[6] / oma;
@@ -357,16 +357,16 @@ __device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, 
     float *of = reinterpret_cast<float *>(o + kCConst);
     for (int k = 0; k < kCConst; ++k) of[k] = (float)o[k];
 }
+__device__ __forceinline__ void write_camera_record(const DevState &S, int tgt, int m) { write_camera_record(S, tgt, m, S.cam_rt[tgt], S.intr[tgt]); }
 
 constexpr int kVStride = 48;      // doubles per view record in vconst: 27 doubles (+5 pad), then at byte 256 the same 27 values as
                                   // floats (read by the fp32-Jacobian kernel): 384 bytes
 constexpr int kVFloatOff = 32;    // offset of the float copy, in doubles
 constexpr int kVPrepThreads = 128;
 
-__global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevState S, int cand, int with_floats)
+// (the point's parameters come from explicit arrays: buffer `tgt` -- or, in the first launch of a solve, the registered start point)
+__device__ __forceinline__ void view_prep_body(const DevProblem &P, const DevState &S, int tgt, int with_floats, const double *cam_rt, const double *intr, const double *board_rt)
 {
-    if (S.ctrl->done) return;
-    const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
     __shared__ double st[kVPrepThreads][kVFloatOff + 1];    // the 27 (+5 pad) doubles of thread t in row t (pitch 33: conflict-free both ways)
     const int t = threadIdx.x;
     const int i = blockIdx.x * kVPrepThreads + t;
@@ -374,20 +374,20 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
         // self-contained (rotations recomputed per view: cheaper than a second launch + round trip)
         const int b = P.view_board[i], m = P.view_cam[i];
         double rt[6], bc[kBoardConst], Rc[9], dRc[27];
-        for (int k = 0; k < 6; ++k) rt[k] = S.board_rt[tgt][6 * b + k];
+        for (int k = 0; k < 6; ++k) rt[k] = board_rt[6 * b + k];
         board_constants(rt, bc);
         double crt[3];
-        for (int k = 0; k < 3; ++k) crt[k] = S.cam_rt[tgt][6 * m + k];
+        for (int k = 0; k < 3; ++k) crt[k] = cam_rt[6 * m + k];
         rotation_and_derivatives(crt, Rc, dRc);
         double *o = st[t];
-        view_point_constants(Rc, S.cam_rt[tgt] + 6 * m + 3, bc, rt + 3, o);
+        view_point_constants(Rc, cam_rt + 6 * m + 3, bc, rt + 3, o);
         for (int k = 0; k < 6; ++k) {           // six 3-vectors d -> R_c d
             const double d0 = bc[6 + 3 * k], d1 = bc[6 + 3 * k + 1], d2 = bc[6 + 3 * k + 2];
             for (int r = 0; r < 3; ++r) o[9 + 3 * k + r] = Rc[3 * r] * d0 + Rc[3 * r + 1] * d1 + Rc[3 * r + 2] * d2;
         }
         for (int k = kVConst; k < kVFloatOff; ++k) o[k] = 0.0;
     } else if (i < P.V + P.C) {
-        write_camera_record(S, tgt, i - P.V);
+        write_camera_record(S, tgt, i - P.V, cam_rt, intr);
     }
     __syncthreads();
     // the block's records leave as one contiguous, coalesced stream: vconst[view][32]
@@ -407,6 +407,13 @@ __global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevSt
             S.vconst[(size_t)kVStride * (v0 + v) + kVFloatOff + k] = __hiloint2double(__float_as_int(f1), __float_as_int(f0));
         }
     }
+}
+
+__global__ __launch_bounds__(kVPrepThreads) void k_view_prep(DevProblem P, DevState S, int cand, int with_floats)
+{
+    if (S.ctrl->done) return;
+    const int tgt = cand ? (S.ctrl->cur ^ 1) : S.ctrl->cur;
+    view_prep_body(P, S, tgt, with_floats, S.cam_rt[tgt], S.intr[tgt], S.board_rt[tgt]);
 }
 
 // tile column -> (parity mask) bookkeeping shared by the hot kernel's epilogue and k_finalize_eval.
@@ -607,6 +614,9 @@ struct KtlScope {
     }
 };
 #define KTL(id) KtlScope ktl_scope(id, S.ctrl)
+// per workgroup of k_schur_gram / k_backsub_prep (iteration 5): stamps of its phases (tscm_debug_phase_stamps, tools/phase_timeline.py)
+constexpr int kPhStamps = 8;
+__device__ long long g_phs[2 * kPhStamps * kKtlGroups];
 __device__ long long g_ktlx[32];         // stamps inside the workgroup that runs the control step (thread 0): kept in LDS
 __shared__ long long s_ktlx[32];         // and written out at the end (a global store in front of a barrier is waited for)
 #define KTLX(i, on) do { if ((on) && threadIdx.x == 0) s_ktlx[i] = wall_clock64(); } while (0)
@@ -1221,11 +1231,11 @@ __device__ __forceinline__ void finish_evaluation(const DevProblem &P, const Dev
 // The same step for a workgroup that only needs its OUTCOME (every workgroup of k_schur_gram but the extra one that
 // writes): of H only the gradient column and the cost entry of each camera enter the step -- 15 entries per camera, two
 // loads per thread straight from the finished sums instead of 16 KB through LDS and two barriers.  Hl: 256 C + kScal + 8.
-__device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int have_backsub, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
+__device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int init, int have_backsub, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
 {
     const int t = threadIdx.x;
     ControlPre pre;
-    control_prefetch(P, S, 0, pre, head);
+    control_prefetch(P, S, init, pre, head);
     // thread (camera m, a): H[m][a][kFR] for a < 14 (a = kFR = 13: the cost entry)
     const int m = min(t >> 4, P.C - 1), a = t & 15;
     const int fa = min(a, 13), ta = f_tile(fa), tb = f_tile(kFR), mk = f_mask(fa) & f_mask(kFR);
@@ -1234,7 +1244,7 @@ __device__ __forceinline__ void control_outcome(const DevProblem &P, const DevSt
     reduce_scalar_partials<false>(P, S, have_backsub, pre.c.lin_fail, scl, sm);
     if (t < 16 * P.C && a < 14) Hl[256 * m + a * 16 + kFR] = ((mk & 1) ? gu : 0.0) + ((mk & 2) ? gv : 0.0);
     __syncthreads();
-    control_step(P, S, 0, pre, sm, Hl, scl, nullptr, /*writer=*/false, out);
+    control_step(P, S, init, pre, sm, Hl, scl, nullptr, /*writer=*/false, out);
 }
 
 // One GPU: everything between the evaluation and the next Schur complement in ONE launch (round 3; before:
@@ -1272,17 +1282,6 @@ __global__ __launch_bounds__(256) void k_reduce_control(DevProblem P, DevState S
     finish_evaluation<true>(P, S, init, have_backsub, /*writer=*/true, Hl, Gall, sm, nullptr, S.ctrl);
     KTLX(8, true);
     KTLX_FLUSH();
-}
-
-// The control step of an evaluation whose reductions are complete, as a launch of its own: behind the LAST evaluation
-// of a solve when the steps in between are taken in the head of k_schur_gram (enqueue_eval / flush_pending_control).
-__global__ __launch_bounds__(256) void k_control_tail(DevProblem P, DevState S, int have_backsub)
-{
-    if (S.ctrl->done) return;
-    __shared__ double sm[256];
-    __shared__ double Hl[256 * kMaxCamLds + kScal + 8];
-    __shared__ double Gall[512 * kMaxCamLds];
-    finish_evaluation<false>(P, S, 0, have_backsub, true, Hl, Gall, sm, nullptr, S.ctrl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1481,6 +1480,10 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     PHASE_STAMP(tsk);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
+    // (ctl & 4: the evaluation whose step is taken here is the solve's INITIAL one -- IterationZero: no back-substitution behind it,
+    // the Jacobi scaling of the camera columns written by the extra workgroup)
+    const int ctl_init = (ctl >> 2) & 1;
+    ctl &= 3;
     const bool extra = ctl != 0 && blockIdx.x == 0;        // the workgroup that writes the control step's results, and nothing else
     const int cblk = ctl ? max((int)blockIdx.x - 1, 0) : (int)blockIdx.x;
     const int4 desc = P.bc_desc[chunk0 + cblk];
@@ -1533,8 +1536,8 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
             control_prefetch(P, S, 0, pre, head);
             control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, &s_ctl);
         } else {
-            if (extra) finish_evaluation<false>(P, S, 0, 1, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
-            else control_outcome(P, S, 1, scratch, scratch + kHl, &s_ctl, head);
+            if (extra) finish_evaluation<false>(P, S, ctl_init, !ctl_init, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
+            else control_outcome(P, S, ctl_init, !ctl_init, scratch, scratch + kHl, &s_ctl, head);
         }
         if (extra) {
             // thread 0 took the serial part of the step and committed it: the outcome, written through, then the epoch
@@ -1685,6 +1688,12 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] = (tiles[0][t][tid] + tiles[1][t][tid]) + (tiles[2][t][tid] + tiles[3][t][tid]);
+#ifdef TSCM_WAVE_TIMELINE
+    if (threadIdx.x == 0 && ktl_scope.on && (int)blockIdx.x < kKtlGroups) {
+        long long *o = g_phs + (size_t)kPhStamps * blockIdx.x;
+        o[0] = tsk; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = wall_clock64(); o[6] = nbd; o[7] = (int)blockIdx.x >= first_round;
+    }
+#endif
 #ifdef TSCM_PHASE_PROFILE
     if (threadIdx.x == 0 && (cblk == 0 || cblk == 200))
         printf("schur_gram wg %d: boards %d  head %lld  E sums %lld  factor %lld  gram %lld  tiles %lld [10 ns]\n", (int)blockIdx.x, nbd, ts0 - tsk, ts1 - ts0, ts2 - ts1, ts3 - ts2, wall_clock64() - ts3);
@@ -2403,6 +2412,12 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
         }
         __syncthreads();
     }
+#ifdef TSCM_WAVE_TIMELINE
+    if (threadIdx.x == 0 && S.ctrl->iteration == 5 && blk < kKtlGroups) {
+        long long *o = g_phs + (size_t)kPhStamps * (kKtlGroups + blk);
+        o[0] = ts0; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = wall_clock64(); o[5] = o[4]; o[6] = nbl; o[7] = 0;
+    }
+#endif
 #ifdef TSCM_PHASE_PROFILE
     if (threadIdx.x == 0 && (blk == 0 || blk == 200))
         printf("backsub_prep wg %d: W.yhat %lld  board solve %lld  view constants %lld [10 ns]\n", blk, ts1 - ts0, ts2 - ts1, wall_clock64() - ts2);
@@ -2576,16 +2591,22 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
 // ---------------------------------------------------------------------------------------------
 // the control block as the host set it up (kernel argument), the arrival counter of the fused T reduction at zero and,
 // with `reset`, the registered start point in buffer 0
-__global__ __launch_bounds__(256) void k_begin_solve(DevState S, CtrlHead head, int C, int B, const double *init_cam,
-                                                     const double *init_intr, const double *init_board, int reset)
+// The first launch of a solve also computes the constants of the initial evaluation (round 5: k_begin_solve + k_view_prep were
+// 4.8 + 8.0 us in front of every solve): the grid is k_view_prep's, every thread also moves its share of the start point into buffer 0, and the
+// constants are computed from where the start point IS (the registered arrays with `reset`, buffer 0 otherwise) -- nothing in
+// this launch reads what another of its workgroups writes.  The control block it installs has cur = 0, done = 0.
+__global__ __launch_bounds__(kVPrepThreads) void k_begin_view_prep(DevProblem P, DevState S, CtrlHead head, const double *init_cam, const double *init_intr,
+                                                                   const double *init_board, int reset, int with_floats)
 {
-    const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
+    const int i0 = blockIdx.x * kVPrepThreads + threadIdx.x, n = gridDim.x * kVPrepThreads;
     if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
-    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
-    if (!reset) return;
-    for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = init_cam[i];
-    for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = init_intr[i];
-    for (int i = i0; i < 6 * B; i += n) S.board_rt[0][i] = init_board[i];
+    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; }
+    if (reset) {
+        for (int i = i0; i < 6 * P.C; i += n) S.cam_rt[0][i] = init_cam[i];
+        for (int i = i0; i < 9 * P.C; i += n) S.intr[0][i] = init_intr[i];
+        for (int i = i0; i < 6 * P.B; i += n) S.board_rt[0][i] = init_board[i];
+    }
+    view_prep_body(P, S, 0, with_floats, reset ? init_cam : S.cam_rt[0], reset ? init_intr : S.intr[0], reset ? init_board : S.board_rt[0]);
 }
 
 // the accepted point lives in buffer `cur`: it becomes buffer 0 (what the caller downloads and the next resident solve
@@ -2595,6 +2616,43 @@ __global__ __launch_bounds__(256) void k_end_solve(DevState S, int C, int B)
     const int i0 = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
     if (i0 == 0) S.ctrl->t_end = wall_clock64();
     if (S.ctrl->cur == 0) return;
+    for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = S.cam_rt[1][i];
+    for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = S.intr[1][i];
+    for (int i = i0; i < 6 * B; i += n) S.board_rt[0][i] = S.board_rt[1][i];
+}
+
+// Last launch of a one-GPU solve whose last evaluation still waits for its control step (the steps in between were taken in
+// k_schur_gram's head): k_control_tail, k_end_solve and the copy of the control block to the host in ONE launch (round 5; they
+// were three, 10.4 + 5.0 + 4.1 us by rocprofv3 behind every solve).  Block 0 takes and commits the step, stamps the end of the
+// solve and writes the control block's head and the iteration log straight into the host's pinned copy; every other block
+// derives the step's OUTCOME itself (control_outcome on the snapshot, exactly like a workgroup of k_schur_gram: same inputs,
+// same bits, no hand-off) and moves its slice of the accepted point into buffer 0.
+__global__ __launch_bounds__(256) void k_finish_solve(DevProblem P, DevState S, int init, int have_backsub, int C, int B, Ctrl *host_ctrl)
+{
+    constexpr int kHl = 256 * kMaxCamLds + kScal + 8, kGall = 512 * kMaxCamLds;
+    __shared__ double sm[256];
+    __shared__ double Hl[kHl];
+    __shared__ CtlOut s_ctl;
+    const CtrlHead *head = S.ctrl_snap;          // (taken by k_reduce_stats: block 0 rewrites S.ctrl while the others may not have started)
+    if (blockIdx.x == 0) {
+        __shared__ double Gall[kGall];
+        finish_evaluation<false>(P, S, init, have_backsub, /*writer=*/true, Hl, Gall, sm, &s_ctl, head);
+        __syncthreads();
+        if (threadIdx.x == 0) S.ctrl->t_end = wall_clock64();
+        __threadfence();
+        __syncthreads();
+        // head + the log entries written so far, 8-byte words (the host's copy is pinned, device-visible memory)
+        const int n_log = min(max(__hip_atomic_load(&S.ctrl->n_log, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0), kMaxLog);
+        const int words = (int)((sizeof(CtrlHead) + sizeof(IterLog) * (size_t)n_log) / 8);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(S.ctrl);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(host_ctrl);
+        for (int i = threadIdx.x; i < words; i += 256) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    control_outcome(P, S, init, have_backsub, Hl, sm, &s_ctl, head);
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(s_ctl.cur) == 0) return;
+    const int i0 = (blockIdx.x - 1) * 256 + threadIdx.x, n = (gridDim.x - 1) * 256;
     for (int i = i0; i < 6 * C; i += n) S.cam_rt[0][i] = S.cam_rt[1][i];
     for (int i = i0; i < 9 * C; i += n) S.intr[0][i] = S.intr[1][i];
     for (int i = i0; i < 6 * B; i += n) S.board_rt[0][i] = S.board_rt[1][i];

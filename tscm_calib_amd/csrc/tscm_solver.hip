@@ -109,6 +109,7 @@ struct tscm_solver {
     double *d_init_cam = nullptr, *d_init_intr = nullptr, *d_init_board = nullptr;
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
+    Ctrl *d_h_ctrl = nullptr;           // ... and its address on the device (k_finish_solve writes the control block there itself)
     size_t lds_eval = 0, lds_eval32 = 0, lds_solve = 0, lds_gram = 0, lds_bs = 0;
     int bs_threads = 128;               // geometry of k_backsub_prep: 128 threads / 16 boards or 256 / 32
     int nv_chunk0[4] = { 0, 0, 0, 0 }, nv_chunks[4] = { 0, 0, 0, 0 };      // chunk ranges of k_schur_gram<NV>
@@ -117,7 +118,7 @@ struct tscm_solver {
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
     int schur_resident[4] = { 0, 0, 0, 0 };   // workgroups of k_schur_gram<NV> that are resident at once (occupancy x CUs): the first round of its grid
     int ctl_epoch = 0;                  // control steps taken in k_schur_gram's head in this solve so far
-    int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator)
+    int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator); + 4: the solve's initial evaluation
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0, withhold_next = 0; // this solve / the next one: fault injection (tscm_solver_debug_withhold_handoff)
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
@@ -685,6 +686,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     HIP_TRY(hipMemset(S.ctrl_snap, 0, sizeof(CtrlHead)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_h_ctrl), s->h_ctrl, 0));
 
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, rp == 58);
@@ -1022,7 +1024,7 @@ static int exchange(LmRun &run, bool t_buffer)
 }
 
 // evaluation of the target point: pose constants, Gram kernel, reductions, statistics (+ all-reduce + control)
-static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
+static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub, bool have_view_constants = false)
 {
     const bool sep = run.separate_control();
     const bool fused = !sep && run.m[0]->P.C <= kMaxCamLds;     // (rigs of more than 8 cameras: k_control as a launch of its own)
@@ -1030,13 +1032,15 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub)
         const DevProblem &P = s->P;
         DevState &S = s->S;
         // the constants of a candidate point were written by k_backsub_prep; the initial point needs them here
-        if (!have_backsub) hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
+        if (!have_backsub && !have_view_constants) hipLaunchKernelGGL(k_view_prep, dim3((P.V + P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, P, S, cand, s->f32_jacobian ? 1 : 0);
         if (int rc = launch_eval(s, cand)) return rc;
-        if (fused && s->ctl_in_schur && cand && !init) {
-            // ... or the reductions alone: the next k_schur_gram takes the control step in its head (flush_pending_control
-            // behind the last evaluation of the solve)
+        if (fused && s->ctl_in_schur && (cand || init)) {
+            // ... or the reductions alone: the next k_schur_gram takes the control step in its head (k_control_tail behind the
+            // last evaluation of the solve).  Round 5: the solve's INITIAL evaluation as well (eval_pending = 1 | 4: IterationZero
+            // in the head of the first Schur kernel) -- k_reduce_control's last workgroup cost every solve 18.4 us where
+            // k_reduce_stats takes 5.5 and the head 4.4
             hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
-            s->eval_pending = 1;
+            s->eval_pending = init ? 5 : 1;
             continue;
         }
         if (fused) {
@@ -1069,7 +1073,7 @@ static int enqueue_iteration(LmRun &run)
         const int ctl = s->eval_pending;                  // (ctl_in_schur: exactly one of the three variants below is launched)
         s->eval_pending = 0;
         if (P.n_slow) hipLaunchKernelGGL(k_schur_factor, dim3((P.n_slow + 255) / 256), dim3(256), 0, s->stream, P, S);
-        const int ce = ctl ? ++s->ctl_epoch : 0;
+        const int ce = ctl ? ++s->ctl_epoch : 0;          // (ctl: 1 one GPU | 2 communicator, + 4: the initial evaluation's step)
         if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce);
         if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce);
         if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce);
@@ -1262,12 +1266,13 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         h.opt.max_lm_diagonal = opt.max_lm_diagonal;
         h.opt.max_invalid = opt.max_num_consecutive_invalid_steps;
         h.opt.jacobi_scaling = opt.jacobi_scaling;
-        const int nb = reset ? std::min(256, (6 * std::max(s->B, s->C) + 255) / 256 + 1) : 1;
-        hipLaunchKernelGGL(k_begin_solve, dim3(nb), dim3(256), 0, s->stream, s->S, h, s->C, s->B, s->d_init_cam, s->d_init_intr, s->d_init_board, reset ? 1 : 0);
+        // ... and the constants of the initial evaluation (k_view_prep's work) in the same launch
+        hipLaunchKernelGGL(k_begin_view_prep, dim3((s->P.V + s->P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, s->P, s->S, h,
+                           s->d_init_cam, s->d_init_intr, s->d_init_board, reset ? 1 : 0, s->f32_jacobian ? 1 : 0);
     }
 
     int rc;
-    if ((rc = enqueue_eval(run, /*cand=*/0, /*init=*/1, /*have_backsub=*/0))) return rc;
+    if ((rc = enqueue_eval(run, /*cand=*/0, /*init=*/1, /*have_backsub=*/0, /*have_view_constants=*/true))) return rc;
     const int check_every = std::max(1, opt.check_every);
     bool done = false;
     for (int it = 1; it <= opt.max_num_iterations && !done; ++it) {
@@ -1279,19 +1284,20 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
             done = s0->h_ctrl->done != 0;
         }
     }
-    // the last evaluation's control step, if the steps were taken in k_schur_gram's head
-    for (tscm_solver *s : run.m)
-        if (s->eval_pending) {
-            if (s->eval_pending == 2) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 0);
-            else hipLaunchKernelGGL(k_control_tail, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 1);
-            s->eval_pending = 0;
-        }
-    // the accepted point into buffer 0 (k_end_solve), the control block and the iteration log to the host: enqueued
-    // behind the last iteration, ONE synchronisation for the whole solve
+    // The end of the solve, enqueued behind the last iteration -- ONE synchronisation for the whole solve: the last evaluation's
+    // control step if the steps were taken in k_schur_gram's head, the accepted point into buffer 0, the control block and the
+    // iteration log to the host.  One GPU: one launch (k_finish_solve); communicator: k_control, k_end_solve and a copy.
     static_assert(sizeof(Ctrl) == sizeof(CtrlHead) + sizeof(IterLog) * kMaxLog, "the log follows the head without padding");
     const size_t ctrl_bytes = sizeof(CtrlHead) + sizeof(IterLog) * (size_t)std::min(opt.max_num_iterations + 1, kMaxLog);
     for (tscm_solver *s : run.m) {
         const int nb = std::min(256, (6 * std::max(s->B, s->C) + 255) / 256 + 1);
+        if (s->eval_pending & 1) {
+            hipLaunchKernelGGL(k_finish_solve, dim3(nb + 1), dim3(256), 0, s->stream, s->P, s->S, s->eval_pending >> 2, !(s->eval_pending >> 2), s->C, s->B, s->d_h_ctrl);
+            s->eval_pending = 0;
+            continue;
+        }
+        if (s->eval_pending == 2) hipLaunchKernelGGL(k_control, dim3(1), dim3(256), 0, s->stream, s->P, s->S, 0);
+        s->eval_pending = 0;
         hipLaunchKernelGGL(k_end_solve, dim3(nb), dim3(256), 0, s->stream, s->S, s->C, s->B);
         HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->S.ctrl, ctrl_bytes, hipMemcpyDeviceToHost, s->stream));
     }
@@ -1785,6 +1791,13 @@ extern "C" int tscm_debug_control_stamps(long long *out)
     if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_ktlx), sizeof(long long) * 32) != hipSuccess) return TSCM_E_HIP;
     return 32;
+}
+extern "C" int tscm_debug_phase_stamps(long long *out, int max_groups)
+{
+    if (max_groups < tscm::kKtlGroups) return TSCM_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_phs), sizeof(long long) * 2 * tscm::kPhStamps * tscm::kKtlGroups) != hipSuccess) return TSCM_E_HIP;
+    return tscm::kPhStamps;
 }
 extern "C" int tscm_debug_wave_views(long long *out, int max_waves)
 {
