@@ -23,19 +23,29 @@
 extern "C" {
 #endif
 
-#define TSCM_ABI_VERSION 5   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
+#define TSCM_ABI_VERSION 6   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
                              /*    zero-initialised structs keep their meaning); 4: unknown exec_flags bits are  */
                              /*    refused, TSCM_EXEC_DENSE_REDUCED_ORDER, the fault injection of the tests is   */
-                             /*    an entry point of its own (tscm_solver_debug_withhold_handoff), no option     */
+                             /*    an entry point of its own (tscm_solver_debug_withhold_handoff), no option;    */
+                             /* 5: tscm_comm_ipc_open / tscm_comm_ipc_connect, tscm_device_peak_fp32_mfma,       */
+                             /*    TSCM_EXEC_GRAPH_REDUCED_ORDER (no struct changed);                            */
+                             /* 6: tscm_options starts with struct_size (the third appended field in four rounds */
+                             /*    was the moment): the library reads only as many bytes as the caller's struct  */
+                             /*    has and refuses a size it does not know -- an options struct of ABI <= 5 is   */
+                             /*    refused instead of misread; TSCM_E_PEER; a late device-side hand-off re-runs  */
+                             /*    the solve on separate launches before it is an error                           */
 
 enum {
     TSCM_OK = 0,
     TSCM_E_INVALID = -1,      /* bad argument / inconsistent problem description      */
     TSCM_E_NO_DEVICE = -2,    /* no HIP device, or hipSetDevice failed                */
     TSCM_E_HIP = -3,          /* a HIP runtime call failed                            */
-    TSCM_E_RCCL = -4,         /* an RCCL call failed                                  */
+    TSCM_E_RCCL = -4,         /* an RCCL call failed (the communicator is aborted)    */
     TSCM_E_UNSUPPORTED = -5,  /* problem shape outside what the kernels support       */
-    TSCM_E_NOMEM = -6
+    TSCM_E_NOMEM = -6,
+    TSCM_E_PEER = -7          /* the IPC exchange back-end: a peer rank did not arrive within its time bound, or its */
+                              /* memory could not be mapped (the communicator is unusable afterwards, like an        */
+                              /* aborted RCCL communicator)                                                          */
 };
 
 /* ceres::TerminationType values the reference looks at (TS.cpp:281). */
@@ -86,6 +96,11 @@ typedef struct tscm_problem {
 /* ceres::Solver::Options fields the path depends on, Ceres defaults
  * (TS.cpp:271-274, multi_calib.cpp:209-212; linear solver is always DENSE_SCHUR). */
 typedef struct tscm_options {
+    size_t struct_size;                  /* sizeof(tscm_options) of the CALLER's header */
+                                         /* (tscm_default_options sets it).  Fields     */
+                                         /* behind it that the caller's struct does not */
+                                         /* have take their defaults; 0 or an unknown   */
+                                         /* size: TSCM_E_INVALID                        */
     int max_num_iterations;              /* 100 mono (TS.cpp:274) / 50 multi           */
     double function_tolerance;           /* 1e-6                                       */
     double gradient_tolerance;           /* 1e-10                                      */
@@ -198,10 +213,17 @@ void tscm_default_options(tscm_options *opt, int mono);
  */
 int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
 int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU, see below */
-/* TESTS ONLY: in the next solve of `s` one producer of the device-side hand-off (Schur-complement tiles -> reduced solve)
- * never reports in; that solve must end with TSCM_E_HIP within the hand-off's time bound, the caller's parameters
- * untouched, and the solver must solve again afterwards. */
+/* A hand-off between workgroups of one launch (Schur-complement tiles -> reduced solve -> back-substitution) that does not
+ * come within its time bound (0.5 s: a debugger, a co-tenant, a context switch -- or a fault) stops the solve on the
+ * device; the library then runs THAT solve again from its start point on the launches that hand nothing over inside a
+ * launch (TSCM_EXEC_SEPARATE_T_REDUCE | _BACKSUB | _CONTROL: same mathematics, same bits) and returns its result;
+ * tscm_last_error() carries a note, tscm_solver_reruns() counts them.  TSCM_E_HIP only if the re-run fails too -- or
+ * with a communicator of several ranks, which would have to agree on it.
+ * TESTS ONLY: tscm_solver_debug_withhold_handoff(s, 1): in the next solve of `s` one producer of the hand-off never
+ * reports in (the solve must come back re-run, within seconds); (s, 2): ... and the re-run is forbidden: that solve
+ * must end with TSCM_E_HIP within the time bound, the caller's parameters untouched, the solver usable afterwards. */
 int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on);
+int tscm_solver_reruns(const tscm_solver *s);                /* solves of `s` that were run again so far (>= 0) */
 int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *summary);
 /* Same as _solve but parameters start from / are left in device memory (used by the
  * benchmark to time the minimiser loop with inputs resident in HBM). reset=1 reloads
@@ -298,7 +320,7 @@ int tscm_comm_create_local(int world, int device, tscm_comm **out /* [world] */)
  *      world: api.Comm.ipc computes it), the 64-byte handles are all-gathered by the caller (socket, file, MPI ...),
  *      every rank calls tscm_comm_ipc_connect with all of them in rank order; then tscm_solver_set_comm as with RCCL.
  *      Exercised between processes on one device; RCCL is the production path across devices. */
-#define TSCM_IPC_HANDLE_BYTES 64
+#define TSCM_IPC_HANDLE_BYTES 80      /* (64 until ABI 5) the HIP handle, then the device's PCI address and the buffer's kind */
 int tscm_comm_ipc_open(int rank, int world, int device, size_t max_doubles, tscm_comm **out, unsigned char handle[TSCM_IPC_HANDLE_BYTES]);
 int tscm_comm_ipc_connect(tscm_comm *c, const unsigned char *handles /* [world][TSCM_IPC_HANDLE_BYTES] */);
 void tscm_comm_destroy(tscm_comm *c);

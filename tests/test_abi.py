@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = lib.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.tscm_abi_version() == 5
+    assert L.tscm_abi_version() == 6
 
 
 def test_struct_layouts_match_header():
@@ -33,6 +33,8 @@ def test_struct_layouts_match_header():
     assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
     assert (o.max_num_consecutive_invalid_steps, o.jacobi_scaling, o.check_every) == (5, 1, 4)
     assert lib.default_options(True).max_num_iterations == 100       # TS.cpp:274
+    # ABI 6: the struct says how long it is (the library reads only that much and refuses a size it does not know)
+    assert o.struct_size == C.sizeof(lib.COptions) == 112
     assert C.sizeof(lib.CIteration) == 72 and C.sizeof(lib.CProblem) == 120        # ABI 2: + board_pose_constant
 
 

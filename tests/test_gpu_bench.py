@@ -109,10 +109,12 @@ def test_the_drivers_torchrun_command_with_two_ranks_on_this_device(hip_device):
 
 def test_a_rank_that_is_gone_is_reported_not_waited_for(hip_device):
     """Failure detection of the IPC exchange: one of two rank processes leaves before the solve; the other's exchange kernel gives
-    up after its bound (10 s) and the solve returns TSCM_E_RCCL -- the exchanges enqueued behind the failed one return at once."""
+    up after its bound (10 s) and the solve returns TSCM_E_PEER (ABI 6: its own code, RCCL had no part in it) -- the exchanges enqueued
+    behind the failed one return at once, and the communicator is unusable afterwards."""
     tool = os.path.join(os.path.dirname(BENCH), "tools", "ipc_check.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, tool, "--world", "2", "--config", "1", "--iterations", "10", "--die-rank", "1"], env=env, capture_output=True, text=True, timeout=300)
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout + out.stderr)[-3000:]
-    assert lines[0]["peer_failure_detected"] and lines[0]["code"] == -4 and 5 < lines[0]["seconds"] < 60
+    assert lines[0]["peer_failure_detected"] and lines[0]["code"] == -7 and 5 < lines[0]["seconds"] < 60
+    assert lines[0]["again_code"] == -7 and lines[0]["again_seconds"] < 2.0

@@ -48,7 +48,7 @@ def rank_main(args):
     solver.set_comm(comm)
     chan.barrier()
     if args.die_rank >= 0:
-        # failure detection: one rank leaves before the solve; the others must come back with TSCM_E_RCCL within the
+        # failure detection: one rank leaves before the solve; the others must come back with TSCM_E_PEER within the
         # exchange kernel's time bound instead of waiting for its flags for ever
         from tscm_calib_amd.lib import TscmError
         if rank == args.die_rank:
@@ -59,7 +59,14 @@ def rank_main(args):
             print(json.dumps({"rank": rank, "peer_failure_detected": False}), flush=True)
             sys.exit(4)
         except TscmError as e:
-            print(json.dumps({"rank": rank, "peer_failure_detected": True, "code": e.code, "seconds": time.perf_counter() - t0, "message": str(e)[:120]}), flush=True)
+            t1 = time.perf_counter()
+            try:                                   # the communicator is unusable from here on: the next solve fails at once, it does not wait again
+                solver.solve(**opts)
+                again = 0
+            except TscmError as e2:
+                again = e2.code
+            print(json.dumps({"rank": rank, "peer_failure_detected": True, "code": e.code, "seconds": t1 - t0, "message": str(e)[:120],
+                              "again_code": again, "again_seconds": time.perf_counter() - t1}), flush=True)
         os._exit(0)                                # (no collective clean-up with a peer that is gone)
     t0 = time.perf_counter()
     s = solver.solve(**opts)                       # in/out through full.cam_rt / intr / board_rt; gathers the boards over the communicator
@@ -122,7 +129,7 @@ def main():
     ap.add_argument("--world", default="2,4,8")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--iterations", type=int, default=12, help="forced LM iterations (0: the natural solve)")
-    ap.add_argument("--die-rank", type=int, default=-1, help="this rank exits before the solve: the others must report TSCM_E_RCCL, not hang")
+    ap.add_argument("--die-rank", type=int, default=-1, help="this rank exits before the solve: the others must report TSCM_E_PEER, not hang")
     args = ap.parse_args()
     if os.environ.get("TSCM_IPC_CHECK_RANK") == "1":
         return rank_main(args)

@@ -53,9 +53,17 @@ class Solver:
         self._comm = comm
         _l.check(_l.lib().tscm_solver_set_comm(self._h, comm._h if comm else None))
 
-    def debug_withhold_handoff(self, on: bool = True):
-        """Tests only: one producer of the device-side hand-off of the NEXT solve never reports in (tscm_solver_debug_withhold_handoff)."""
-        _l.check(_l.lib().tscm_solver_debug_withhold_handoff(self._h, 1 if on else 0))
+    def debug_withhold_handoff(self, on=True):
+        """Tests only: one producer of the device-side hand-off of the NEXT solve never reports in (tscm_solver_debug_withhold_handoff);
+        on = 2: ... and the library must not run that solve again on separate launches."""
+        _l.check(_l.lib().tscm_solver_debug_withhold_handoff(self._h, int(on)))
+
+    def reruns(self) -> int:
+        """Solves of this solver that were run again on separate launches after a late device-side hand-off."""
+        n = _l.lib().tscm_solver_reruns(self._h)
+        if n < 0:
+            _l.check(n)
+        return n
 
     def solve(self, **options) -> dict:
         """ceres::Solve equivalent: in/out through problem.cam_rt / intr / board_rt."""

@@ -2595,18 +2595,19 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
 // 4.8 + 8.0 us in front of every solve): the grid is k_view_prep's, every thread also moves its share of the start point into buffer 0, and the
 // constants are computed from where the start point IS (the registered arrays with `reset`, buffer 0 otherwise) -- nothing in
 // this launch reads what another of its workgroups writes.  The control block it installs has cur = 0, done = 0.
-__global__ __launch_bounds__(kVPrepThreads) void k_begin_view_prep(DevProblem P, DevState S, CtrlHead head, const double *init_cam, const double *init_intr,
-                                                                   const double *init_board, int reset, int with_floats)
+__global__ __launch_bounds__(kVPrepThreads) void k_begin_view_prep(DevProblem P, DevState S, CtrlHead head, const double *src_cam, const double *src_intr,
+                                                                   const double *src_board, double *bak_cam, double *bak_intr, double *bak_board, int with_floats)
 {
+    // src_*: where the start point is if not in buffer 0 already (the registered arrays with `reset`; the backup on a re-run);
+    // bak_*: where a copy of the start point goes (what a re-run of this solve starts from: a late hand-off, tscm_solver.hip)
     const int i0 = blockIdx.x * kVPrepThreads + threadIdx.x, n = gridDim.x * kVPrepThreads;
     if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
-    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; }
-    if (reset) {
-        for (int i = i0; i < 6 * P.C; i += n) S.cam_rt[0][i] = init_cam[i];
-        for (int i = i0; i < 9 * P.C; i += n) S.intr[0][i] = init_intr[i];
-        for (int i = i0; i < 6 * P.B; i += n) S.board_rt[0][i] = init_board[i];
-    }
-    view_prep_body(P, S, 0, with_floats, reset ? init_cam : S.cam_rt[0], reset ? init_intr : S.intr[0], reset ? init_board : S.board_rt[0]);
+    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
+    const double *cam = src_cam ? src_cam : S.cam_rt[0], *intr = src_intr ? src_intr : S.intr[0], *board = src_board ? src_board : S.board_rt[0];
+    for (int i = i0; i < 6 * P.C; i += n) { const double v = cam[i]; if (src_cam) S.cam_rt[0][i] = v; if (bak_cam) bak_cam[i] = v; }
+    for (int i = i0; i < 9 * P.C; i += n) { const double v = intr[i]; if (src_intr) S.intr[0][i] = v; if (bak_intr) bak_intr[i] = v; }
+    for (int i = i0; i < 6 * P.B; i += n) { const double v = board[i]; if (src_board) S.board_rt[0][i] = v; if (bak_board) bak_board[i] = v; }
+    view_prep_body(P, S, 0, with_floats, cam, intr, board);
 }
 
 // the accepted point lives in buffer `cur`: it becomes buffer 0 (what the caller downloads and the next resident solve

@@ -64,7 +64,11 @@ struct tscm_local_group {
 // rank).  4 us where an RCCL all-reduce of 16-32 KB takes 15-25 -- and the only back-end that can put several rank
 // PROCESSES on one device, which is how the multi-process path runs on a one-GPU box (tools/ipc_check.py,
 // `bench.py --gpus N` with fewer devices than ranks).  Exercised between processes on ONE device only (no
-// multi-GPU box in reach): across devices the arrival flags would want fine-grained memory -- RCCL stays the default.
+// multi-GPU box in reach).  Across devices it is correct by construction since round 5 -- the buffer (slots and flags) is
+// fine-grained device memory (hipExtMallocWithFlags: coherent for a peer's system-scope stores and loads), peer access is
+// enabled explicitly at connect, and a rank whose buffer could only be had coarse-grained refuses peers on other devices --
+// but unmeasured: RCCL stays the default.  A peer that does not arrive within the bound makes the communicator unusable
+// (TSCM_E_PEER from then on, like an aborted RCCL communicator).
 constexpr int kIpcMaxWorld = 16;
 struct IpcPeers { double *base[kIpcMaxWorld]; };
 struct tscm_ipc {
@@ -75,6 +79,8 @@ struct tscm_ipc {
     bool connected = false;
     long long count = 0;                // exchanges so far: parity and flag value of the next one
     int *d_fault = nullptr;             // raised by a kernel whose peers did not arrive within the bound
+    bool fine = false;                  // the buffer is fine-grained memory (a peer on another device may use it)
+    bool dead = false;                  // a peer fault or a failed solve: the ranks' exchange counters can no longer be trusted to agree
     size_t slot_doubles() const { return max_doubles; }
     size_t flags_offset() const { return 2 * (size_t)world * max_doubles; }        // in doubles (flags are 8-byte words)
     size_t total_bytes() const { return 8 * (flags_offset() + 2 * (size_t)world); }
@@ -107,6 +113,7 @@ struct tscm_solver {
     double *h_cam_rt = nullptr, *h_intr = nullptr, *h_board_rt = nullptr;
     // resident initial parameters for the benchmark
     double *d_init_cam = nullptr, *d_init_intr = nullptr, *d_init_board = nullptr;
+    double *d_start_cam = nullptr, *d_start_intr = nullptr, *d_start_board = nullptr;    // start point of the solve in progress (a re-run begins there)
     bool have_init = false;
     Ctrl *h_ctrl = nullptr;             // pinned
     Ctrl *d_h_ctrl = nullptr;           // ... and its address on the device (k_finish_solve writes the control block there itself)
@@ -121,6 +128,8 @@ struct tscm_solver {
     int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator); + 4: the solve's initial evaluation
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0, withhold_next = 0; // this solve / the next one: fault injection (tscm_solver_debug_withhold_handoff)
+    int n_reruns = 0;                   // solves that were run again on separate launches after a late hand-off
+    bool no_rerun = false, no_rerun_next = false;      // fault injection: the late hand-off of this / the next solve stays an error
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
     int solve_variant = 0;              // 0: k_solve_reduced (up to 4 cameras: one dense block), 1: k_solve_nd (5..8 cameras, or TSCM_EXEC_GRAPH_REDUCED_ORDER), 3: k_solve_reduced_big (more than 8 cameras)
     int dense4_resident = 0;            // workgroups of k_solve_reduced<4, 16, 64, true>'s launch that are resident at once
@@ -189,6 +198,7 @@ extern "C" int tscm_device_synchronize(int device)
 
 extern "C" void tscm_default_options(tscm_options *o, int mono)
 {
+    o->struct_size = sizeof(tscm_options);
     o->max_num_iterations = mono ? 100 : 50;   // TS.cpp:274 ; Ceres default (multi_calib.cpp:212 is commented out)
     o->function_tolerance = 1e-6;
     o->gradient_tolerance = 1e-10;
@@ -652,6 +662,9 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_alloc(s, &s->d_init_cam, 6 * (size_t)C))) return rc;
     if ((rc = dev_alloc(s, &s->d_init_intr, 9 * (size_t)C))) return rc;
     if ((rc = dev_alloc(s, &s->d_init_board, 6 * (size_t)B))) return rc;
+    if ((rc = dev_alloc(s, &s->d_start_cam, 6 * (size_t)C))) return rc;
+    if ((rc = dev_alloc(s, &s->d_start_intr, 9 * (size_t)C))) return rc;
+    if ((rc = dev_alloc(s, &s->d_start_board, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.board_pc, (size_t)kBoardConst * B))) return rc;
     if ((rc = dev_alloc(s, &S.cam_pc, (size_t)kCamConst * C))) return rc;
     if ((rc = dev_alloc(s, &S.vconst, (size_t)kVStride * V))) return rc;
@@ -791,7 +804,14 @@ extern "C" int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on)
 {
     if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
     s->withhold_next = on ? 1 : 0;
+    s->no_rerun_next = on == 2;          // 2: ... and the solve is NOT run again on separate launches (the error path itself)
     return 0;
+}
+
+extern "C" int tscm_solver_reruns(const tscm_solver *s)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    return s->n_reruns;
 }
 
 extern "C" int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm)
@@ -976,6 +996,7 @@ static int comm_allreduce(tscm_comm *c, double *buf, size_t n, hipStream_t strea
     if (c->ipc) {
         tscm_ipc *x = c->ipc;
         if (!x->connected) return fail(TSCM_E_INVALID, "tscm_comm_ipc_connect has not been called");
+        if (x->dead) return fail(TSCM_E_PEER, "the IPC communicator is unusable after an earlier failure (a peer that did not arrive, or a failed solve)");
         IpcPeers peers{};
         for (int r = 0; r < x->world; ++r) peers.base[r] = static_cast<double *>(x->mapped[r]);
         for (size_t off = 0; off < n; off += x->max_doubles) {
@@ -993,7 +1014,7 @@ static int comm_check(tscm_comm *c)
     if (!c || !c->ipc) return 0;
     int f = 0;
     HIP_TRY(hipMemcpy(&f, c->ipc->d_fault, sizeof(int), hipMemcpyDeviceToHost));
-    if (f) return fail(TSCM_E_RCCL, "IPC exchange: a peer rank did not arrive within the bound (failed or gone)");
+    if (f) { c->ipc->dead = true; return fail(TSCM_E_PEER, "IPC exchange: a peer rank did not arrive within the bound (failed or gone); the communicator is unusable from here on"); }
     return 0;
 }
 
@@ -1157,7 +1178,7 @@ struct LmRunGuard {
     }
 };
 
-static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset);
+static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset, bool rerun, bool *late_handoff);
 
 // Waits for the solver's stream.  With a multi-rank RCCL communicator a peer that has failed (or died) leaves this
 // rank's all-reduce kernel spinning for ever -- over the intra-node transports an ncclCommAbort on the FAILING rank does
@@ -1189,8 +1210,27 @@ static int sync_stream(tscm_solver *s)
 // as one exits non-zero).  A failed rank must not be re-used: start a fresh process.
 static int run_lm(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset)
 {
-    const int rc = run_lm_inner(run, opt_in, sums, reset);
+    bool late = false;
+    int rc = run_lm_inner(run, opt_in, sums, reset, /*rerun=*/false, &late);
+    if (late && !run.m[0]->comm && run.m.size() == 1 && !run.m[0]->no_rerun) {
+        // A device-side hand-off of a fused launch came late (0.5 s: a debugger, a co-tenant, a context switch -- or a real
+        // fault).  The solve was stopped on the device and nothing of it has left it; it is run again from its start point
+        // (k_begin_view_prep kept a copy) on the launches that hand nothing over inside a launch -- same mathematics, same
+        // bits as the fused ones (tests/test_gpu_parity.py).  Only if that fails too is it an error.  With a communicator the
+        // ranks would have to agree on the re-run: there the late hand-off stays TSCM_E_HIP.
+        tscm_options o2;
+        tscm_default_options(&o2, run.m[0]->mono);
+        if (opt_in) std::memcpy(&o2, opt_in, std::min(opt_in->struct_size, sizeof(tscm_options)));
+        o2.struct_size = sizeof(tscm_options);
+        o2.exec_flags |= TSCM_EXEC_SEPARATE_T_REDUCE | TSCM_EXEC_SEPARATE_BACKSUB | TSCM_EXEC_SEPARATE_CONTROL;
+        const std::string first = g_err;
+        bool late2 = false;
+        rc = run_lm_inner(run, &o2, sums, reset, /*rerun=*/true, &late2);
+        if (rc == 0) g_err = "note: " + first + "; the solve was run again on separate launches and completed";
+        ++run.m[0]->n_reruns;
+    }
     tscm_comm *c = run.m[0]->comm;
+    if (rc != 0 && rc != TSCM_E_INVALID && c && c->ipc && c->world > 1) c->ipc->dead = true;     // (its exchange counter may be behind the peers' now)
     if (rc != 0 && rc != TSCM_E_INVALID && c && c->comm && c->world > 1) {
         const std::string keep = g_err;
         (void)ncclCommAbort(c->comm);
@@ -1200,12 +1240,22 @@ static int run_lm(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, in
     return rc;
 }
 
-static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset)
+static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, int reset, bool rerun, bool *late_handoff)
 {
     tscm_solver *s0 = run.m[0];
     for (tscm_solver *s : run.m) if (!s->have_init) return fail(TSCM_E_INVALID, "tscm_solver_upload_params has not been called");
+    // the caller's struct may be SHORTER than this library's (built against an older header of ABI >= 6): read what it has, the
+    // rest keeps its default.  The shortest struct the library knows ends behind exec_flags (ABI 6); a size of 0, a smaller or a
+    // larger one is refused -- a struct of ABI <= 5 has max_num_iterations where struct_size is and never passes
     tscm_options opt;
-    if (opt_in) opt = *opt_in; else tscm_default_options(&opt, s0->mono);
+    tscm_default_options(&opt, s0->mono);
+    if (opt_in) {
+        constexpr size_t kMinOptions = offsetof(tscm_options, exec_flags) + sizeof(int);
+        if (opt_in->struct_size < kMinOptions || opt_in->struct_size > sizeof(tscm_options))
+            return fail(TSCM_E_INVALID, "tscm_options.struct_size is not a size this library knows (initialise the struct with tscm_default_options; ABI 6)");
+        std::memcpy(&opt, opt_in, opt_in->struct_size);
+        opt.struct_size = sizeof(tscm_options);
+    }
     if (opt.max_num_iterations < 0 || opt.max_num_iterations > TSCM_MAX_ITERATIONS) return fail(TSCM_E_INVALID, "max_num_iterations must be in [0, 255]");
     if (opt.exec_flags & ~TSCM_EXEC_ALL) return fail(TSCM_E_INVALID, "unknown bits in tscm_options.exec_flags (an options struct of an older ABI?)");
     HIP_TRY(hipSetDevice(s0->device));
@@ -1225,12 +1275,14 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
             s->ctl_epoch = 0;
         }
         s->withhold = s->withhold_next; s->withhold_next = 0;
+        if (!rerun) { s->no_rerun = s->no_rerun_next; s->no_rerun_next = false; }
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
         s->nd = (opt.exec_flags & TSCM_EXEC_DENSE_REDUCED_ORDER) ? 1 : 0;
         s->graph_order = (opt.exec_flags & TSCM_EXEC_GRAPH_REDUCED_ORDER) != 0 || (s->solve_variant == 0 && s->nd);
         s->t_epoch = 0;
     }
     if (s0->comm && !s0->comm->group && !s0->comm->ipc && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
+    if (s0->comm && s0->comm->ipc && s0->comm->ipc->dead) return fail(TSCM_E_PEER, "the IPC communicator is unusable after an earlier failure (a peer that did not arrive, or a failed solve)");
     if (s0->comm && s0->comm->group) {
         // a local group runs on ONE stream: lock step by stream order, no events
         tscm_local_group *g = s0->comm->group;
@@ -1267,8 +1319,13 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         h.opt.max_invalid = opt.max_num_consecutive_invalid_steps;
         h.opt.jacobi_scaling = opt.jacobi_scaling;
         // ... and the constants of the initial evaluation (k_view_prep's work) in the same launch
+        // (start point: the registered arrays with `reset`, buffer 0 otherwise, the backup of the first attempt on a re-run -- the
+        // first attempt leaves that backup behind)
+        const bool from_init = reset && !rerun;
         hipLaunchKernelGGL(k_begin_view_prep, dim3((s->P.V + s->P.C + kVPrepThreads - 1) / kVPrepThreads), dim3(kVPrepThreads), 0, s->stream, s->P, s->S, h,
-                           s->d_init_cam, s->d_init_intr, s->d_init_board, reset ? 1 : 0, s->f32_jacobian ? 1 : 0);
+                           rerun ? s->d_start_cam : from_init ? s->d_init_cam : nullptr, rerun ? s->d_start_intr : from_init ? s->d_init_intr : nullptr,
+                           rerun ? s->d_start_board : from_init ? s->d_init_board : nullptr,
+                           rerun ? nullptr : s->d_start_cam, rerun ? nullptr : s->d_start_intr, rerun ? nullptr : s->d_start_board, s->f32_jacobian ? 1 : 0);
     }
 
     int rc;
@@ -1311,7 +1368,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         Ctrl *h = s->h_ctrl;
         tscm_summary *sum = &sums[r];
         if ((rc = collect_timing(s))) return rc;
-        if (h->fault) return fail(TSCM_E_HIP, "a device-side hand-off (Schur-complement tiles -> reduced solve) did not arrive within its time bound: the solve was stopped");
+        if (h->fault) { *late_handoff = true; return fail(TSCM_E_HIP, "a device-side hand-off (Schur-complement tiles -> reduced solve) did not arrive within its time bound: the solve was stopped"); }
         if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
         sum->termination_type = h->term_type;
         sum->num_iterations = std::min(h->n_log, TSCM_MAX_ITERATIONS + 1);
@@ -1675,7 +1732,8 @@ extern "C" int tscm_comm_create_local(int world, int device, tscm_comm **out)
     return 0;
 }
 
-static_assert(sizeof(hipIpcMemHandle_t) <= TSCM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t larger than the ABI buffer");
+struct IpcIdent { int pci[3]; int fine; };
+static_assert(sizeof(hipIpcMemHandle_t) + sizeof(IpcIdent) <= TSCM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t + identity larger than the ABI buffer");
 
 extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_doubles, tscm_comm **out, unsigned char handle[TSCM_IPC_HANDLE_BYTES])
 {
@@ -1688,21 +1746,36 @@ extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_do
     std::unique_ptr<tscm_ipc> x(new tscm_ipc);
     c->rank = rank; c->world = world; c->device = device;
     x->rank = rank; x->world = world; x->max_doubles = (max_doubles + 1) & ~(size_t)1;
-    if (hipMalloc(&x->own, x->total_bytes()) != hipSuccess) return fail(TSCM_E_NOMEM, "hipMalloc of the exchange buffer failed");
-    if (hipMalloc(reinterpret_cast<void **>(&x->d_fault), sizeof(int)) != hipSuccess) { (void)hipFree(x->own); return fail(TSCM_E_NOMEM, "hipMalloc failed"); }
+    if (hipMalloc(reinterpret_cast<void **>(&x->d_fault), sizeof(int)) != hipSuccess) return fail(TSCM_E_NOMEM, "hipMalloc failed");
     hipIpcMemHandle_t h;
-    {
-        hipError_t e = hipMemset(x->own, 0, x->total_bytes());
+    // fine-grained first (what a peer on ANOTHER device needs for its system-scope flag stores and my loads of them to meet);
+    // where that cannot be had or exported, ordinary device memory -- enough for ranks that share this device, and the handle
+    // says so: a peer on another device then refuses to connect
+    hipError_t e = hipErrorUnknown;
+    for (int attempt = 0; attempt < 2 && e != hipSuccess; ++attempt) {
+        x->fine = attempt == 0;
+        e = x->fine ? hipExtMallocWithFlags(&x->own, x->total_bytes(), hipDeviceMallocFinegrained) : hipMalloc(&x->own, x->total_bytes());
+        if (e != hipSuccess) { x->own = nullptr; (void)hipGetLastError(); continue; }
+        e = hipMemset(x->own, 0, x->total_bytes());
         if (e == hipSuccess) e = hipMemset(x->d_fault, 0, sizeof(int));
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipIpcGetMemHandle(&h, x->own);
-        if (e != hipSuccess) {
-            (void)hipFree(x->own); (void)hipFree(x->d_fault);
-            return fail(TSCM_E_HIP, std::string("IPC exchange buffer: ") + hipGetErrorString(e) + " (hipIpcGetMemHandle needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC)");
-        }
+        if (e != hipSuccess) { (void)hipFree(x->own); x->own = nullptr; (void)hipGetLastError(); }
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(x->d_fault);
+        return fail(TSCM_E_HIP, std::string("IPC exchange buffer: ") + hipGetErrorString(e) + " (hipIpcGetMemHandle needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC)");
     }
     std::memset(handle, 0, TSCM_IPC_HANDLE_BYTES);
     std::memcpy(handle, &h, sizeof(h));
+    {
+        // behind the HIP handle: which device the buffer lives on (PCI address: ordinals differ between processes) and its kind
+        IpcIdent id{};
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        id.pci[0] = prop.pciDomainID; id.pci[1] = prop.pciBusID; id.pci[2] = prop.pciDeviceID; id.fine = x->fine ? 1 : 0;
+        std::memcpy(handle + sizeof(h), &id, sizeof(id));
+    }
     x->mapped[rank] = x->own;
     c->ipc = x.release();
     *out = c.release();
@@ -1715,10 +1788,32 @@ extern "C" int tscm_comm_ipc_connect(tscm_comm *c, const unsigned char *handles)
     tscm_ipc *x = c->ipc;
     if (x->connected) return fail(TSCM_E_INVALID, "already connected");
     HIP_TRY(hipSetDevice(c->device));
+    IpcIdent me{};
+    std::memcpy(&me, handles + (size_t)TSCM_IPC_HANDLE_BYTES * x->rank + sizeof(hipIpcMemHandle_t), sizeof(me));
     for (int r = 0; r < x->world; ++r) {
         if (r == x->rank) continue;
         hipIpcMemHandle_t h;
+        IpcIdent id{};
         std::memcpy(&h, handles + (size_t)TSCM_IPC_HANDLE_BYTES * r, sizeof(h));
+        std::memcpy(&id, handles + (size_t)TSCM_IPC_HANDLE_BYTES * r + sizeof(h), sizeof(id));
+        if (std::memcmp(id.pci, me.pci, sizeof(id.pci)) != 0) {
+            // a peer on another device: both buffers fine-grained, and peer access enabled here and now (not lazily)
+            if (!id.fine || !x->fine) return fail(TSCM_E_UNSUPPORTED, "IPC exchange across devices needs fine-grained exchange buffers on both ranks (one of them is ordinary device memory): put the ranks on one device or use RCCL");
+            int ndev = 0, peer = -1;
+            HIP_TRY(hipGetDeviceCount(&ndev));
+            for (int d = 0; d < ndev && peer < 0; ++d) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, d));
+                if (prop.pciDomainID == id.pci[0] && prop.pciBusID == id.pci[1] && prop.pciDeviceID == id.pci[2]) peer = d;
+            }
+            if (peer < 0) return fail(TSCM_E_UNSUPPORTED, "IPC exchange: a peer rank's device is not visible to this process (HIP_VISIBLE_DEVICES): no peer access");
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, c->device, peer));
+            if (!can) return fail(TSCM_E_UNSUPPORTED, "IPC exchange: no peer access between this rank's device and a peer rank's");
+            const hipError_t pe = hipDeviceEnablePeerAccess(peer, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { HIP_TRY(pe); }
+            (void)hipGetLastError();
+        }
         HIP_TRY(hipIpcOpenMemHandle(&x->mapped[r], h, hipIpcMemLazyEnablePeerAccess));
     }
     x->connected = true;

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libtscm_hip.so")
 UNIQUE_ID_BYTES = 128
-IPC_HANDLE_BYTES = 64
+IPC_HANDLE_BYTES = 80
 MAX_ITERATIONS = 255
 # tscm_options.exec_flags (tscm.h)
 EXEC_SEPARATE_T_REDUCE = 1
@@ -28,7 +28,7 @@ EXEC_DENSE_REDUCED_ORDER = 32
 EXEC_GRAPH_REDUCED_ORDER = 64
 
 E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
-           -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM"}
+           -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM", -7: "TSCM_E_PEER"}
 TERMINATION = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
 
 
@@ -50,7 +50,7 @@ class CProblem(C.Structure):
 
 class COptions(C.Structure):
     _fields_ = [
-        ("max_num_iterations", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("struct_size", C.c_size_t), ("max_num_iterations", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
         ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
         ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
@@ -113,7 +113,7 @@ class CCornerSet(C.Structure):
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_device_peak_fp64_ex", "tscm_device_peak_fp32_mfma", "tscm_default_options",
-    "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_solve", "tscm_solver_upload_params",
+    "tscm_solver_create", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_reruns", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
     "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
@@ -168,6 +168,7 @@ def lib():
     L.tscm_comm_info.argtypes = [vp, ip, ip, ip]
     L.tscm_solver_set_comm.argtypes = [vp, vp]
     L.tscm_solver_debug_withhold_handoff.argtypes = [vp, C.c_int]
+    L.tscm_solver_reruns.argtypes = [vp]
     L.tscm_solver_solve.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary)]
     L.tscm_solver_upload_params.argtypes = [vp, dp, dp, dp]
     L.tscm_solver_solve_resident.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary), C.c_int]
