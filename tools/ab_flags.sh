@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/r04_ab_flags.sh <config> "<flag values>" [rounds]  -- bench.py --exec-flags A/B in one call (same box, alternating)
+# usage (GPU box): bash tools/ab_flags.sh <config> "<exec_flags values>" [rounds]  -- bench.py --exec-flags A/B in one call (same box, alternating)
 cd $GRAFT_REPO_ROOT
 cfg=$1; flags=$2; n=${3:-2}
 for r in $(seq $n); do for f in $flags; do

@@ -88,7 +88,7 @@ def rank_main(args):
                           "final_cost": s["final_cost"], "fingerprint_ipc_ranks": prints, "fingerprint_local_group": local,
                           "identical": ok, "device_us_per_iteration_ipc": [1e6 * d / max(1, s["lm_iterations"]) for d in dev],
                           "device_us_per_iteration_local_group": 1e6 * rs[0]["seconds_solve"] / max(1, rs[0]["lm_iterations"]),
-                          "wall_seconds_ipc": max(walls)}), flush=True)
+                          "wall_seconds_ipc": max(walls), "exchange_buffer": getattr(comm, "note", "")}), flush=True)
         if not ok:
             sys.exit(3)
     chan.close()

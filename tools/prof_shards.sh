@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/r04_prof_shards.sh <tag> <config> <worlds>  -- rocprofv3 kernel medians of tools/bench_shards.py (the communicator path)
+# usage (GPU box): bash tools/prof_shards.sh <tag> <config> <worlds>  -- rocprofv3 kernel medians of tools/bench_shards.py (the communicator path)
 cd $GRAFT_REPO_ROOT
 tag=$1; cfg=$2; w=$3
 bash tools/prof_tool.sh ${tag} tools/bench_shards.py --config $cfg --worlds $w > gpurun_out/${tag}_prof.txt 2>&1

@@ -138,16 +138,18 @@ class Comm:
     def ipc(rank: int, world: int, device: int, allgather, n_cameras: int = 32) -> "Comm":
         """Communicator of the IPC back-end (tscm_comm_ipc_open / _connect): one process per rank, the ranks may
         share a device.  `allgather(bytes) -> list[bytes]` is the caller's side channel (every rank calls it once, with
-        its 64-byte handle; it returns all ranks' handles in rank order).  `n_cameras`: upper bound of the rigs this
+        its TSCM_IPC_HANDLE_BYTES-byte handle; it returns all ranks' handles in rank order).  `n_cameras`: upper bound of the rigs this
         communicator will serve (sizes the exchange slots: 256 doubles per camera-pair block)."""
         h = C.c_void_p()
         mine = (C.c_ubyte * _l.IPC_HANDLE_BYTES)()
         max_doubles = 256 * max(n_cameras * (n_cameras + 1) // 2, n_cameras) + 8 + world
         _l.check(_l.lib().tscm_comm_ipc_open(rank, world, device, max_doubles, C.byref(h), mine))
+        note = _l.lib().tscm_last_error().decode(errors="replace")      # (which kind of memory the exchange buffer got)
         c = Comm(None, rank, world, device, _handle=h)
+        c.note = note
         handles = allgather(bytes(mine))
         if len(handles) != world or any(len(x) != _l.IPC_HANDLE_BYTES for x in handles):
-            raise RuntimeError("allgather must return one 64-byte handle per rank")
+            raise RuntimeError(f"allgather must return one {_l.IPC_HANDLE_BYTES}-byte handle per rank")
         buf = (C.c_ubyte * (_l.IPC_HANDLE_BYTES * world)).from_buffer_copy(b"".join(handles))
         _l.check(_l.lib().tscm_comm_ipc_connect(c._h, buf))
         return c

@@ -36,7 +36,7 @@
 
 // workgroups of the fused launch per CU: 2.  At 3 the two-tiles-per-thread variant spills ten doubles inside the phase loop, and
 // config 5 runs 364.5 us per iteration (130.7 us per rank on 8 shards, all back-substitution groups riding) against 359.9 (126.3,
-// none riding) at 2 -- measured in one call, tools/r04_ab_libs.sh
+// none riding) at 2 -- measured in one call, tools/variants.sh
 #ifndef TSCM_ND_WGS_PER_CU
 #define TSCM_ND_WGS_PER_CU 2
 #endif

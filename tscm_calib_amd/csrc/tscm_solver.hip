@@ -1777,6 +1777,7 @@ extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_do
         std::memcpy(handle + sizeof(h), &id, sizeof(id));
     }
     x->mapped[rank] = x->own;
+    g_err = x->fine ? "note: IPC exchange buffer in fine-grained device memory" : "note: IPC exchange buffer in ordinary device memory (ranks on this device only)";
     c->ipc = x.release();
     *out = c.release();
     return 0;
