@@ -604,7 +604,7 @@ constexpr int kKtlKernels = 6, kKtlGroups = 2048;
 __device__ long long g_ktl[2 * kKtlKernels * kKtlGroups];
 struct KtlScope {
     long long t0; int id; bool on; int blk;
-    __device__ KtlScope(int id_, const Ctrl *c) : t0(wall_clock64()), id(id_), on(c->iteration == 5), blk((int)blockIdx.x) {}
+    __device__ KtlScope(int id_, const CtrlHead *c) : t0(wall_clock64()), id(id_), on(c->iteration == 5), blk((int)blockIdx.x) {}
     __device__ ~KtlScope()
     {
         if (on && threadIdx.x == 0 && blk < kKtlGroups) {
@@ -1476,7 +1476,9 @@ struct RawTc {
 template <int NV>
 __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch)
 {
-    KTL(3);
+#ifdef TSCM_WAVE_TIMELINE
+    KtlScope ktl_scope(3, ctl ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));      // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
+#endif
     PHASE_STAMP(tsk);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
