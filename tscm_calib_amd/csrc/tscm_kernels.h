@@ -2158,8 +2158,11 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 // consecutive boards, whose views are consecutive record slots.  Small workgroups on purpose: the kernel streams the W
 // region, a CU sustains ~20 GB/s of it, so the time is set by the CU with the most bytes -- thousands of small
 // workgroups spread evenly, a few hundred large ones leave CUs with one or with two of them (measured: 2.3 TB/s).
-//   phase A  q_b = sum_v W_v yhat[m_v]: the W records of a round of 32 slots are ONE contiguous piece of memory, read
-//            flat (every wave instruction 512 consecutive bytes) into LDS; 16 lanes per slot take their columns from there
+//   phase A  q_b = sum_v W_v yhat[m_v]: 16 lanes per slot, lane a loads column a of the slot's W record (six adjacent doubles,
+//            three 16-byte loads) straight into registers, multiplies by yhat[m_v][a] and the 16 lanes sum (DPP).  Round 5:
+//            before, the records of a round were read flat into LDS and the columns taken from there -- two barriers and an LDS
+//            round trip per round of 32 slots, with the next round's loads behind the first; tools/ubench_stream.hip: the column
+//            pattern streams exactly as fast as the flat one (7.1 TB/s).  Everything of a round of 64 slots is requested at once
 //   phase B  one lane per board: y_b = L^{-T} (z - L^{-1} S_b q_b);  delta_b = -s_b y_b;  candidate = x + delta
 //            (sum_v Y_v yhat = L^{-1} S_b sum_v W_v yhat: one forward substitution per board);  the candidate rotations
 //            R_c of the cameras are prepared by lanes of the second wave
@@ -2171,15 +2174,15 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
 // threads / 16 boards (thousands of small workgroups: balanced on mid-size problems) and 256 threads / 32 boards for
 // problems with more groups of 16 than fit the chip at once -- the serial phases B and C cost a workgroup the same ~5 us
 // whatever its size, so larger workgroups halve their share per board.
-constexpr int kBsRound = 32;       // slots per round of phase A
 constexpr int kBsTile = 64;        // views per round of phase C
 template <int NTH> struct BsGeom {
     static constexpr int kBoards = NTH / 8;
-    static constexpr int kLoads = (kBsRound * kRecW + NTH - 1) / NTH;                 // W doubles per thread and round
-    static constexpr int kLdsA = kBsRound * kRecW + kBsRound * 6;
-    static constexpr int kLds = kBsTile * (kVFloatOff + 1) > kLdsA ? kBsTile * (kVFloatOff + 1) : kLdsA;     // dynamic LDS, doubles
+    static constexpr int kPassSlots = NTH / 16;                                        // phase A: 16 lanes per slot
+    static constexpr int kPasses = 4;                                                  // ... four passes per round: 24 doubles of W per thread
+    static constexpr int kRoundSlots = kPasses * kPassSlots;                           // 64 slots at 256 threads, 32 at 128
+    static constexpr int kLdsA = kRoundSlots * 6, kLdsB = kBoards * kFac, kLdsC = kBsTile * (kVFloatOff + 1);
+    static constexpr int kLds = kLdsC > kLdsB ? (kLdsC > kLdsA ? kLdsC : kLdsA) : (kLdsB > kLdsA ? kLdsB : kLdsA);     // dynamic LDS, doubles
     static_assert(kBoards * kFac == 7 * NTH, "the factor records are 7 doubles per thread");
-    static_assert(kBoards * kFac <= kBsRound * kRecW, "the factor records re-use the W area");
     static_assert(kBoards <= 64 && 64 + kMaxCam <= NTH, "lane roles of phase B: the boards in wave 0, the cameras from wave 1 on");
 };
 
@@ -2191,7 +2194,7 @@ template <int NTH> struct BsGeom {
 template <int NTH, bool WAIT>
 __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState &S, int with_floats, const int blk, const int nblk, const int epoch, const int t_need)
 {
-    constexpr int kBsBoards = BsGeom<NTH>::kBoards, kBsThreads = NTH, kLoads = BsGeom<NTH>::kLoads;
+    constexpr int kBsBoards = BsGeom<NTH>::kBoards, kBsThreads = NTH, kPassSlots = BsGeom<NTH>::kPassSlots, kPasses = BsGeom<NTH>::kPasses, kRoundSlots = BsGeom<NTH>::kRoundSlots;
 #ifndef TSCM_BS_CAM_LANE0
 #define TSCM_BS_CAM_LANE0 64
 #endif
@@ -2204,8 +2207,7 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
     int fail = WAIT ? 0 : S.ctrl->lin_fail;
     if (ctrl_done) return;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
-    double *s_w = dyn;                                     // [kBsRound][kRecW]   phase A
-    double (*s_qv)[6] = reinterpret_cast<double (*)[6]>(dyn + kBsRound * kRecW);     // [kBsRound][6] W yhat per slot of the round
+    double (*s_qv)[6] = reinterpret_cast<double (*)[6]>(dyn);     // [kRoundSlots][6] W yhat per slot of the round   phase A
     double *s_fac = dyn;                                   // [kBsBoards][kFac]   phase B
     double *st_all = dyn;                                  // [kBsTile][kVFloatOff + 1]  phase C
     __shared__ double s_q[kBsBoards][6], s_new[kBsBoards][6];
@@ -2241,16 +2243,22 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
     // ---- phase A -----------------------------------------------------------------------------------------------------
     {
         const int grp = t >> 4, a = t & 15;
-        const double *wsrc = S.rec[cur];
-        const size_t w_end = (size_t)kRecW * max(s1, 1);               // first double behind this workgroup's records
-        double v[kLoads];
-        int camv = 0;
-        {
-            const size_t base = (size_t)kRecW * s0;
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(S.rec[cur], sizeof(double) * (size_t)kRecW * P.V);      // (the W region only: a slot behind s1 - 1 is never addressed)
+        constexpr unsigned BAD = 0xffffe000u;
+        // column a of the W records of this lane's slot in each of the round's passes, and the slot's camera
+        double w[kPasses][6];
+        int camv[kPasses];
+        auto request = [&](int rbase) {
 #pragma unroll
-            for (int j = 0; j < kLoads; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
-            camv = P.slot_cam[min(s0 + (t & 31), max(s1 - 1, 0))];
-        }
+            for (int j = 0; j < kPasses; ++j) {
+                const int slot = rbase + kPassSlots * j + grp;
+                const unsigned off = (a < kFA && slot < s1) ? 8u * ((unsigned)kRecW * (unsigned)slot + 6u * (unsigned)a) : BAD;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const d2 v = buf_load_2f64(r_w, off, 16u * (unsigned)k); w[j][2 * k] = v[0]; w[j][2 * k + 1] = v[1]; }
+                camv[j] = P.slot_cam[min(slot, max(s1 - 1, 0))];
+            }
+        };
+        request(s0);
         if constexpr (WAIT) {
             __shared__ int s_flag;
             if (t == 0) {
@@ -2275,29 +2283,17 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
             for (int i = t; i < P.n_pad; i += kBsThreads) s_yh[i] = handoff_load(&S.yhat[i]);
             // (the candidate's per-camera records are written by the solver workgroup once it has published the step)
         }
-        for (int rbase = s0; rbase < s1; rbase += kBsRound) {
-            const int rend = min(s1, rbase + kBsRound);
-            __syncthreads();                                            // the previous round is done with s_w / s_qv (and s_yh is there)
+        for (int rbase = s0; rbase < s1; rbase += kRoundSlots) {
+            const int rend = min(s1, rbase + kRoundSlots);
+            __syncthreads();                                            // the previous round is done with s_qv (and s_yh is there)
 #pragma unroll
-            for (int j = 0; j < kLoads; ++j) if (t + kBsThreads * j < kBsRound * kRecW) s_w[t + kBsThreads * j] = v[j];
-            const int cam_l = camv;
-            if (rbase + kBsRound < s1) {
-                // the next round's records are requested before this round computes
-                const size_t base = (size_t)kRecW * (rbase + kBsRound);
-#pragma unroll
-                for (int j = 0; j < kLoads; ++j) { const size_t e = base + t + kBsThreads * j; v[j] = wsrc[e < w_end ? e : w_end - 1]; }
-                camv = P.slot_cam[min(rbase + kBsRound + (t & 31), s1 - 1)];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int pass = 0; pass < kBsRound / (NTH / 16); ++pass) {
-                const int sl = (NTH / 16) * pass + grp;                          // slot of the round; its camera sits in lane sl of every wave
-                const int cam = __shfl(cam_l, sl);
-                const double yh = a < kFA ? s_yh[16 * cam + a] : 0.0;
+            for (int j = 0; j < kPasses; ++j) {
+                const int sl = kPassSlots * j + grp;                    // slot of the round
+                const double yh = a < kFA ? s_yh[16 * camv[j] + a] : 0.0;
                 double p[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    p[k] = (a < kFA ? s_w[kRecW * sl + 6 * a + k] : 0.0) * yh;
+                    p[k] = (a < kFA ? w[j][k] : 0.0) * yh;
                     p[k] = row16_allsum(p[k]);
                 }
                 if (a == 0) {
@@ -2305,6 +2301,7 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
                     for (int k = 0; k < 6; ++k) s_qv[sl][k] = p[k];
                 }
             }
+            if (rbase + kRoundSlots < s1) request(rbase + kRoundSlots);      // (boards of more than two views: the next round's records while this one's sums are formed)
             __syncthreads();
             // per board, its views in slot order (deterministic)
             if (t < nbl) {
