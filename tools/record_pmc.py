@@ -5,7 +5,7 @@
     python tools/record_pmc.py gpurun_out/pmc_<fetch tag> gpurun_out/pmc_<write tag> [config] [gpurun_out/pmc_<sq pass> ...]
 
 Further pass directories (SQ_* / GRBM_* counters) are averaged over the k_eval_gram dispatches into the entry's
-`sq_round4` block.
+`sq_round<N>` block (N = TSCM_ROUND, default 5).
 
 Units and corrections as MI355X_MICROARCH.md prescribes and tools/calib_fetch.hip confirmed on these boxes: both counters
 report KB; FETCH_SIZE counts half of the bytes of this library's 8 B/lane and 16 B/lane loads (x2), WRITE_SIZE is exact.
@@ -21,6 +21,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+
+ROUND = int(os.environ.get("TSCM_ROUND", "5"))       # which round's evidence this is (keys `sq_round<N>`, `..._all_kernels_round<N>`)
 
 
 def per_kernel(d, counter):
@@ -53,7 +55,7 @@ def main():
     n_corners = {4: 2160000, 5: 8640000}.get(config)
     keep = {k: v for k, v in doc.get(f"config{config}", {}).items() if k.startswith("sq")}       # SQ counter blocks are recorded separately
     doc[f"config{config}"] = {
-        "kernel_src_sha": sha, "round": 4,
+        "kernel_src_sha": sha, "round": ROUND,
         "FETCH_SIZE_KB_per_launch": ev["FETCH_SIZE_KB_per_launch"], "WRITE_SIZE_KB_per_launch": ev["WRITE_SIZE_KB_per_launch"],
         "read_bytes_corrected": ev["read_bytes_corrected"], "hbm_bytes_per_launch": ev["hbm_bytes_per_launch"],
         "algorithmic_bytes_per_launch": n_corners * bench.BYTES_PER_CORNER if n_corners else None,
@@ -72,8 +74,8 @@ def main():
             for c in tot:
                 sq[c] = tot[c] / n[c]
         sq["passes"] = "tools/pmc.sh, one rocprofv3 --pmc pass per directory: " + ", ".join(os.path.basename(d) for d in sq_dirs) + "; per k_eval_gram dispatch"
-        doc[f"config{config}"]["sq_round4"] = sq
-    doc[f"config{config}_all_kernels_round4"] = {"kernel_src_sha": sha, "per_launch": kernels}
+        doc[f"config{config}"][f"sq_round{ROUND}"] = sq
+    doc[f"config{config}_all_kernels_round{ROUND}"] = {"kernel_src_sha": sha, "per_launch": kernels}
     json.dump(doc, open(path, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:34s} read {v['read_bytes_corrected'] / 1e6:7.2f} MB  write {v['write_bytes'] / 1e6:7.2f} MB")
