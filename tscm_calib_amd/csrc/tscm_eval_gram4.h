@@ -183,16 +183,16 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     // record offsets of this lane's entries in the seven stores of a view (bytes inside the view's W / E record; lanes
     // without an entry store past the end of the buffer).  Columns by group: see g4_wcol.
     constexpr unsigned BAD = 0xffffe000u;
-    unsigned o1e = BAD, o1w = BAD, o2 = BAD, o3e = BAD, o4 = BAD, o5 = BAD, o6 = BAD;
+    unsigned o1e = BAD, o1w = BAD, o2 = BAD, o3e = BAD, o4 = BAD, o5 = BAD, o6 = BAD, o7a = BAD, o7b = BAD;
     {
         const int b = lb, j = lj, i = li;
         auto W = [](int wcol, int row) { return 8u * (unsigned)(6 * wcol + row); };
         const int f1 = g4_wcol(4 + i), f1j = g4_wcol(4 + j), f2 = g4_wcol(8 + i), f2j = g4_wcol(8 + j), f3 = g4_wcol(12 + i);
         if (b == 0 && j < 3 && i < 3) { o1e = 8u * (unsigned)(6 * j + i); o3e = 8u * (unsigned)(6 * i + 3 + j); }
-        if (b == 0 && j == 3 && i < 3) o1w = W(kFR, i);                      // w_b rows x r
+        if (b == 0 && j == 3 && i < 3) { o1w = W(kFR, i); o7a = 8u * (unsigned)i; }                 // w_b rows x r (and once more in the G region)
         if (b == 1 && j < 3) o1w = W(f1, 3 + j);                             // t_b rows x (t_c | alpha)
         if (b == 0 && i < 3) o2 = W(f1j, i);                                 // w_b rows x (t_c | alpha)
-        if (b == 0 && i == 3 && j < 3) o2 = W(kFR, 3 + j);                   // t_b rows x r
+        if (b == 0 && i == 3 && j < 3) { o2 = W(kFR, 3 + j); o7b = 8u * (unsigned)(3 + j); }       // t_b rows x r (G region)
         if (b == 3 && j < 3 && i < 3) o2 = W(f3, j);                         // w_b rows x (one* | xi | lambda), held transposed
         if (b == 0 && i < 3) o4 = W(f2j, i);                                 // w_b rows x (w_c | f*)
         if (b == 2 && j < 3) o4 = W(f2, 3 + j);                              // t_b rows x (w_c | f*)
@@ -300,6 +300,9 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
             buf_store_f64(r_rec, o4, offW, split2 ? u4 : a4);
             buf_store_f64(r_rec, o5, offW, T1 - accU[1]);
             buf_store_f64(r_rec, o6, offW, a4 - u4);
+            const unsigned offG = 8u * ((unsigned)(kRecW + kRecE) * (unsigned)P.V + (unsigned)kRecG * slot);
+            buf_store_f64(r_rec, o7a, offG, T0);          // E^T r once more, compact (k_reduce_stats reads it there)
+            buf_store_f64(r_rec, o7b, offG, tb1);
         }
 #ifdef TSCM_WAVE_TIMELINE
         { TL_STAMP(ts5); TL_ADD(0, ts0, ts1); TL_ADD(1, ts1, ts2); TL_ADD(2, ts2, ts3); TL_ADD(3, ts3, ts4); TL_ADD(4, ts4, ts5); }

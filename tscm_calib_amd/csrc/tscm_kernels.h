@@ -7,6 +7,7 @@
 //                      W region [V][84]  E^T [F | r]   COLUMN-major: 14 columns (F order, column 13 = E^T r) x 6 rows
 //                      E region [V][18]  E^T E_wb      3 columns (the w_b columns) x 6 rows: rows 0-2 w_b x w_b,
 //                                                      rows 3-5 t_b x w_b
+//                      G region [V][6]   E^T r         column 13 of W once more, compact (board statistics)
 //                    The t_b x t_b block of E^T E is not stored: it is (E_tb^T F_tc) R_c, three FMAs per entry from
 //                    the t_c columns of W and the camera rotation the view was evaluated with (tb_tb; cconst is
 //                    double-buffered like the records for that reason).
@@ -32,7 +33,9 @@ namespace tscm {
 
 constexpr int kRecW = 84;          // doubles per view in the W region: E^T [F | r], 14 columns x 6 rows, column-major
 constexpr int kRecE = 18;          // doubles per view in the E region: E^T E_wb, 3 columns x 6 rows, column-major
-constexpr int kRec = kRecW + kRecE;  // doubles per view over both regions (allocation size, offset limits)
+constexpr int kRecG = 6;           // doubles per view in the G region: E^T r once more, compact (round 5): the board statistics read 48
+                                   // contiguous bytes per view instead of the last 48 of every 672-byte W record
+constexpr int kRec = kRecW + kRecE + kRecG;  // doubles per view over the regions (allocation size, offset limits)
 constexpr int kWcolTc = 3;         // W columns of t_c: F index 3, 4, 5 (the gradient column E^T r is F index kFR = 13)
 // per-board factor record (doubles)
 constexpr int kFac = 56;
@@ -133,6 +136,7 @@ __device__ __forceinline__ void set_prio(int p)
 // record regions (V = views of this rank)
 __device__ __forceinline__ const double *rec_w(const double *rec, int slot) { return rec + (size_t)kRecW * slot; }
 __device__ __forceinline__ const double *rec_e(const double *rec, int V, int slot) { return rec + (size_t)kRecW * V + (size_t)kRecE * slot; }
+__device__ __forceinline__ const double *rec_g(const double *rec, int V, int slot) { return rec + (size_t)(kRecW + kRecE) * V + (size_t)kRecG * slot; }
 
 struct Options {
     int max_num_iterations;
@@ -445,11 +449,13 @@ typedef const double __attribute__((address_space(4))) *cptr4;
 
 // lane-constant part of the record addressing, computed once per kernel: byte offset of the lane's row-kq entry inside
 // the allocation for slot 0 (region base included) and the byte stride per slot of its region
-struct RecLane { unsigned off, stride; };
+struct RecLane { unsigned off, stride, goff, gstride; };
 __device__ __forceinline__ RecLane rec_lane(int lane, unsigned V)
 {
     const int col = lane & 15, kq = lane >> 4;
     RecLane r;
+    // the gradient column once more in the compact G region: row kq (kq < 3) / rows 3 | 4 5 (kq == 3) of the view's six
+    r.goff = col == kTcR ? 8u * ((unsigned)(kRecW + kRecE) * V + (unsigned)kq) : 0xffffe000u; r.gstride = col == kTcR ? 8u * kRecG : 0u;
     if (col < 3) { r.off = 8u * ((unsigned)kRecW * V + 6u * (unsigned)col + (unsigned)kq); r.stride = 8u * kRecE; }
     else if (col == 15) { r.off = 0xffffe000u; r.stride = 0u; }
     else {
@@ -493,6 +499,9 @@ __device__ __forceinline__ void store_view_record(__amdgpu_buffer_rsrc_t r_rec, 
     // ... and the v-row parts of f* / one* in the next record column
     buf_store_f64(r_rec, (split ? off : BAD) + 48u, 0u, selT - selU);
     buf_store_2f64(r_rec, (split && k3 ? off : BAD) + 56u, tbT[1] - tbU[1], tbT[2] - tbU[2]);
+    const unsigned og = rl.goff + __umul24(slot, rl.gstride);
+    buf_store_f64(r_rec, og, 0u, selT);
+    buf_store_2f64(r_rec, (k3 ? og : BAD) + 8u, tbT[1], tbT[2]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1009,9 +1018,9 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
                 double w[4][6];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const double *W = rec_w(S.rec[tgt], min(qb + u, q1 - 1));
+                    const double *G = rec_g(S.rec[tgt], P.V, min(qb + u, q1 - 1));
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) w[u][i] = W[6 * kFR + i];
+                    for (int i = 0; i < 6; ++i) w[u][i] = G[i];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
