@@ -67,12 +67,17 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
     double *bxy = lds_all + 4 * kTile32;                    // board points: one copy, written by every wave with the same values
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
-    const int cam = P.chunk_cam[chunk];
-    for (int i = lane; i < 2 * P.n_points; i += 64) bxy[i] = P.board_xy[i];
+    // head in two dependent round trips, as in k_eval_gram4 (round 5): control block + 16-byte chunk descriptor + the first 128
+    // board coordinates; then everything that hangs on the descriptor at once (below)
+    const v4i cd = *(const v4i __attribute__((address_space(4))) *)(const void *)(P.chunk_desc + chunk);
+    const int cam = cd[0], vb = cd[1], ve = cd[2];
+    const int n2 = 2 * P.n_points;
+    const double bx0 = P.board_xy[min(lane, n2 - 1)], bx1 = P.board_xy[min(lane + 64, n2 - 1)];
     // wave-uniform constants through the constant address space: scalar loads into SGPR operands; the
     // float copies k_view_prep stores behind the doubles feed the fp32 derivative math directly
     typedef const float __attribute__((address_space(4))) *fptr4;
-    const int vb = P.chunk_vb[chunk], ve = P.chunk_ve[chunk];
+    double *const cc_buf[2] = { S.cconst[0], S.cconst[1] };
+    double *const rec_buf[2] = { S.rec[0], S.rec[1] };
     const int col = lane & 15, kq = lane >> 4;
     d4 camU = { 0.0, 0.0, 0.0, 0.0 }, camV = { 0.0, 0.0, 0.0, 0.0 };
     double rr = 0.0;                               // this lane's share of r^T r, fp64
@@ -89,9 +94,9 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
     const lds_f4 pA = (lds_f4)(T2 + ((col >> 2) + 4 * (col & 3)) * kP2 + KB * kq);
     if (ctrl_done) return;
     const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
-    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(S.rec[tgt], sizeof(double) * (size_t)kRec * P.V);
-    const cptr4 cc = (cptr4)(S.cconst[tgt] + kCStride * cam);
-    const fptr4 cf = (fptr4)(S.cconst[tgt] + kCStride * cam + kCConst);
+    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(tgt ? rec_buf[1] : rec_buf[0], sizeof(double) * (size_t)kRec * P.V);
+    const cptr4 cc = (cptr4)((tgt ? cc_buf[1] : cc_buf[0]) + kCStride * cam);
+    const fptr4 cf = (fptr4)((tgt ? cc_buf[1] : cc_buf[0]) + kCStride * cam + kCConst);
     const RecLane rl = rec_lane(lane, (unsigned)P.V);
     const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
     const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
@@ -99,16 +104,30 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
     // read with v_readlane; the observations of a camera's views are contiguous, so the offset is a running
     // sum.  No dependent global load -- and therefore no in-order vmcnt wait behind the previous view's
     // record stores -- is left inside the view loop.
-    int off_next = vb < ve ? P.view_obs[vb] : 0;
+    int off_next = cd[3];
+    int m_cnt0 = 0, m_slot0 = 0;
+    if (vb + lane < min(ve, vb + 64)) { m_cnt0 = P.view_count[vb + lane]; m_slot0 = P.view_slot[vb + lane]; }
+    if (vb < ve) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
+    {
+        // one dword of every 64-byte line of the first view's and the camera's constants (doubles and floats) through the scalar cache
+        typedef const int __attribute__((address_space(4))) *cptr4i;
+        const cptr4i v0 = (cptr4i)(S.vconst + (size_t)kVStride * min(vb, P.V - 1)), c0 = (cptr4i)cc;
+        const int k0 = v0[0], k1 = v0[16], k2 = v0[32], k3 = v0[48], k4 = v0[64], k5 = v0[80], k6 = c0[16], k7 = c0[48], k8 = c0[80], k9 = c0[112], k10 = c0[128];
+        asm volatile("" :: "s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6), "s"(k7), "s"(k8), "s"(k9), "s"(k10));
+    }
+    // the board coordinates: every wave writes the same values into the workgroup's one copy
+    if (lane < n2) bxy[lane] = bx0;
+    if (lane + 64 < n2) bxy[lane + 64] = bx1;
+    for (int i = lane + 128; i < n2; i += 64) bxy[i] = P.board_xy[i];
     for (int vbase = vb; vbase < ve; vbase += 64) {
     const int vend = min(ve, vbase + 64);
     int m_cnt = 0, m_slot = 0;
-    if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
-    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));       // the loads complete here, outside the view loop
-    {
-        const int c0n = __builtin_amdgcn_readlane(m_cnt, 0);
-        if (lane < c0n) { pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next); }
+    if (vbase == vb) { m_cnt = m_cnt0; m_slot = m_slot0; }
+    else {
+        if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
+        pf_u = buf_load_f64(r_u, 8u * lane, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, 8u * lane, 8u * (unsigned)off_next);
     }
+    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));       // the loads complete here, outside the view loop
     for (int view = vbase; view < vend; ++view) {
         const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
         const int off = off_next;
