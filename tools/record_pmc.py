@@ -26,7 +26,7 @@ ROUND = int(os.environ.get("TSCM_ROUND", "5"))       # which round's evidence th
 
 
 def per_kernel(d, counter):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)      # (the newest pass: gpurun merges every call's files into the directory)
     tot, n = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -66,7 +66,7 @@ def main():
     if sq_dirs:
         sq = {}
         for d in sq_dirs:
-            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+            f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)      # (the newest pass: gpurun merges every call's files into the directory)
             tot, n = collections.defaultdict(float), collections.Counter()
             for r in csv.DictReader(open(f)):
                 if "k_eval_gram" in r["Kernel_Name"]:
