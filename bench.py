@@ -486,6 +486,9 @@ def main():
                        "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)" if exchange != "ipc" or n_dev >= world
                                       else f"frames sharded over {world} rank processes on {n_dev} GPU(s) (IPC exchange: a run of the multi-process path, not a scaling measurement)"},
             "exchange": exchange if multi else None, "n_devices": None if stub else min(world, n_dev),
+            # (the IPC back-end between DEVICES -- fine-grained buffers, explicit peer access: ABI 6 -- has never met a second device)
+            "exchange_note": ("IPC exchange across devices: correct by construction, never measured; RCCL is the production back-end"
+                              if multi and exchange == "ipc" and not stub and min(world, n_dev) > 1 else None),
             "natural_solve": {"termination": natural["message"], "iterations": natural["num_iterations"] - 1,
                               "rmse_px": natural["rmse"], "seconds": natural["seconds_total"],
                               "device_seconds": natural["seconds_solve"],
