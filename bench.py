@@ -68,7 +68,7 @@ FP32_PEAK_TFLOPS = 157.3             # MI355X FP32 vector (packed) = FP32 matrix
 HBM_PEAK_GBS = 8000.0
 BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
-CPU_BASELINE_ITERS = 8
+CPU_BASELINE_ITERS = 6               # 1 thread: 4 s per iteration of the full config 4 on the boxes seen so far -- ~24 s of CPU work
 EVENT_STRIDE_MAX = 8                 # an event pair holds the stream for ~11 us (6.4 in front of the launch, 4.6 behind it: kernel
                                      # trace of the driver's command, profiles/r05_eval_fixed_cost.txt): long runs time every 8th launch
 MIN_TIMED_LAUNCHES = 4               # ... short runs time more of them, so that at least this many are measured.  (8 until round 5:

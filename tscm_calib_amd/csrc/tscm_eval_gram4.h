@@ -105,11 +105,6 @@ __device__ __forceinline__ double quad_tb(double x, double c0, double c1, double
 __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S, int cand)
 {
     KTL(0);
-#ifdef TSCM_ABLATE
-    constexpr int ablate = TSCM_ABLATE;      // profiling builds only (make ABLATE=n): 1 no MFMA phases, 2 no epilogue, 4 no geometry, 8 one constant record per chunk
-#else
-    constexpr int ablate = 0;
-#endif
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
 #ifdef TSCM_WAVE_TIMELINE
     const long long tl_t0 = wall_clock64();
@@ -234,12 +229,12 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         if (tl_on && tl_nv < kTlViews) g_tlv[(size_t)(4 + kTlViews) * chunk + 4 + tl_nv] = wall_clock64();
         ++tl_nv;
 #endif
-        const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * ((ablate & 8) ? vb : view));      // (ablate 8: every view reads the chunk's first constant record: scalar-cache hits)
+        const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);
         auto VC = [&](int k) { return vcs[k]; };
         const bool valid = lane < cnt;
         double fv[16];                          // v-rows wait in registers until the u-rows have been consumed (index = tile column)
         auto PUT = [&](int c, double u, double v) { (c < 8 ? fu_lo : fu_hi)[4 * c] = u; fv[c] = v; };
-        if (valid && !(ablate & 4)) {
+        if (valid) {
             const double x = bxy[2 * lane], y = bxy[2 * lane + 1];
             // semantic column -> tile column of this kernel
             constexpr int tcol[15] = { kG4Wb, kG4Wb + 1, kG4Wb + 2, kG4Tc, kG4Tc + 1, kG4Tc + 2, kG4Wc, kG4Wc + 1, kG4Wc + 2,
@@ -267,7 +262,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         if (tl_nv == 1) tl_w[1] = wall_clock64();
 #endif
         double accU[3] = { 0.0, 0.0, 0.0 }, accV[3] = { 0.0, 0.0, 0.0 };
-        if (!(ablate & 1)) gram4_full(aN, aR, aB, accU);
+        gram4_full(aN, aR, aB, accU);
         wave_lds_fence();
         TL_STAMP(ts2);
         if (valid) {
@@ -276,13 +271,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         }
         wave_lds_fence();
         TL_STAMP(ts3);
-        if (!(ablate & 1)) gram4_full(aN, aR, aB, accV);
+        gram4_full(aN, aR, aB, accV);
         TL_STAMP(ts4);
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
 #pragma unroll
         for (int q = 0; q < 3; ++q) { camU[q] += accU[q]; camV[q] += accV[q]; }
         // ---- epilogue: the view's record (same values, same operation order as store_view_record) ------------------
-        if (!(ablate & 2)) {
+        {
             int le = lane;
             asm volatile("" : "+v"(le));         // lane predicates are rebuilt per view instead of living in SGPR pairs
             const int b = (le >> 2) & 3, i = le >> 4;
