@@ -61,10 +61,7 @@ def test_random_rig_three_iterations(hip_device, seed):
     assert max(d.values()) < 1e-7, d
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_random_large_rig_three_iterations(hip_device, seed):
-    """7..14 cameras (register/LDS solver up to 8, k_solve_reduced_big beyond), boards seen by 1..C cameras (the
-    explicit pair-list Schur path), unseen boards, ragged views."""
+def large_rig(seed):
     rng = np.random.default_rng(7000 + seed)
     C = int(rng.integers(7, 15))
     if rng.integers(0, 2):
@@ -78,7 +75,14 @@ def test_random_large_rig_three_iterations(hip_device, seed):
     cnt[idx] = rng.integers(0, p.n_points + 1, size=idx.shape[0])
     q = p.copy()
     q.view_count[:] = cnt
-    q = q.normalised()
+    return q.normalised()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_large_rig_three_iterations(hip_device, seed):
+    """7..14 cameras (register/LDS solver up to 8, k_solve_reduced_big beyond), boards seen by 1..C cameras (the
+    explicit pair-list Schur path), unseen boards, ragged views."""
+    q = large_rig(seed)
     pg, po = q.copy().normalised(), q.copy().normalised()
     with api.Solver(pg) as s:
         gs = s.solve(max_num_iterations=3)
