@@ -99,6 +99,47 @@ def fixed_cost(tl, tv):
         print(f"    {t:4.1f} us after the first wave start: waves past their first geometry {np.mean(cnt):.2f} per SIMD")
 
 
+def placement(L, tmin):
+    """Is the order in which the waves of a SIMD finish a function of the workgroup index?  (If it is, the chunk table could
+    hand the wave that the arbiter favours more views.)  Prints, per rank of a workgroup on its CU by block index, when its
+    waves end; how often that rank is blockIdx / 256 (round-robin placement over 8 XCDs x 32 CUs); and how often the waves of
+    a SIMD finish in block order."""
+    cu = collections.defaultdict(set)
+    for blk, wave, hw, xcc, t0, t1 in L:
+        cu[(xcc & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)].add(blk)
+    rank = {}
+    for v in cu.values():
+        for k, b in enumerate(sorted(v)):
+            rank[b] = k
+    by_rank = collections.defaultdict(list)
+    start_rank = collections.defaultdict(list)
+    for blk, wave, hw, xcc, t0, t1 in L:
+        by_rank[rank[blk]].append((t1 - tmin) / 100.0)
+        start_rank[rank[blk]].append((t0 - tmin) / 100.0)
+    print("  workgroups per CU:", dict(sorted(collections.Counter(len(v) for v in cu.values()).items())),
+          " rank on the CU == blockIdx / 256 for %.1f %% of the workgroups;" % (100.0 * sum(1 for b, k in rank.items() if k == b // 256) / len(rank)),
+          " XCD == blockIdx %% 8 for %.1f %% of the waves" % (100.0 * sum(1 for r in L if (r[3] & 15) == r[0] % 8) / len(L)))
+    for k in sorted(by_rank):
+        print(f"  waves of the {k + 1}. workgroup of a CU (by block index): start mean {statistics.fmean(start_rank[k]):5.2f}, end mean {statistics.fmean(by_rank[k]):6.2f} us"
+              f"  (p10 {sorted(by_rank[k])[len(by_rank[k]) // 10]:6.2f}  p90 {sorted(by_rank[k])[9 * len(by_rank[k]) // 10]:6.2f})")
+    simd = collections.defaultdict(list)
+    for blk, wave, hw, xcc, t0, t1 in L:
+        simd[(xcc & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3)].append((t1, blk))
+    full = [v for v in simd.values() if len(v) == 4]
+    in_order = sum(1 for v in full if [b for _, b in sorted(v)] == sorted(b for _, b in v))
+    rev_order = sum(1 for v in full if [b for _, b in sorted(v)] == sorted((b for _, b in v), reverse=True))
+    pos = collections.Counter()
+    for v in full:
+        order = [b for _, b in sorted(v)]
+        blks = sorted(order)
+        for k, b in enumerate(order):
+            pos[(blks.index(b), k)] += 1
+    print(f"  SIMDs with four waves: {len(full)}; they finish in block order on {in_order}, in reverse block order on {rev_order}")
+    print("  rows: rank by block index; columns: 1st..4th to finish")
+    for r in range(4):
+        print("   ", [pos[(r, k)] for k in range(4)])
+
+
 def main():
     if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
         lines = []
@@ -135,6 +176,7 @@ def main():
         starts = [sorted(v, key=lambda x: x[1])[k][0] for v in simd.values() if len(v) > k]
         print(f"  {k + 1}. wave to finish on its SIMD: end mean {statistics.fmean(ends):6.1f} us  (min {min(ends):6.1f}  max {max(ends):6.1f}),"
               f" start mean {statistics.fmean(starts):5.1f} us")
+    placement(L, tmin)
     ends = [r[5] for r in L]
     print(f"kernel (first start -> last end) {(max(ends) - tmin) / 100.0:.1f} us; wave duration mean "
           f"{statistics.fmean((r[5] - r[4]) / 100.0 for r in L):.1f} us")
