@@ -142,7 +142,9 @@ enum {
                                            /* block instead of along the camera-pair graph (same solution to rounding)       */
     TSCM_EXEC_GRAPH_REDUCED_ORDER = 64,    /* rigs of up to 4 cameras: k_solve_nd along the camera-pair graph instead of the  */
                                            /* dense k_solve_reduced (which is faster there: tests and A/B runs)               */
-    TSCM_EXEC_ALL = 127
+    TSCM_EXEC_SEPARATE_STATS = 128,        /* keep the reductions behind a candidate's evaluation (k_reduce_stats) a launch of  */
+                                           /* their own instead of the first workgroups of the next Schur-complement launch    */
+    TSCM_EXEC_ALL = 255
 };
 
 /* ceres::IterationSummary subset */

@@ -596,6 +596,28 @@ def test_control_step_in_the_schur_kernels_head_and_in_the_reductions_launch_agr
         assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+@pytest.mark.parametrize("cfg", [1, 3, 4, 5])
+def test_reductions_riding_in_the_schur_launch_and_in_a_launch_of_their_own_agree_bit_for_bit(hip_device, cfg):
+    """One GPU: the reductions behind a candidate's evaluation (camera-tile sums, board statistics, the snapshot of the LM
+    state) are the first workgroups of the next Schur-complement launch (k_schur_gram<NV, true>: written through, counted
+    in, waited for in front of the control step); tscm_options.exec_flags = TSCM_EXEC_SEPARATE_STATS keeps them
+    k_reduce_stats, a launch of their own.  Same decisions, same log, same bits -- natural solves and forced iterations
+    with rejected steps, grids of one round (configs 1, 3, 4) and of several (config 5)."""
+    forced = dict(max_num_iterations=12 if cfg >= 4 else 30, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
+                  min_trust_region_radius=0.0)
+    for opts in (dict(), forced):
+        p = synth.make_config(cfg)
+        a, b = p.copy().normalised(), p.copy().normalised()
+        with api.Solver(a) as s:
+            sa = s.solve(**opts)
+        with api.Solver(b) as s:
+            sb = s.solve(exec_flags=lib.EXEC_SEPARATE_STATS, **opts)
+        assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+        assert sa["iterations"] == sb["iterations"]
+        assert sa["final_cost"] == sb["final_cost"] and sa["lm_iterations"] == sb["lm_iterations"]
+        assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+
+
 def test_every_fusion_switched_off_gives_the_same_bits(hip_device):
     """exec_flags = SEPARATE_T_REDUCE | SEPARATE_BACKSUB | SEPARATE_CONTROL: the six-launch iteration of the start of
     round 3 (k_schur_gram, k_T_reduce, k_solve_reduced, k_backsub_prep, Gram kernel, k_reduce_control) against the

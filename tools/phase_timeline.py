@@ -21,6 +21,17 @@ def report(name, st, phases):
     if not len(st):
         print(f"{name}: no stamps")
         return
+    red = st[st[:, 6] < 0]
+    if len(red):      # k_schur_gram<NV, true>: the reductions of the evaluation ride in front of the grid
+        t0r = st[:, 0].min()
+        print(f"{name}: {len(red)} reduction workgroups in front: start mean {(red[:, 0] - t0r).mean() / 100:.2f} (last {(red[:, 0] - t0r).max() / 100:.2f}), "
+              f"end mean {(red[:, 5] - t0r).mean() / 100:.2f}, last end {(red[:, 5] - t0r).max() / 100:.2f} us after the launch's first start")
+        rest = st[st[:, 6] >= 0]
+        w = (rest[:, 7] >> 1) / 100.0
+        print(f"  the others saw the count complete {w.mean():.2f} us after their start (min {w.min():.2f}, max {w.max():.2f}); "
+              f"that is {((rest[:, 0] - t0r) / 100.0 + w).mean():.2f} us after the launch's first start (max {((rest[:, 0] - t0r) / 100.0 + w).max():.2f})")
+        t0keep = t0r
+        st = rest
     t0 = st[:, 0].min()
     us = (st[:, :6] - t0) / 100.0
     order = np.argsort(us[:, 0], kind="stable")

@@ -61,6 +61,7 @@ constexpr int kCConst = 48;        // per-camera constants: [0,9) R_c, [9,12) t_
 constexpr int kCStride = 72;       // doubles per camera record in cconst: 48 doubles, then the same 48 values as floats
 constexpr int kCst = 80;           // LDS constant block: [0,27) view, [27,75) camera
 constexpr int kScal = 8;           // scalars appended to H_stage
+constexpr int kStStride = 16;      // doubles between the board-statistics partials of two workgroups: a 128-byte line each (written by ONE workgroup: see k_schur_gram<NV, true>)
 constexpr int kCamSl = 16;         // the per-camera tile reduction runs in slices of 32 of the 512 raw entries: C * kCamSl workgroups
 constexpr int kSmallBids = 36;     // camera-pair blocks of a rig of <= 8 cameras (8 + 28): their partial-tile ranges travel as kernel arguments
 constexpr int kMaxCamLds = 8;      // n_pad = 16*C <= 128: reduced system solved in registers/LDS (k_solve_reduced)
@@ -240,6 +241,8 @@ struct DevState {
     Ctrl *ctrl;
     CtrlHead *ctrl_snap;               // copy of the control block's head taken by k_reduce_stats: what the control step in the head of the
                                        // NEXT launch (k_schur_gram, every workgroup) reads while that launch's writer workgroup advances `ctrl`
+    int *stats_count, *stats_flag;     // k_schur_gram<NV, true>: arrivals of its reduction workgroups, counted over the solve; the count the last arrival of a launch
+                                       // found, in a line of its own (what the waiting workgroups poll: loads there, read-modify-writes here)
     struct CtlPub *ctl_pub;            // outcome of that step, published by the writer workgroup for the workgroups of later rounds of the grid
 };
 // epoch: number of control steps taken in k_schur_gram's head in this solve so far (monotonic, zeroed by k_begin_solve)
@@ -1047,7 +1050,7 @@ __device__ void board_stats_block(const DevProblem &P, const DevState &S, int ca
     double red[2] = { gsq, xsq }, m = gmax;
     block_reduce256<2>(red, m, sm);
     const double s1 = red[0], s2 = red[1];
-    if (threadIdx.x == 0) { handoff_store(&S.st_part[3 * blk], m); handoff_store(&S.st_part[3 * blk + 1], s1); handoff_store(&S.st_part[3 * blk + 2], s2); }
+    if (threadIdx.x == 0) { handoff_store(&S.st_part[kStStride * blk], m); handoff_store(&S.st_part[kStStride * blk + 1], s1); handoff_store(&S.st_part[kStStride * blk + 2], s2); }
 }
 
 // one launch for the two independent post-evaluation reductions:
@@ -1163,7 +1166,7 @@ __device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, cons
         for (int i = t; i < n; i += 4 * 256) {
             double q[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + 3 * (size_t)min(i + 256 * u, n - 1); q[u][0] = THROUGH ? handoff_load(src) : src[0]; q[u][1] = THROUGH ? handoff_load(src + 1) : src[1]; q[u][2] = THROUGH ? handoff_load(src + 2) : src[2]; }
+            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + kStStride * (size_t)min(i + 256 * u, n - 1); q[u][0] = THROUGH ? handoff_load(src) : src[0]; q[u][1] = THROUGH ? handoff_load(src + 1) : src[1]; q[u][2] = THROUGH ? handoff_load(src + 2) : src[2]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const bool in = i + 256 * u < n; g4[u] = fmax(g4[u], in ? q[u][0] : 0.0); s4[u] += in ? q[u][1] : 0.0; x4[u] += in ? q[u][2] : 0.0; }
         }
@@ -1240,6 +1243,8 @@ __device__ __forceinline__ void finish_evaluation(const DevProblem &P, const Dev
 // The same step for a workgroup that only needs its OUTCOME (every workgroup of k_schur_gram but the extra one that
 // writes): of H only the gradient column and the cost entry of each camera enter the step -- 15 entries per camera, two
 // loads per thread straight from the finished sums instead of 16 KB through LDS and two barriers.  Hl: 256 C + kScal + 8.
+// THROUGH: the finished sums and the board statistics were handed over inside this launch (k_schur_gram<NV, true>)
+template <bool THROUGH = false>
 __device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int init, int have_backsub, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
 {
     const int t = threadIdx.x;
@@ -1248,9 +1253,10 @@ __device__ __forceinline__ void control_outcome(const DevProblem &P, const DevSt
     // thread (camera m, a): H[m][a][kFR] for a < 14 (a = kFR = 13: the cost entry)
     const int m = min(t >> 4, P.C - 1), a = t & 15;
     const int fa = min(a, 13), ta = f_tile(fa), tb = f_tile(kFR), mk = f_mask(fa) & f_mask(kFR);
-    const double gu = S.campart2[(size_t)512 * m + ta * 16 + tb], gv = S.campart2[(size_t)512 * m + 256 + ta * 16 + tb];
+    const double *pu = &S.campart2[(size_t)512 * m + ta * 16 + tb], *pv = &S.campart2[(size_t)512 * m + 256 + ta * 16 + tb];
+    const double gu = THROUGH ? handoff_load(pu) : *pu, gv = THROUGH ? handoff_load(pv) : *pv;
     double *scl = Hl + 256 * P.C;
-    reduce_scalar_partials<false>(P, S, have_backsub, pre.c.lin_fail, scl, sm);
+    reduce_scalar_partials<THROUGH>(P, S, have_backsub, pre.c.lin_fail, scl, sm);
     if (t < 16 * P.C && a < 14) Hl[256 * m + a * 16 + kFR] = ((mk & 1) ? gu : 0.0) + ((mk & 2) ? gv : 0.0);
     __syncthreads();
     control_step(P, S, init, pre, sm, Hl, scl, nullptr, /*writer=*/false, out);
@@ -1482,11 +1488,22 @@ struct RawTc {
 // launch starts -- take the step themselves; the workgroups of LATER rounds of the grid (config 5 on one GPU: 1256 chunks,
 // 2.5 rounds) start when a first-round workgroup has finished, long after workgroup 0, and read the published outcome:
 // the step is paid once per launch, not once per round.
-template <int NV>
-__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch)
+// RIDE (round 5, one GPU, a candidate's evaluation): the reductions behind the evaluation -- k_reduce_stats' workgroups -- are the
+// FIRST n_stats workgroups of this grid instead of a launch of their own (5.2 us + a kernel boundary at config 4; 7.5 at config
+// 5): they are dispatched first, write their results through (handoff_store, as they always did), the last one of them takes the
+// snapshot of the LM state, and each counts itself in (S.stats_count, monotonic over the solve: stats_target = n_stats x the number of such launches
+// so far; the last arrival copies the count into S.stats_flag, a line of its own: 370 polling workgroups on the counter's line
+// held the arrivals up by 4.5 us).  Every other workgroup waits for that count in front of the control step -- the reduction
+// workgroups hold the lowest block indices, so they are resident or finished whatever else is -- and reads the finished sums and
+// the board statistics with handoff_load.  The snapshot is read through the scalar cache as before: nobody touches its lines in
+// this launch before the count is complete (the instrumented build's scope reads S.ctrl instead), the scalar caches and the
+// XCDs' L2s start a launch invalidated, one workgroup wrote all of it THROUGH -- the first touch of a waiting workgroup's XCD
+// fetches what was written.  (st_part / campart2 are pieces of lines written from several XCDs: handoff_load, no shortcut.)
+template <int NV, bool RIDE = false>
+__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target)
 {
 #ifdef TSCM_WAVE_TIMELINE
-    KtlScope ktl_scope(3, ctl ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));      // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
+    KtlScope ktl_scope(3, ctl && !RIDE ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));      // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
 #endif
     PHASE_STAMP(tsk);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
@@ -1495,8 +1512,10 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     // the Jacobi scaling of the camera columns written by the extra workgroup)
     const int ctl_init = (ctl >> 2) & 1;
     ctl &= 3;
-    const bool extra = ctl != 0 && blockIdx.x == 0;        // the workgroup that writes the control step's results, and nothing else
-    const int cblk = ctl ? max((int)blockIdx.x - 1, 0) : (int)blockIdx.x;
+    const int n_stats = RIDE ? P.C * kCamSl + S.n_st_blocks : 0;
+    const int bid = (int)blockIdx.x - n_stats;             // index among the workgroups of the Schur complement proper
+    const bool extra = ctl != 0 && bid == 0;               // the workgroup that writes the control step's results, and nothing else
+    const int cblk = ctl ? max(bid - 1, 0) : max(bid, 0);
     const int4 desc = P.bc_desc[chunk0 + cblk];
     constexpr int NT = NV * (NV + 1) / 2;
     // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
@@ -1510,6 +1529,33 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     double (&tiles)[4][NT][256] = lds_blk.tiles;
     int ctrl_done, cur;
     double radius, dmin, dmax;
+#ifdef TSCM_WAVE_TIMELINE
+    long long t_waited = 0;
+#endif
+    if (RIDE && bid < 0) {
+        // a reduction workgroup of the evaluation in front of this launch (k_reduce_stats' body; the candidate's evaluation)
+        double *sm = reinterpret_cast<double *>(&lds_blk);
+        const int blk = (int)blockIdx.x, nc = P.C * kCamSl;
+        if (blk == n_stats - 1 && threadIdx.x < sizeof(CtrlHead) / 8)
+            __hip_atomic_store(&reinterpret_cast<unsigned long long *>(S.ctrl_snap)[threadIdx.x], reinterpret_cast<const unsigned long long *>(S.ctrl)[threadIdx.x],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!S.ctrl->done) {
+            if (blk < nc) cam_reduce_block(P, S, blk, sm);
+            else board_stats_block(P, S, /*cand=*/1, /*init=*/0, blk - nc, sm);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the written-through results are complete, then the count (see "hand-offs")
+        __syncthreads();
+        if (threadIdx.x == 0 && __hip_atomic_fetch_add(S.stats_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stats_target - 1)
+            __hip_atomic_store(S.stats_flag, stats_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the last one: everybody's results are complete
+#ifdef TSCM_WAVE_TIMELINE
+        if (threadIdx.x == 0 && ktl_scope.on && blk < kKtlGroups) {
+            long long *o = g_phs + (size_t)kPhStamps * blk;
+            const long long te = wall_clock64();
+            o[0] = tsk; o[1] = te; o[2] = te; o[3] = te; o[4] = te; o[5] = te; o[6] = -1; o[7] = 0;      // (boards = -1: a reduction workgroup)
+        }
+#endif
+        return;
+    }
     if (ctl) {
         constexpr int kHl = 256 * kMaxCamLds + kScal + 8, kGall = 512 * kMaxCamLds;
         static_assert(sizeof(Lds) / sizeof(double) >= kHl + kGall + 256, "finish_evaluation's LDS (C <= 8) fits the kernel's block");
@@ -1520,8 +1566,33 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
         // launch commits the advanced state to S.ctrl while the others may not even have started -- a workgroup that read
         // S.ctrl itself could find the step already taken and take it a second time.  Nobody writes the snapshot here.
         const CtrlHead *head = S.ctrl_snap;
+        if (RIDE) {
+            // the reductions ride in this launch: their results (and the snapshot) are there when all of them have counted themselves in
+            // (a workgroup of a later round finds the count complete)
+            __shared__ int s_late;
+            if (threadIdx.x == 0) {
+                const long long t_start = wall_clock64();
+                int late = 0;
+                while (__hip_atomic_load(S.stats_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stats_target) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t_start > kHandoffTimeoutTicks) { late = 1; break; }
+                }
+                if (late) {          // a device fault like any other late hand-off
+                    __hip_atomic_store(&S.ctrl->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S.ctrl->term_type, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&S.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_late = late;
+            }
+            __syncthreads();
+            if (s_late) return;
+        }
+        PHASE_STAMP(tsw);
+#ifdef TSCM_WAVE_TIMELINE
+        t_waited = tsw;
+#endif
         if (head->done) return;
-        if (!extra && (int)blockIdx.x >= first_round) {
+        if (!extra && bid >= first_round) {
             // a later round of the grid: the outcome is published (or about to be)
             if (threadIdx.x == 0) {
                 const long long t_start = wall_clock64();
@@ -1548,7 +1619,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
             control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, &s_ctl);
         } else {
             if (extra) finish_evaluation<false>(P, S, ctl_init, !ctl_init, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
-            else control_outcome(P, S, ctl_init, !ctl_init, scratch, scratch + kHl, &s_ctl, head);
+            else control_outcome<false>(P, S, ctl_init, !ctl_init, scratch, scratch + kHl, &s_ctl, head);
         }
         if (extra) {
             // thread 0 took the serial part of the step and committed it: the outcome, written through, then the epoch
@@ -1702,7 +1773,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
 #ifdef TSCM_WAVE_TIMELINE
     if (threadIdx.x == 0 && ktl_scope.on && (int)blockIdx.x < kKtlGroups) {
         long long *o = g_phs + (size_t)kPhStamps * blockIdx.x;
-        o[0] = tsk; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = wall_clock64(); o[6] = nbd; o[7] = (int)blockIdx.x >= first_round;
+        o[0] = tsk; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = wall_clock64(); o[6] = nbd; o[7] = (bid >= first_round ? 1 : 0) | ((RIDE && t_waited ? t_waited - tsk : 0) << 1);      // (bit 0: a later round; above: ticks until the riding reductions had arrived)
     }
 #endif
 #ifdef TSCM_PHASE_PROFILE
@@ -2610,7 +2681,7 @@ __global__ __launch_bounds__(kVPrepThreads) void k_begin_view_prep(DevProblem P,
     // bak_*: where a copy of the start point goes (what a re-run of this solve starts from: a late hand-off, tscm_solver.hip)
     const int i0 = blockIdx.x * kVPrepThreads + threadIdx.x, n = gridDim.x * kVPrepThreads;
     if (i0 == 0) { head.t_begin = wall_clock64(); static_cast<CtrlHead &>(*S.ctrl) = head; }
-    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
+    if (i0 == 0) { *S.t_count = 0; *S.y_flag = 0; *S.fac_fail = 0; S.ctl_pub->epoch = 0; *S.stats_count = 0; *S.stats_flag = 0; }      // every solve starts with the hand-off counters of the fused launches at zero
     const double *cam = src_cam ? src_cam : S.cam_rt[0], *intr = src_intr ? src_intr : S.intr[0], *board = src_board ? src_board : S.board_rt[0];
     for (int i = i0; i < 6 * P.C; i += n) { const double v = cam[i]; if (src_cam) S.cam_rt[0][i] = v; if (bak_cam) bak_cam[i] = v; }
     for (int i = i0; i < 9 * P.C; i += n) { const double v = intr[i]; if (src_intr) S.intr[0][i] = v; if (bak_intr) bak_intr[i] = v; }

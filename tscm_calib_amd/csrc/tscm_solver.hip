@@ -125,6 +125,8 @@ struct tscm_solver {
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
     int schur_resident[4] = { 0, 0, 0, 0 };   // workgroups of k_schur_gram<NV> that are resident at once (occupancy x CUs): the first round of its grid
     int ctl_epoch = 0;                  // control steps taken in k_schur_gram's head in this solve so far
+    bool stats_ride = false;            // this solve: the reductions behind a candidate's evaluation are the first workgroups of the next k_schur_gram (k_schur_gram<NV, true>)
+    int stats_epoch = 0;                // launches of k_schur_gram<NV, true> in this solve so far (S.ctl_pub->stats_arrived counts their reduction workgroups)
     int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator); + 4: the solve's initial evaluation
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0, withhold_next = 0; // this solve / the next one: fault injection (tscm_solver_debug_withhold_handoff)
@@ -688,10 +690,13 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     S.n_st_blocks = (B + 255) / 256;
     if ((rc = dev_alloc(s, &S.bs_part, 2 * (size_t)S.n_bs_blocks))) return rc;
     S.n_bs_blocks = (B + s->bs_threads / 8 - 1) / (s->bs_threads / 8);        // groups of k_backsub_prep's geometry
-    if ((rc = dev_alloc(s, &S.st_part, 3 * (size_t)S.n_st_blocks))) return rc;
+    if ((rc = dev_alloc(s, &S.st_part, kStStride * (size_t)S.n_st_blocks))) return rc;
     if ((rc = dev_alloc(s, &S.ctrl, 1))) return rc;
     if ((rc = dev_alloc(s, &S.ctrl_snap, 1))) return rc;
     if ((rc = dev_alloc(s, &S.ctl_pub, 1))) return rc;
+    if ((rc = dev_alloc(s, &S.stats_count, 64))) return rc;      // (256 bytes each: lines of their own)
+    if ((rc = dev_alloc(s, &S.stats_flag, 64))) return rc;
+    HIP_TRY(hipMemset(S.stats_count, 0, 256)); HIP_TRY(hipMemset(S.stats_flag, 0, 256));
     HIP_TRY(hipMemset(S.ctl_pub, 0, sizeof(CtlPub)));
     HIP_TRY(hipMemset(S.T, 0, sizeof(double) * 256 * (size_t)n_bids));
     HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal + world)));
@@ -1060,6 +1065,8 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub, bool h
             // last evaluation of the solve).  Round 5: the solve's INITIAL evaluation as well (eval_pending = 1 | 4: IterationZero
             // in the head of the first Schur kernel) -- k_reduce_control's last workgroup cost every solve 18.4 us where
             // k_reduce_stats takes 5.5 and the head 4.4
+            // ... and a candidate's reductions ride in that launch as well (eval_pending | 8: k_schur_gram<NV, true>)
+            if (s->stats_ride && !init) { s->eval_pending = 1 | 8; continue; }
             hipLaunchKernelGGL(k_reduce_stats, dim3(P.C * kCamSl + S.n_st_blocks), dim3(256), 0, s->stream, P, S, cand, init);
             s->eval_pending = init ? 5 : 1;
             continue;
@@ -1094,10 +1101,17 @@ static int enqueue_iteration(LmRun &run)
         const int ctl = s->eval_pending;                  // (ctl_in_schur: exactly one of the three variants below is launched)
         s->eval_pending = 0;
         if (P.n_slow) hipLaunchKernelGGL(k_schur_factor, dim3((P.n_slow + 255) / 256), dim3(256), 0, s->stream, P, S);
-        const int ce = ctl ? ++s->ctl_epoch : 0;          // (ctl: 1 one GPU | 2 communicator, + 4: the initial evaluation's step)
-        if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce);
-        if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce);
-        if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce);
+        const int ce = ctl ? ++s->ctl_epoch : 0;          // (ctl: 1 one GPU | 2 communicator, + 4: the initial evaluation's step, + 8: the reductions ride)
+        if (ctl & 8) {
+            const int ns = P.C * kCamSl + S.n_st_blocks, target = ns * ++s->stats_epoch;
+            if (s->nv_chunks[1]) hipLaunchKernelGGL((k_schur_gram<1, true>), dim3(ns + s->nv_chunks[1] + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl & 7, s->schur_resident[1], ce, target);
+            if (s->nv_chunks[2]) hipLaunchKernelGGL((k_schur_gram<2, true>), dim3(ns + s->nv_chunks[2] + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl & 7, s->schur_resident[2], ce, target);
+            if (s->nv_chunks[3]) hipLaunchKernelGGL((k_schur_gram<3, true>), dim3(ns + s->nv_chunks[3] + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl & 7, s->schur_resident[3], ce, target);
+        } else {
+            if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0);
+            if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0);
+            if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce, 0);
+        }
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
@@ -1273,6 +1287,9 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
                               !(opt.exec_flags & TSCM_EXEC_SEPARATE_CONTROL);
             s->eval_pending = 0;
             s->ctl_epoch = 0;
+            // (one GPU, the control step from the finished sums themselves: not behind an all-reduce)
+            s->stats_ride = s->ctl_in_schur && !s->comm && s->P.C <= kMaxCamLds && !(opt.exec_flags & TSCM_EXEC_SEPARATE_STATS);
+            s->stats_epoch = 0;
         }
         s->withhold = s->withhold_next; s->withhold_next = 0;
         if (!rerun) { s->no_rerun = s->no_rerun_next; s->no_rerun_next = false; }
@@ -1349,7 +1366,10 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     for (tscm_solver *s : run.m) {
         const int nb = std::min(256, (6 * std::max(s->B, s->C) + 255) / 256 + 1);
         if (s->eval_pending & 1) {
-            hipLaunchKernelGGL(k_finish_solve, dim3(nb + 1), dim3(256), 0, s->stream, s->P, s->S, s->eval_pending >> 2, !(s->eval_pending >> 2), s->C, s->B, s->d_h_ctrl);
+            // (the reductions of the solve's last evaluation found no Schur kernel to ride in)
+            if (s->eval_pending & 8) hipLaunchKernelGGL(k_reduce_stats, dim3(s->P.C * kCamSl + s->S.n_st_blocks), dim3(256), 0, s->stream, s->P, s->S, 1, 0);
+            const int was_init = (s->eval_pending >> 2) & 1;
+            hipLaunchKernelGGL(k_finish_solve, dim3(nb + 1), dim3(256), 0, s->stream, s->P, s->S, was_init, !was_init, s->C, s->B, s->d_h_ctrl);
             s->eval_pending = 0;
             continue;
         }
