@@ -21,17 +21,15 @@ def report(name, st, phases):
     if not len(st):
         print(f"{name}: no stamps")
         return
-    red = st[st[:, 6] < 0]
-    if len(red):      # k_schur_gram<NV, true>: the reductions of the evaluation ride in front of the grid
+    red = st[(st[:, 7] >> 32) > 0]
+    if len(red):      # k_schur_gram<NV, true>: the first workgroups take a reduction block of the evaluation in front of their chunk
         t0r = st[:, 0].min()
-        print(f"{name}: {len(red)} reduction workgroups in front: start mean {(red[:, 0] - t0r).mean() / 100:.2f} (last {(red[:, 0] - t0r).max() / 100:.2f}), "
-              f"end mean {(red[:, 5] - t0r).mean() / 100:.2f}, last end {(red[:, 5] - t0r).max() / 100:.2f} us after the launch's first start")
-        rest = st[st[:, 6] >= 0]
-        w = (rest[:, 7] >> 1) / 100.0
-        print(f"  the others saw the count complete {w.mean():.2f} us after their start (min {w.min():.2f}, max {w.max():.2f}); "
-              f"that is {((rest[:, 0] - t0r) / 100.0 + w).mean():.2f} us after the launch's first start (max {((rest[:, 0] - t0r) / 100.0 + w).max():.2f})")
-        t0keep = t0r
-        st = rest
+        rd = (red[:, 7] >> 32) / 100.0
+        print(f"{name}: {len(red)} workgroups with a reduction block in front: block done {rd.mean():.2f} us after their start (max {rd.max():.2f}; "
+              f"last {((red[:, 0] - t0r) / 100.0 + rd).max():.2f} us after the launch's first start)")
+        w = ((st[:, 7] & 0xffffffff) >> 1) / 100.0
+        print(f"  the count was seen complete {w.mean():.2f} us after a workgroup's start (min {w.min():.2f}, max {w.max():.2f}); "
+              f"that is {((st[:, 0] - t0r) / 100.0 + w).mean():.2f} us after the launch's first start (max {((st[:, 0] - t0r) / 100.0 + w).max():.2f})")
     t0 = st[:, 0].min()
     us = (st[:, :6] - t0) / 100.0
     order = np.argsort(us[:, 0], kind="stable")

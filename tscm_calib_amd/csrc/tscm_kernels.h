@@ -1081,7 +1081,24 @@ struct CtlOut { int cur, done; double radius, dmin, dmax; };
 // `head`: where the LM state is read from -- S.ctrl where the calling workgroup is the only one that takes the step
 // (k_reduce_control's last workgroup, k_control_tail, k_control), S.ctrl_snap where every workgroup of a launch takes it
 // while one of them writes S.ctrl (k_schur_gram)
-__device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre, const CtrlHead *head)
+// ... split in two for a workgroup that has to WAIT for the evaluation's reductions first (k_schur_gram<NV, true>): what does not
+// depend on them -- the parameters of both buffers, the camera flags, the back-substitution's partials (summed per thread) -- is
+// requested in front of the wait, the LM state behind it
+struct ControlEarly { double x0[2], x1[2]; int act[2], cst[2]; double mb, ss; };
+__device__ __forceinline__ void control_early_params(const DevProblem &P, const DevState &S, ControlEarly &e)
+{
+    // (both parameter buffers and the camera flags are requested without waiting for `cur`: one round trip, not two)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = threadIdx.x + 256 * j;
+        const int m = min(p >> 4, P.C - 1), a = p & 15;
+        const int ia = a < 6 ? 6 * m + a : 9 * m + min(a - 6, 8);
+        e.x0[j] = a < 6 ? S.cam_rt[0][ia] : S.intr[0][ia];
+        e.x1[j] = a < 6 ? S.cam_rt[1][ia] : S.intr[1][ia];
+        e.act[j] = P.cam_active[m]; e.cst[j] = P.cam_const[m];
+    }
+}
+__device__ __forceinline__ void control_state(const DevProblem &P, int init, ControlPre &pre, const CtrlHead *head, const ControlEarly &e)
 {
     // (the LM state through the scalar cache: wave-uniform, and when 500 workgroups take the step at once -- k_schur_gram's
     // head -- 2,000 waves x 22 vector loads of the same six cache lines queue up at one L2 channel)
@@ -1094,27 +1111,21 @@ __device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevS
         for (unsigned q = 0; q < sizeof(CtrlHead) / 8; ++q) w[q] = src[q];
         __builtin_memcpy(&pre.c, w, sizeof(CtrlHead));
     }
-    // (both parameter buffers and the camera flags are requested without waiting for `cur`: one round trip, not two)
-    double x0[2], x1[2];
-    int act[2], cst[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = threadIdx.x + 256 * j;
-        const int m = min(p >> 4, P.C - 1), a = p & 15;
-        const int ia = a < 6 ? 6 * m + a : 9 * m + min(a - 6, 8);
-        x0[j] = a < 6 ? S.cam_rt[0][ia] : S.intr[0][ia];
-        x1[j] = a < 6 ? S.cam_rt[1][ia] : S.intr[1][ia];
-        act[j] = P.cam_active[m]; cst[j] = P.cam_const[m];
-    }
     const int tgt = init ? pre.c.cur : (pre.c.cur ^ 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int p = threadIdx.x + 256 * j;
         const int a = p & 15;
         const bool in = p < 16 * P.C && a < 15;
-        pre.x[j] = in ? (tgt ? x1[j] : x0[j]) : 0.0;
-        pre.free_param[j] = in & (act[j] != 0) & !((a < 6) & (cst[j] != 0));
+        pre.x[j] = in ? (tgt ? e.x1[j] : e.x0[j]) : 0.0;
+        pre.free_param[j] = in & (e.act[j] != 0) & !((a < 6) & (e.cst[j] != 0));
     }
+}
+__device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevState &S, int init, ControlPre &pre, const CtrlHead *head)
+{
+    ControlEarly e;
+    control_early_params(P, S, e);
+    control_state(P, init, pre, head, e);
 }
 __device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy,
                              bool writer = true, CtlOut *out = nullptr);
@@ -1138,11 +1149,11 @@ __device__ __forceinline__ double camera_tile_entry(const double *G, int t)
 // and the eight + four of them in the ragged ends were twelve memory round trips in a row (5 us of the control
 // workgroup's 10, tools/kernel_timeline.py).
 // THROUGH: the board statistics were handed over inside this launch (handoff_store): read them the same way
-template <bool THROUGH>
-__device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, const DevState &S, int have_backsub, int lin_fail, double *sc, double *sm)
+// (the back-substitution's partials, summed per thread: written by the launch before -- no hand-off)
+__device__ __forceinline__ void backsub_partials(const DevState &S, int have_backsub, double &mb, double &ss)
 {
     const int t = threadIdx.x;
-    double mb = 0.0, ss = 0.0;
+    mb = 0.0; ss = 0.0;
     if (have_backsub) {
         const d2 *bp = reinterpret_cast<const d2 *>(S.bs_part);
         const int n = S.n_bs_blocks;
@@ -1159,6 +1170,11 @@ __device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, cons
         const d2 r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         mb = r[0]; ss = r[1];
     }
+}
+template <bool THROUGH>
+__device__ __forceinline__ void reduce_scalar_partials_from(const DevProblem &P, const DevState &S, double mb, double ss, int lin_fail, double *sc, double *sm)
+{
+    const int t = threadIdx.x;
     double gm = 0.0, gs = 0.0, xs = 0.0;
     {
         const int n = S.n_st_blocks;
@@ -1179,6 +1195,13 @@ __device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, cons
         sc[0] = mb; sc[1] = ss; sc[2] = xs; sc[3] = gs; sc[4] = lin_fail ? 1.0 : 0.0; sc[5] = 0.0; sc[6] = 0.0; sc[7] = 0.0;
         for (int r = 0; r < P.world; ++r) sc[kScal + r] = r == P.rank ? gm : 0.0;
     }
+}
+template <bool THROUGH>
+__device__ __forceinline__ void reduce_scalar_partials(const DevProblem &P, const DevState &S, int have_backsub, int lin_fail, double *sc, double *sm)
+{
+    double mb, ss;
+    backsub_partials(S, have_backsub, mb, ss);
+    reduce_scalar_partials_from<THROUGH>(P, S, mb, ss, lin_fail, sc, sm);
 }
 
 // camera tiles (raw u/v sums -> [F|r]^T[F|r]) into H_stage + reduction of the per-block scalar partials, for the paths
@@ -1243,7 +1266,28 @@ __device__ __forceinline__ void finish_evaluation(const DevProblem &P, const Dev
 // The same step for a workgroup that only needs its OUTCOME (every workgroup of k_schur_gram but the extra one that
 // writes): of H only the gradient column and the cost entry of each camera enter the step -- 15 entries per camera, two
 // loads per thread straight from the finished sums instead of 16 KB through LDS and two barriers.  Hl: 256 C + kScal + 8.
-// THROUGH: the finished sums and the board statistics were handed over inside this launch (k_schur_gram<NV, true>)
+// ... in two parts for k_schur_gram<NV, true>: control_early in front of the wait for the riding reductions, this behind it (the same
+// loads, the same arithmetic in the same order: same bits)
+__device__ __forceinline__ void control_early(const DevProblem &P, const DevState &S, int have_backsub, ControlEarly &e)
+{
+    control_early_params(P, S, e);
+    backsub_partials(S, have_backsub, e.mb, e.ss);
+}
+__device__ __forceinline__ void control_outcome_late(const DevProblem &P, const DevState &S, int init, const ControlEarly &e, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
+{
+    const int t = threadIdx.x;
+    ControlPre pre;
+    control_state(P, init, pre, head, e);
+    const int m = min(t >> 4, P.C - 1), a = t & 15;
+    const int fa = min(a, 13), ta = f_tile(fa), tb = f_tile(kFR), mk = f_mask(fa) & f_mask(kFR);
+    const double gu = S.campart2[(size_t)512 * m + ta * 16 + tb], gv = S.campart2[(size_t)512 * m + 256 + ta * 16 + tb];
+    double *scl = Hl + 256 * P.C;
+    reduce_scalar_partials_from<false>(P, S, e.mb, e.ss, pre.c.lin_fail, scl, sm);
+    if (t < 16 * P.C && a < 14) Hl[256 * m + a * 16 + kFR] = ((mk & 1) ? gu : 0.0) + ((mk & 2) ? gv : 0.0);
+    __syncthreads();
+    control_step(P, S, init, pre, sm, Hl, scl, nullptr, /*writer=*/false, out);
+}
+// THROUGH: the finished sums and the board statistics were handed over inside this launch
 template <bool THROUGH = false>
 __device__ __forceinline__ void control_outcome(const DevProblem &P, const DevState &S, int init, int have_backsub, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
 {
@@ -1500,7 +1544,7 @@ struct RawTc {
 // XCDs' L2s start a launch invalidated, one workgroup wrote all of it THROUGH -- the first touch of a waiting workgroup's XCD
 // fetches what was written.  (st_part / campart2 are pieces of lines written from several XCDs: handoff_load, no shortcut.)
 template <int NV, bool RIDE = false>
-__global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target)
+__global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
 {
 #ifdef TSCM_WAVE_TIMELINE
     KtlScope ktl_scope(3, ctl && !RIDE ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));      // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
@@ -1513,9 +1557,10 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     const int ctl_init = (ctl >> 2) & 1;
     ctl &= 3;
     const int n_stats = RIDE ? P.C * kCamSl + S.n_st_blocks : 0;
-    const int bid = (int)blockIdx.x - n_stats;             // index among the workgroups of the Schur complement proper
+    const int bid = (int)blockIdx.x;
     const bool extra = ctl != 0 && bid == 0;               // the workgroup that writes the control step's results, and nothing else
-    const int cblk = ctl ? max(bid - 1, 0) : max(bid, 0);
+    const int jblk = ctl ? bid - 1 : bid;                  // (RIDE: reduction block jblk < n_stats in front of chunk jblk < n_chunks)
+    const int cblk = RIDE ? min(max(jblk, 0), n_chunks - 1) : max(jblk, 0);
     const int4 desc = P.bc_desc[chunk0 + cblk];
     constexpr int NT = NV * (NV + 1) / 2;
     // what phase 0a gathers per board: sums over its views of E^T E_wb (18) and of E^T r (6), then per view the raw
@@ -1527,15 +1572,69 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     double (&sumE)[kChunkBoards][NE] = lds_blk.sumE;
     double (&facl)[kChunkBoards][kFac] = lds_blk.facl;
     double (&tiles)[4][NT][256] = lds_blk.tiles;
+    const int chunk = chunk0 + cblk;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int a = lane & 15, kq = lane >> 4;
+    const int c0 = desc.x, nbd = desc.y - desc.x, slot0 = desc.z;       // boards c0 .. c0 + nbd - 1 (<= kChunkBoards), views at slots slot0 + NV * i
+    constexpr unsigned BAD = 0xffffe000u;
+    double ev[4][NJ];
+    double w[4][NV][6];
+    // the boards of a chunk share their camera set: the rotation of view p's camera is chunk-uniform
+    const double *Rcp[NV];
+    auto request = [&](int cur_) {
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(S.rec[cur_], sizeof(double) * (size_t)kRec * P.V);
+        // ---- requests: the pieces of the records of the boards this lane gathers (phase 0a), the W columns of the four
+        //      groups of four boards its wave contracts (phase 1), the Jacobi scaling of the board it factors (phase 0b)
+        {
+            const int e = tid & 15;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // entry e + 16 j of the list above: offset of its first term inside the allocation relative to the board's
+                // first view, stride between the views' terms (0: a single term)
+                const int idx = e + 16 * j;
+                const int pv = idx < 24 ? 0 : (idx - 24) / 9, r9 = idx < 24 ? 0 : (idx - 24) % 9;
+                const bool summed = idx < 24;
+                const unsigned first = idx < 18 ? 8u * ((unsigned)kRecW * (unsigned)P.V + (unsigned)idx)
+                                     : idx < 24 ? 8u * (unsigned)(6 * kFR + idx - 18)
+                                     : 8u * (unsigned)(kRecW * pv + 6 * (kWcolTc + r9 / 3) + 3 + r9 % 3);
+                const unsigned per_slot = idx < 18 ? 8u * kRecE : 8u * kRecW;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bf = 16 * i + (tid >> 4);
+                    const unsigned o0 = idx < NE ? first + per_slot * (unsigned)(slot0 + NV * min(bf, nbd - 1)) : BAD;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < NV; ++p) acc += buf_load_f64(r_w, (p == 0 || summed) ? o0 : BAD, per_slot * (unsigned)p);
+                    ev[i][j] = acc;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int bg = 16 * wave + 4 * g + kq;
+            const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + 6u * (unsigned)a) : BAD;
+#pragma unroll
+            for (int p = 0; p < NV; ++p)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {          // column a of the view's W: six adjacent doubles
+                    const d2 v = buf_load_2f64(r_w, base, 8u * (unsigned)(kRecW * p + 2 * k));
+                    w[g][p][2 * k] = v[0]; w[g][p][2 * k + 1] = v[1];
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < NV; ++p) Rcp[p] = S.cconst[cur_] + kCStride * P.slot_cam[slot0 + p];
+    };
     int ctrl_done, cur;
     double radius, dmin, dmax;
 #ifdef TSCM_WAVE_TIMELINE
-    long long t_waited = 0;
+    long long t_waited = 0, t_reduced = 0;
 #endif
-    if (RIDE && bid < 0) {
-        // a reduction workgroup of the evaluation in front of this launch (k_reduce_stats' body; the candidate's evaluation)
+    if (RIDE && !extra && jblk < n_stats) {
+        // a reduction block of the evaluation in front of this launch (k_reduce_stats' body; the candidate's evaluation) before
+        // the workgroup's own chunk
         double *sm = reinterpret_cast<double *>(&lds_blk);
-        const int blk = (int)blockIdx.x, nc = P.C * kCamSl;
+        const int blk = jblk, nc = P.C * kCamSl;
         if (blk == n_stats - 1 && threadIdx.x < sizeof(CtrlHead) / 8)
             __hip_atomic_store(&reinterpret_cast<unsigned long long *>(S.ctrl_snap)[threadIdx.x], reinterpret_cast<const unsigned long long *>(S.ctrl)[threadIdx.x],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1548,13 +1647,21 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
         if (threadIdx.x == 0 && __hip_atomic_fetch_add(S.stats_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stats_target - 1)
             __hip_atomic_store(S.stats_flag, stats_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the last one: everybody's results are complete
 #ifdef TSCM_WAVE_TIMELINE
-        if (threadIdx.x == 0 && ktl_scope.on && blk < kKtlGroups) {
-            long long *o = g_phs + (size_t)kPhStamps * blk;
-            const long long te = wall_clock64();
-            o[0] = tsk; o[1] = te; o[2] = te; o[3] = te; o[4] = te; o[5] = te; o[6] = -1; o[7] = 0;      // (boards = -1: a reduction workgroup)
-        }
+        t_reduced = wall_clock64();
 #endif
-        return;
+        __syncthreads();                                          // (the LDS goes on to the requests' consumers)
+    }
+    if (RIDE && jblk >= n_chunks) return;                         // (a grid of fewer chunks than reduction blocks)
+    // RIDE: the records are requested BEFORE the wait for the riding reductions and the control step, from the buffer an accepted
+    // step makes current (S.ctrl->cur is the state in front of the step; whoever reads it after the extra workgroup's commit, or
+    // sees the step rejected, asks again below): the 34 MB stream while the reductions run, the control step's own loads come
+    // after it.  First-round workgroups only -- a later round finds the outcome published.
+    int cur_spec = -1;
+    ControlEarly early;
+    if (RIDE && !extra && bid < first_round) {
+        cur_spec = (S.ctrl->cur ^ 1) & 1;
+        control_early(P, S, !ctl_init, early);          // (what the control step reads that the reductions do not write: ahead of the records)
+        request(cur_spec);
     }
     if (ctl) {
         constexpr int kHl = 256 * kMaxCamLds + kScal + 8, kGall = 512 * kMaxCamLds;
@@ -1619,6 +1726,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
             control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, &s_ctl);
         } else {
             if (extra) finish_evaluation<false>(P, S, ctl_init, !ctl_init, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
+            else if (RIDE && cur_spec >= 0) control_outcome_late(P, S, ctl_init, early, scratch, scratch + kHl, &s_ctl, head);
             else control_outcome<false>(P, S, ctl_init, !ctl_init, scratch, scratch + kHl, &s_ctl, head);
         }
         if (extra) {
@@ -1643,62 +1751,11 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
     }
     if (ctrl_done) return;
     PHASE_STAMP(ts0);
-    const int chunk = chunk0 + cblk;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int a = lane & 15, kq = lane >> 4;
-    const int c0 = desc.x, nbd = desc.y - desc.x, slot0 = desc.z;       // boards c0 .. c0 + nbd - 1 (<= kChunkBoards), views at slots slot0 + NV * i
-    const double *rec = S.rec[cur];
-    // ---- requests: the pieces of the records of the boards this lane gathers (phase 0a), the W columns of the four
-    //      groups of four boards its wave contracts (phase 1), the Jacobi scaling of the board it factors (phase 0b)
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(rec, sizeof(double) * (size_t)kRec * P.V);
-    constexpr unsigned BAD = 0xffffe000u;
-    double ev[4][NJ];
-    {
-        const int e = tid & 15;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            // entry e + 16 j of the list above: offset of its first term inside the allocation relative to the board's
-            // first view, stride between the views' terms (0: a single term)
-            const int idx = e + 16 * j;
-            const int pv = idx < 24 ? 0 : (idx - 24) / 9, r9 = idx < 24 ? 0 : (idx - 24) % 9;
-            const bool summed = idx < 24;
-            const unsigned first = idx < 18 ? 8u * ((unsigned)kRecW * (unsigned)P.V + (unsigned)idx)
-                                 : idx < 24 ? 8u * (unsigned)(6 * kFR + idx - 18)
-                                 : 8u * (unsigned)(kRecW * pv + 6 * (kWcolTc + r9 / 3) + 3 + r9 % 3);
-            const unsigned per_slot = idx < 18 ? 8u * kRecE : 8u * kRecW;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int bf = 16 * i + (tid >> 4);
-                const unsigned o0 = idx < NE ? first + per_slot * (unsigned)(slot0 + NV * min(bf, nbd - 1)) : BAD;
-                double acc = 0.0;
-#pragma unroll
-                for (int p = 0; p < NV; ++p) acc += buf_load_f64(r_w, (p == 0 || summed) ? o0 : BAD, per_slot * (unsigned)p);
-                ev[i][j] = acc;
-            }
-        }
-    }
-    double w[4][NV][6];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int bg = 16 * wave + 4 * g + kq;
-        const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + 6u * (unsigned)a) : BAD;
-#pragma unroll
-        for (int p = 0; p < NV; ++p)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {          // column a of the view's W: six adjacent doubles
-                const d2 v = buf_load_2f64(r_w, base, 8u * (unsigned)(kRecW * p + 2 * k));
-                w[g][p][2 * k] = v[0]; w[g][p][2 * k + 1] = v[1];
-            }
-    }
+    if (!RIDE || cur != cur_spec) request(cur);
     double sb[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) sb[i] = tid < nbd ? S.s_b[6 * (c0 + tid) + i] : 1.0;
     const bool board_is_const = tid < nbd && P.board_const[c0 + tid] != 0;
-    // the boards of a chunk share their camera set: the rotation of view p's camera is chunk-uniform
-    const double *Rcp[NV];
-#pragma unroll
-    for (int p = 0; p < NV; ++p) Rcp[p] = S.cconst[cur] + kCStride * P.slot_cam[slot0 + p];
     // ---- phase 0a: 16 lanes per board, 16 boards per pass ------------------------------------------------------------
     {
         const int e = tid & 15, grp = tid >> 4;
@@ -1773,7 +1830,7 @@ __global__ __launch_bounds__(256) void k_schur_gram(DevProblem P, DevState S, in
 #ifdef TSCM_WAVE_TIMELINE
     if (threadIdx.x == 0 && ktl_scope.on && (int)blockIdx.x < kKtlGroups) {
         long long *o = g_phs + (size_t)kPhStamps * blockIdx.x;
-        o[0] = tsk; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = wall_clock64(); o[6] = nbd; o[7] = (bid >= first_round ? 1 : 0) | ((RIDE && t_waited ? t_waited - tsk : 0) << 1);      // (bit 0: a later round; above: ticks until the riding reductions had arrived)
+        o[0] = tsk; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = wall_clock64(); o[6] = nbd; o[7] = (bid >= first_round ? 1 : 0) | ((RIDE && t_waited ? t_waited - tsk : 0) << 1) | ((RIDE && t_reduced ? t_reduced - tsk : 0) << 32);      // (bit 0: a later round; above: ticks until the riding reductions had arrived)
     }
 #endif
 #ifdef TSCM_PHASE_PROFILE

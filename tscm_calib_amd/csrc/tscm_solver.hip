@@ -123,6 +123,7 @@ struct tscm_solver {
     bool fuse_reduce = true;            // this solve: k_T_reduce rides in the reduced solve's launch (tscm_options.exec_flags & TSCM_EXEC_SEPARATE_T_REDUCE clears it)
     bool fuse_backsub = true;           // this solve: k_backsub_prep rides in it too (TSCM_EXEC_SEPARATE_BACKSUB clears it)
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
+    int schur_resident_ride[4] = { 0, 0, 0, 0 };   // ... of k_schur_gram<NV, true>
     int schur_resident[4] = { 0, 0, 0, 0 };   // workgroups of k_schur_gram<NV> that are resident at once (occupancy x CUs): the first round of its grid
     int ctl_epoch = 0;                  // control steps taken in k_schur_gram's head in this solve so far
     bool stats_ride = false;            // this solve: the reductions behind a candidate's evaluation are the first workgroups of the next k_schur_gram (k_schur_gram<NV, true>)
@@ -475,7 +476,10 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[1], reinterpret_cast<const void *>(k_schur_gram<1>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[2], reinterpret_cast<const void *>(k_schur_gram<2>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[3], reinterpret_cast<const void *>(k_schur_gram<3>), 256, 0));
-        for (int nv = 1; nv <= 3; ++nv) s->schur_resident[nv] *= prop.multiProcessorCount;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[1], reinterpret_cast<const void *>(k_schur_gram<1, true>), 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[2], reinterpret_cast<const void *>(k_schur_gram<2, true>), 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[3], reinterpret_cast<const void *>(k_schur_gram<3, true>), 256, 0));
+        for (int nv = 1; nv <= 3; ++nv) { s->schur_resident[nv] *= prop.multiProcessorCount; s->schur_resident_ride[nv] *= prop.multiProcessorCount; }
         const int per_bchunk = std::min<int>(kChunkBoards, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
         size_t i = 0;
         while (i < order_b.size()) {
@@ -1104,13 +1108,13 @@ static int enqueue_iteration(LmRun &run)
         const int ce = ctl ? ++s->ctl_epoch : 0;          // (ctl: 1 one GPU | 2 communicator, + 4: the initial evaluation's step, + 8: the reductions ride)
         if (ctl & 8) {
             const int ns = P.C * kCamSl + S.n_st_blocks, target = ns * ++s->stats_epoch;
-            if (s->nv_chunks[1]) hipLaunchKernelGGL((k_schur_gram<1, true>), dim3(ns + s->nv_chunks[1] + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl & 7, s->schur_resident[1], ce, target);
-            if (s->nv_chunks[2]) hipLaunchKernelGGL((k_schur_gram<2, true>), dim3(ns + s->nv_chunks[2] + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl & 7, s->schur_resident[2], ce, target);
-            if (s->nv_chunks[3]) hipLaunchKernelGGL((k_schur_gram<3, true>), dim3(ns + s->nv_chunks[3] + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl & 7, s->schur_resident[3], ce, target);
+            if (s->nv_chunks[1]) hipLaunchKernelGGL((k_schur_gram<1, true>), dim3(std::max(ns, s->nv_chunks[1]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl & 7, s->schur_resident_ride[1], ce, target, s->nv_chunks[1]);
+            if (s->nv_chunks[2]) hipLaunchKernelGGL((k_schur_gram<2, true>), dim3(std::max(ns, s->nv_chunks[2]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl & 7, s->schur_resident_ride[2], ce, target, s->nv_chunks[2]);
+            if (s->nv_chunks[3]) hipLaunchKernelGGL((k_schur_gram<3, true>), dim3(std::max(ns, s->nv_chunks[3]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl & 7, s->schur_resident_ride[3], ce, target, s->nv_chunks[3]);
         } else {
-            if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0);
-            if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0);
-            if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce, 0);
+            if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0, s->nv_chunks[1]);
+            if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0, s->nv_chunks[2]);
+            if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce, 0, s->nv_chunks[3]);
         }
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
         if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
@@ -1288,7 +1292,11 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
             s->eval_pending = 0;
             s->ctl_epoch = 0;
             // (one GPU, the control step from the finished sums themselves: not behind an all-reduce)
-            s->stats_ride = s->ctl_in_schur && !s->comm && s->P.C <= kMaxCamLds && !(opt.exec_flags & TSCM_EXEC_SEPARATE_STATS);
+            // -- and a grid of ONE round: every workgroup that takes a reduction block in front of its chunk is resident (they wait for
+            // each other), and at config 5 (1256 chunks, 2.5 rounds) the ride costs 2.5 us where it saves 4 at config 4
+            const int nv_used = s->nv_chunks[1] ? 1 : s->nv_chunks[2] ? 2 : 3;
+            s->stats_ride = s->ctl_in_schur && !s->comm && s->P.C <= kMaxCamLds && !(opt.exec_flags & TSCM_EXEC_SEPARATE_STATS) &&
+                            std::max(s->P.C * kCamSl + s->S.n_st_blocks, s->nv_chunks[nv_used]) + 1 <= s->schur_resident_ride[nv_used];
             s->stats_epoch = 0;
         }
         s->withhold = s->withhold_next; s->withhold_next = 0;
