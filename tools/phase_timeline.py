@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tscm_calib_amd import api, lib, synth        # noqa: E402
 
 
-def report(name, st, phases):
+def report(name, st, phases, n_cam_blocks=0):
+    st_all = st
     st = st[st[:, 0] > 0]
     if not len(st):
         print(f"{name}: no stamps")
@@ -27,6 +28,12 @@ def report(name, st, phases):
         rd = (red[:, 7] >> 32) / 100.0
         print(f"{name}: {len(red)} workgroups with a reduction block in front: block done {rd.mean():.2f} us after their start (max {rd.max():.2f}; "
               f"last {((red[:, 0] - t0r) / 100.0 + rd).max():.2f} us after the launch's first start)")
+        if n_cam_blocks:
+            allr = (st_all[:, 7] >> 32) / 100.0
+            camr, brdr = allr[1:1 + n_cam_blocks], allr[1 + n_cam_blocks:]
+            camr, brdr = camr[camr > 0], brdr[brdr > 0]
+            if len(camr) and len(brdr):
+                print(f"  camera-tile blocks: done after {camr.mean():.2f} us (max {camr.max():.2f}); board-statistics blocks: {brdr.mean():.2f} (max {brdr.max():.2f})")
         w = ((st[:, 7] & 0xffffffff) >> 1) / 100.0
         print(f"  the count was seen complete {w.mean():.2f} us after a workgroup's start (min {w.min():.2f}, max {w.max():.2f}); "
               f"that is {((st[:, 0] - t0r) / 100.0 + w).mean():.2f} us after the launch's first start (max {((st[:, 0] - t0r) / 100.0 + w).max():.2f})")
@@ -61,7 +68,7 @@ def main():
         if w <= 0:
             raise SystemExit(f"tscm_debug_phase_stamps: {w} (needs a -DTSCM_WAVE_TIMELINE build)")
         st = buf.reshape(2, G, w)
-        report("k_schur_gram", st[0], ["head/control", "records+E sums", "factor", "Gram", "tiles"])
+        report("k_schur_gram", st[0], ["head/control", "records+E sums", "factor", "Gram", "tiles"], n_cam_blocks=16 * p.n_cameras)
         report("k_backsub_prep / riders", st[1][:, [0, 1, 2, 3, 4, 5, 6, 7]][:, [1, 2, 3, 4, 5, 5, 6, 7]], ["W.yhat", "board solve", "view constants"])
 
 

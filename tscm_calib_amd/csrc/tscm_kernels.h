@@ -1638,10 +1638,10 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
         if (blk == n_stats - 1 && threadIdx.x < sizeof(CtrlHead) / 8)
             __hip_atomic_store(&reinterpret_cast<unsigned long long *>(S.ctrl_snap)[threadIdx.x], reinterpret_cast<const unsigned long long *>(S.ctrl)[threadIdx.x],
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!S.ctrl->done) {
-            if (blk < nc) cam_reduce_block(P, S, blk, sm);
-            else board_stats_block(P, S, /*cand=*/1, /*init=*/0, blk - nc, sm);
-        }
+        // (no look at ctrl->done first: a branch on a loaded value is a round trip in front of the block's own loads, and what a
+        // finished solve's reductions write nobody reads)
+        if (blk < nc) cam_reduce_block(P, S, blk, sm);
+        else board_stats_block(P, S, /*cand=*/1, /*init=*/0, blk - nc, sm);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the written-through results are complete, then the count (see "hand-offs")
         __syncthreads();
         if (threadIdx.x == 0 && __hip_atomic_fetch_add(S.stats_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stats_target - 1)
@@ -1751,7 +1751,54 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
     }
     if (ctrl_done) return;
     PHASE_STAMP(ts0);
-    if (!RIDE || cur != cur_spec) request(cur);
+    if constexpr (RIDE) {
+        if (cur != cur_spec) request(cur);
+    } else {
+        // (the same requests written out where they always were: this instantiation serves the grids of several rounds -- config 5 --
+        // and inlined from the lambda above it came out 2.8 us slower there)
+        const double *rec = S.rec[cur];
+        // ---- requests: the pieces of the records of the boards this lane gathers (phase 0a), the W columns of the four
+        //      groups of four boards its wave contracts (phase 1), the Jacobi scaling of the board it factors (phase 0b)
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(rec, sizeof(double) * (size_t)kRec * P.V);
+        {
+            const int e = tid & 15;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                // entry e + 16 j of the list above: offset of its first term inside the allocation relative to the board's
+                // first view, stride between the views' terms (0: a single term)
+                const int idx = e + 16 * j;
+                const int pv = idx < 24 ? 0 : (idx - 24) / 9, r9 = idx < 24 ? 0 : (idx - 24) % 9;
+                const bool summed = idx < 24;
+                const unsigned first = idx < 18 ? 8u * ((unsigned)kRecW * (unsigned)P.V + (unsigned)idx)
+                                     : idx < 24 ? 8u * (unsigned)(6 * kFR + idx - 18)
+                                     : 8u * (unsigned)(kRecW * pv + 6 * (kWcolTc + r9 / 3) + 3 + r9 % 3);
+                const unsigned per_slot = idx < 18 ? 8u * kRecE : 8u * kRecW;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bf = 16 * i + (tid >> 4);
+                    const unsigned o0 = idx < NE ? first + per_slot * (unsigned)(slot0 + NV * min(bf, nbd - 1)) : BAD;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < NV; ++p) acc += buf_load_f64(r_w, (p == 0 || summed) ? o0 : BAD, per_slot * (unsigned)p);
+                    ev[i][j] = acc;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int bg = 16 * wave + 4 * g + kq;
+            const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + 6u * (unsigned)a) : BAD;
+#pragma unroll
+            for (int p = 0; p < NV; ++p)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {          // column a of the view's W: six adjacent doubles
+                    const d2 v = buf_load_2f64(r_w, base, 8u * (unsigned)(kRecW * p + 2 * k));
+                    w[g][p][2 * k] = v[0]; w[g][p][2 * k + 1] = v[1];
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < NV; ++p) Rcp[p] = S.cconst[cur] + kCStride * P.slot_cam[slot0 + p];
+    }
     double sb[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) sb[i] = tid < nbd ? S.s_b[6 * (c0 + tid) + i] : 1.0;
