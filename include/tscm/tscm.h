@@ -215,15 +215,18 @@ void tscm_default_options(tscm_options *opt, int mono);
  */
 int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
 int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU, see below */
-/* A hand-off between workgroups of one launch (Schur-complement tiles -> reduced solve -> back-substitution) that does not
+/* A hand-off between workgroups of one launch (evaluation's reductions -> control step; Schur-complement tiles -> reduced
+ * solve -> back-substitution) that does not
  * come within its time bound (0.5 s: a debugger, a co-tenant, a context switch -- or a fault) stops the solve on the
  * device; the library then runs THAT solve again from its start point on the launches that hand nothing over inside a
- * launch (TSCM_EXEC_SEPARATE_T_REDUCE | _BACKSUB | _CONTROL: same mathematics, same bits) and returns its result;
+ * launch (TSCM_EXEC_SEPARATE_T_REDUCE | _BACKSUB | _CONTROL, which implies _STATS: same mathematics, same bits) and returns its result;
  * tscm_last_error() carries a note, tscm_solver_reruns() counts them.  TSCM_E_HIP only if the re-run fails too -- or
  * with a communicator of several ranks, which would have to agree on it.
  * TESTS ONLY: tscm_solver_debug_withhold_handoff(s, 1): in the next solve of `s` one producer of the hand-off never
  * reports in (the solve must come back re-run, within seconds); (s, 2): ... and the re-run is forbidden: that solve
- * must end with TSCM_E_HIP within the time bound, the caller's parameters untouched, the solver usable afterwards. */
+ * must end with TSCM_E_HIP within the time bound, the caller's parameters untouched, the solver usable afterwards;
+ * (s, 3): like 1 for the other hand-off of an iteration -- one of the reductions behind the evaluation that ride in
+ * the Schur-complement launch never counts itself in. */
 int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on);
 int tscm_solver_reruns(const tscm_solver *s);                /* solves of `s` that were run again so far (>= 0) */
 int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *summary);

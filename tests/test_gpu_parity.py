@@ -708,6 +708,27 @@ def test_late_handoff_reruns_the_solve_on_separate_launches(hip_device):
     assert a["num_iterations"] == 3 and b["num_iterations"] == c["num_iterations"] and b["final_cost"] == c["final_cost"]
 
 
+def test_late_riding_reduction_reruns_the_solve_on_separate_launches(hip_device):
+    """The other hand-off of an iteration: the reductions behind a candidate's evaluation ride in the next Schur-complement
+    launch and every other workgroup waits for them in front of the control step.  One of them never counts itself in
+    (fault injection 3): the wait ends at its time bound, the solve is stopped and run again on separate launches -- same
+    log, same bits as the undisturbed solve."""
+    import time
+    p = H.small_rig(4, 10, seed=34)
+    ref = p.copy().normalised()
+    with api.Solver(ref) as s:
+        rs = s.solve()
+    q = p.copy().normalised()
+    with api.Solver(q) as s:
+        t0 = time.time()
+        s.debug_withhold_handoff(3)
+        qs = s.solve()
+        assert 0.4 < time.time() - t0 < 10.0 and s.reruns() == 1
+        assert "run again on separate launches" in lib.lib().tscm_last_error().decode()
+    assert qs["num_iterations"] == rs["num_iterations"] and qs["iterations"] == rs["iterations"]
+    assert np.array_equal(q.intr, ref.intr) and np.array_equal(q.board_rt, ref.board_rt) and np.array_equal(q.cam_rt, ref.cam_rt)
+
+
 def test_late_handoff_without_a_rerun_is_a_hard_error(hip_device):
     """... and where the re-run is not available (forbidden here by the fault injection; in production: a communicator of several
     ranks, which would have to agree on it) the call must return TSCM_E_HIP within the time bound -- not hang, and not go on as a

@@ -63,11 +63,20 @@ def main():
     with api.Solver(p) as s:
         s.solve(max_num_iterations=10, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0, min_trust_region_radius=0.0)
         G = 2048
-        buf = np.zeros(2 * 8 * G, dtype=np.int64)
+        buf = np.zeros(3 * 8 * G, dtype=np.int64)
         w = lib.lib().tscm_debug_phase_stamps(buf.ctypes.data_as(ctypes.c_void_p), G)
         if w <= 0:
             raise SystemExit(f"tscm_debug_phase_stamps: {w} (needs a -DTSCM_WAVE_TIMELINE build)")
-        st = buf.reshape(2, G, w)
+        st = buf.reshape(3, G, w)
+        rb = st[2][st[2][:, 0] > 0]
+        if len(rb):
+            t0 = st[0][st[0][:, 0] > 0][:, 0].min()
+            for kind, name in ((1, "camera-tile blocks"), (0, "board-statistics blocks")):
+                r = rb[rb[:, 4] == kind]
+                if len(r):
+                    a = (r[:, :4] - t0) / 100.0
+                    print(f"{name} ({len(r)}), us after the launch's first start: start {a[:, 0].mean():.2f}, results computed and stores issued {a[:, 1].mean():.2f} (max {a[:, 1].max():.2f}), "
+                          f"stores acknowledged {a[:, 2].mean():.2f} (max {a[:, 2].max():.2f}), counted in {a[:, 3].mean():.2f} (max {a[:, 3].max():.2f})")
         report("k_schur_gram", st[0], ["head/control", "records+E sums", "factor", "Gram", "tiles"], n_cam_blocks=16 * p.n_cameras)
         report("k_backsub_prep / riders", st[1][:, [0, 1, 2, 3, 4, 5, 6, 7]][:, [1, 2, 3, 4, 5, 5, 6, 7]], ["W.yhat", "board solve", "view constants"])
 

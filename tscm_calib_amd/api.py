@@ -55,7 +55,8 @@ class Solver:
 
     def debug_withhold_handoff(self, on=True):
         """Tests only: one producer of the device-side hand-off of the NEXT solve never reports in (tscm_solver_debug_withhold_handoff);
-        on = 2: ... and the library must not run that solve again on separate launches."""
+        on = 2: ... and the library must not run that solve again on separate launches; on = 3: like 1 for a reduction that rides in
+        the Schur-complement launch."""
         _l.check(_l.lib().tscm_solver_debug_withhold_handoff(self._h, int(on)))
 
     def reruns(self) -> int:

@@ -628,7 +628,7 @@ struct KtlScope {
 #define KTL(id) KtlScope ktl_scope(id, S.ctrl)
 // per workgroup of k_schur_gram / k_backsub_prep (iteration 5): stamps of its phases (tscm_debug_phase_stamps, tools/phase_timeline.py)
 constexpr int kPhStamps = 8;
-__device__ long long g_phs[2 * kPhStamps * kKtlGroups];
+__device__ long long g_phs[3 * kPhStamps * kKtlGroups];       // [0] k_schur_gram, [1] back-substitution, [2] k_schur_gram<NV, true>'s reduction blocks
 __device__ long long g_ktlx[32];         // stamps inside the workgroup that runs the control step (thread 0): kept in LDS
 __shared__ long long s_ktlx[32];         // and written out at the end (a global store in front of a barrier is waited for)
 #define KTLX(i, on) do { if ((on) && threadIdx.x == 0) s_ktlx[i] = wall_clock64(); } while (0)
@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
     // other address follows from them arithmetically -- the second round trip already brings the data
     // (ctl & 4: the evaluation whose step is taken here is the solve's INITIAL one -- IterationZero: no back-substitution behind it,
     // the Jacobi scaling of the camera columns written by the extra workgroup)
-    const int ctl_init = (ctl >> 2) & 1;
+    const int ctl_init = (ctl >> 2) & 1, withhold = (ctl >> 4) & 1;      // (withhold: fault injection, tscm_solver_debug_withhold_handoff(s, 3))
     ctl &= 3;
     const int n_stats = RIDE ? P.C * kCamSl + S.n_st_blocks : 0;
     const int bid = (int)blockIdx.x;
@@ -1642,12 +1642,18 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
         // finished solve's reductions write nobody reads)
         if (blk < nc) cam_reduce_block(P, S, blk, sm);
         else board_stats_block(P, S, /*cand=*/1, /*init=*/0, blk - nc, sm);
+        PHASE_STAMP(tr1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the written-through results are complete, then the count (see "hand-offs")
         __syncthreads();
-        if (threadIdx.x == 0 && __hip_atomic_fetch_add(S.stats_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stats_target - 1)
+        PHASE_STAMP(tr2);
+        if (threadIdx.x == 0 && !(withhold && blk == 1) && __hip_atomic_fetch_add(S.stats_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stats_target - 1)
             __hip_atomic_store(S.stats_flag, stats_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the last one: everybody's results are complete
 #ifdef TSCM_WAVE_TIMELINE
         t_reduced = wall_clock64();
+        if (threadIdx.x == 0 && ktl_scope.on && blk < kKtlGroups) {
+            long long *o = g_phs + (size_t)kPhStamps * (2 * kKtlGroups + blk);
+            o[0] = tsk; o[1] = tr1; o[2] = tr2; o[3] = t_reduced; o[4] = blk < nc;
+        }
 #endif
         __syncthreads();                                          // (the LDS goes on to the requests' consumers)
     }

@@ -812,7 +812,7 @@ static tscm_comm *effective_comm(const tscm_solver *s, int exec_flags)
 extern "C" int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on)
 {
     if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
-    s->withhold_next = on ? 1 : 0;
+    s->withhold_next = on == 3 ? 2 : on ? 1 : 0;      // (3: a reduction block riding in the Schur-complement launch, not a producer of the tiles)
     s->no_rerun_next = on == 2;          // 2: ... and the solve is NOT run again on separate launches (the error path itself)
     return 0;
 }
@@ -1108,9 +1108,9 @@ static int enqueue_iteration(LmRun &run)
         const int ce = ctl ? ++s->ctl_epoch : 0;          // (ctl: 1 one GPU | 2 communicator, + 4: the initial evaluation's step, + 8: the reductions ride)
         if (ctl & 8) {
             const int ns = P.C * kCamSl + S.n_st_blocks, target = ns * ++s->stats_epoch;
-            if (s->nv_chunks[1]) hipLaunchKernelGGL((k_schur_gram<1, true>), dim3(std::max(ns, s->nv_chunks[1]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl & 7, s->schur_resident_ride[1], ce, target, s->nv_chunks[1]);
-            if (s->nv_chunks[2]) hipLaunchKernelGGL((k_schur_gram<2, true>), dim3(std::max(ns, s->nv_chunks[2]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl & 7, s->schur_resident_ride[2], ce, target, s->nv_chunks[2]);
-            if (s->nv_chunks[3]) hipLaunchKernelGGL((k_schur_gram<3, true>), dim3(std::max(ns, s->nv_chunks[3]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl & 7, s->schur_resident_ride[3], ce, target, s->nv_chunks[3]);
+            if (s->nv_chunks[1]) hipLaunchKernelGGL((k_schur_gram<1, true>), dim3(std::max(ns, s->nv_chunks[1]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], (ctl & 7) | (s->withhold == 2 ? 16 : 0), s->schur_resident_ride[1], ce, target, s->nv_chunks[1]);
+            if (s->nv_chunks[2]) hipLaunchKernelGGL((k_schur_gram<2, true>), dim3(std::max(ns, s->nv_chunks[2]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], (ctl & 7) | (s->withhold == 2 ? 16 : 0), s->schur_resident_ride[2], ce, target, s->nv_chunks[2]);
+            if (s->nv_chunks[3]) hipLaunchKernelGGL((k_schur_gram<3, true>), dim3(std::max(ns, s->nv_chunks[3]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], (ctl & 7) | (s->withhold == 2 ? 16 : 0), s->schur_resident_ride[3], ce, target, s->nv_chunks[3]);
         } else {
             if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0, s->nv_chunks[1]);
             if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0, s->nv_chunks[2]);
@@ -1130,7 +1130,7 @@ static int enqueue_iteration(LmRun &run)
             const int n_bs = s->fuse_backsub && s->bs_threads == 256 && S.n_bs_blocks <= s->dense4_resident - 1 - n_prod ? S.n_bs_blocks : 0;       // all of them, or none: see below
             if (n_prod || n_bs)
                 hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
-                                   P, S, ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                                   P, S, ++s->t_epoch, s->withhold == 1 ? 1 : 0, n_prod, n_bs, wf);
             else hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_dense4, s->stream, P, S, 0, 0, 0, 0, 0);
             if (!n_bs && S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf);
             if (!n_bs && S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf);
@@ -1151,9 +1151,9 @@ static int enqueue_iteration(LmRun &run)
                 const size_t lds = std::max(s->lds_nd[v], n_bs ? s->lds_bs : (size_t)0);
                 const dim3 grid(1 + n_prod + n_bs);
                 if (two) {
-                    hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                    hipLaunchKernelGGL((k_solve_nd<2, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold == 1 ? 1 : 0, n_prod, n_bs, wf);
                 } else {
-                    hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold, n_prod, n_bs, wf);
+                    hipLaunchKernelGGL((k_solve_nd<1, true>), grid, dim3(kNdThreads), lds, s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), ++s->t_epoch, s->withhold == 1 ? 1 : 0, n_prod, n_bs, wf);
                 }
             } else {
                 if (two) hipLaunchKernelGGL((k_solve_nd<2, false>), dim3(1), dim3(kNdThreads), s->lds_nd[v], s->stream, P, S, s->d_nd_map[v], s->d_nd_tab[v], s->d_nd_bs[v], s->plan[v].dims(), 0, 0, 0, 0, 0);
@@ -1920,7 +1920,7 @@ extern "C" int tscm_debug_phase_stamps(long long *out, int max_groups)
 {
     if (max_groups < tscm::kKtlGroups) return TSCM_E_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return TSCM_E_HIP;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_phs), sizeof(long long) * 2 * tscm::kPhStamps * tscm::kKtlGroups) != hipSuccess) return TSCM_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tscm::g_phs), sizeof(long long) * 3 * tscm::kPhStamps * tscm::kKtlGroups) != hipSuccess) return TSCM_E_HIP;
     return tscm::kPhStamps;
 }
 extern "C" int tscm_debug_wave_views(long long *out, int max_waves)
