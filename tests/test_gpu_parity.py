@@ -598,11 +598,13 @@ def test_control_step_in_the_schur_kernels_head_and_in_the_reductions_launch_agr
 
 @pytest.mark.parametrize("cfg", [1, 3, 4, 5])
 def test_reductions_riding_in_the_schur_launch_and_in_a_launch_of_their_own_agree_bit_for_bit(hip_device, cfg):
-    """One GPU: the reductions behind a candidate's evaluation (camera-tile sums, board statistics, the snapshot of the LM
-    state) are the first workgroups of the next Schur-complement launch (k_schur_gram<NV, true>: written through, counted
-    in, waited for in front of the control step); tscm_options.exec_flags = TSCM_EXEC_SEPARATE_STATS keeps them
-    k_reduce_stats, a launch of their own.  Same decisions, same log, same bits -- natural solves and forced iterations
-    with rejected steps, grids of one round (configs 1, 3, 4) and of several (config 5)."""
+    """One GPU, a Schur-complement grid of one round: the reductions behind a candidate's evaluation (camera-tile sums, board
+    statistics, the snapshot of the LM state) are taken by the first workgroups of the next Schur-complement launch in front
+    of their own chunks (k_schur_gram<NV, true>: written through, counted in, waited for in front of the control step, the
+    records requested meanwhile from the buffer an accepted step makes current -- a rejected step asks again);
+    tscm_options.exec_flags = TSCM_EXEC_SEPARATE_STATS keeps them k_reduce_stats, a launch of their own.  Same decisions,
+    same log, same bits -- natural solves and forced iterations with rejected steps; configs 1, 3, 4 ride, config 5 (a grid
+    of 2.5 rounds) takes the separate launch either way."""
     forced = dict(max_num_iterations=12 if cfg >= 4 else 30, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0,
                   min_trust_region_radius=0.0)
     for opts in (dict(), forced):
@@ -646,8 +648,8 @@ def test_fusions_of_an_eight_camera_rig_give_the_same_bits(hip_device):
     p = synth.make_problem(8, 600, 81)
     for opts in (dict(), forced):
         ref = None
-        for flags in (0, lib.EXEC_SEPARATE_T_REDUCE, lib.EXEC_SEPARATE_BACKSUB, lib.EXEC_SEPARATE_CONTROL,
-                      lib.EXEC_SEPARATE_T_REDUCE | lib.EXEC_SEPARATE_BACKSUB | lib.EXEC_SEPARATE_CONTROL):
+        for flags in (0, lib.EXEC_SEPARATE_T_REDUCE, lib.EXEC_SEPARATE_BACKSUB, lib.EXEC_SEPARATE_CONTROL, lib.EXEC_SEPARATE_STATS,
+                      lib.EXEC_SEPARATE_T_REDUCE | lib.EXEC_SEPARATE_BACKSUB | lib.EXEC_SEPARATE_CONTROL | lib.EXEC_SEPARATE_STATS):
             q = p.copy().normalised()
             with api.Solver(q) as s:
                 r = s.solve(exec_flags=flags, **opts)
