@@ -33,7 +33,8 @@ extern "C" {
                              /*    was the moment): the library reads only as many bytes as the caller's struct  */
                              /*    has and refuses a size it does not know -- an options struct of ABI <= 5 is   */
                              /*    refused instead of misread; TSCM_E_PEER; a late device-side hand-off re-runs  */
-                             /*    the solve on separate launches before it is an error                           */
+                             /*    the solve on separate launches before it is an error; TSCM_EXEC_SEPARATE_STATS */
+                             /*    (no struct changed; a library without the bit refuses it)                     */
 
 enum {
     TSCM_OK = 0,
