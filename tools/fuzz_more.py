@@ -1,7 +1,8 @@
 """Extended GPU <-> oracle fuzz: the bodies of tests/test_gpu_fuzz.py over seed ranges beyond the ones the suite runs.
 A case that misses the suite's tolerances is looked at a second time: the oracle is run on the same rig with its
-intrinsics moved by one or two ulps, and the case counts as a failure only if the GPU path is further from the oracle
-than the oracle is from itself (x10) -- the random rigs include cameras whose intrinsics three iterations from a bad
+intrinsics moved by one or two ulps, and the case counts as a failure only if in some quantity the suite compares (costs,
+gradient norms, step norms, radii, final parameters) the GPU path is further from the oracle than the oracle is from
+itself (x10), or if it takes different accept / reject decisions -- the random rigs include cameras whose intrinsics three iterations from a bad
 start barely determine, and there a cost agrees to 1e-9 with nothing, the oracle's own rerun included.
 Run on a GPU box: python tools/fuzz_more.py [first_seed] [n_small] [n_large]; exits non-zero on any failure."""
 import sys
@@ -17,27 +18,36 @@ n_small = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 n_large = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 
 
-def rel_cost_gaps(a, b):
-    return [abs(x["cost"] - y["cost"]) / abs(y["cost"]) for x, y in zip(a["iterations"], b["iterations"])]
+def gaps(a, b, pa, pb):
+    """worst relative gap of every quantity the suite compares: per-iteration cost, gradient max-norm, step norm, radius; final parameters"""
+    g = {"cost": 0.0, "gradient_max_norm": 0.0, "step_norm": 0.0, "trust_region_radius": 0.0}
+    for x, y in zip(a["iterations"], b["iterations"]):
+        for k in g:
+            g[k] = max(g[k], abs(x[k] - y[k]) / max(abs(y[k]), 1e-12))
+    g.update({"param " + k: v for k, v in F.H.param_rel_err(pa, pb).items()})
+    return g
 
 
 def second_look(build, seed):
-    """(GPU-to-oracle gap, oracle-to-perturbed-oracle gap) of the per-iteration costs, worst iteration each"""
+    """per quantity: (GPU-to-oracle gap, oracle-to-perturbed-oracle gap), worst iteration each"""
     q = build(seed)
-    base = orc.solve(q.copy().normalised(), max_num_iterations=3)
-    with api.Solver(q.copy().normalised()) as s:
+    po = q.copy().normalised()
+    base = orc.solve(po, max_num_iterations=3)
+    pg = q.copy().normalised()
+    with api.Solver(pg) as s:
         gs = s.solve(max_num_iterations=3)
-    if gs["num_iterations"] != base["num_iterations"]:
-        return float("inf"), 0.0
-    gap = max(rel_cost_gaps(gs, base))
+    if gs["num_iterations"] != base["num_iterations"] or [i["step_is_successful"] for i in gs["iterations"]] != [i["step_is_successful"] for i in base["iterations"]]:
+        return None
+    gap = gaps(gs, base, pg, po)
     rng = np.random.default_rng(seed)
-    own = 0.0
+    own = {k: 0.0 for k in gap}
     for _ in range(4):
         p = q.copy().normalised()
         p.intr *= 1.0 + 2.2e-16 * rng.integers(-2, 3, size=p.intr.shape)
         o = orc.solve(p, max_num_iterations=3)
         if o["num_iterations"] == base["num_iterations"]:
-            own = max(own, max(rel_cost_gaps(o, base)))
+            for k, v in gaps(o, base, p, po).items():
+                own[k] = max(own[k], v)
     return gap, own
 
 
@@ -48,13 +58,16 @@ for name, fn, build, n in (("small", F.test_random_rig_three_iterations, F.rando
         try:
             fn(None, seed)
         except AssertionError:
-            gap, own = second_look(build, seed)
-            if gap <= 10.0 * own:
+            look = second_look(build, seed)
+            worst = None if look is None else max(look[0], key=lambda k: look[0][k] / max(10.0 * look[1][k], 1e-12))
+            if look is not None and look[0][worst] <= max(10.0 * look[1][worst], 1e-12):
                 conditioned += 1
-                print("cond", name, seed, "GPU-oracle cost gap %.2e, oracle against itself two ulps away %.2e" % (gap, own), flush=True)
+                k = max(look[0], key=lambda k: look[0][k])
+                print("cond", name, seed, "largest gap: %s, GPU-oracle %.2e, oracle against itself two ulps away %.2e" % (k, look[0][k], look[1][k]), flush=True)
             else:
                 fails += 1
-                print("FAIL", name, seed, "GPU-oracle cost gap %.2e, oracle against itself two ulps away %.2e" % (gap, own), flush=True)
+                print("FAIL", name, seed, "different decisions" if look is None else
+                      "%s: GPU-oracle gap %.2e, oracle against itself two ulps away %.2e" % (worst, look[0][worst], look[1][worst]), flush=True)
                 traceback.print_exc(limit=3)
         except Exception as e:          # noqa: BLE001
             fails += 1
