@@ -332,6 +332,8 @@ __device__ __forceinline__ void view_point_constants(const double Rc[9], const d
 //   cam_rt[cur^1], intr[cur^1]        reduced_solution_tail (solver)      -> backsub_body<.., true> (phase B)    flag: y_flag
 //   ctrl->done / fault / term_type    solver or a waiting workgroup (late hand-off) -> waiting workgroups        (atomics both sides)
 //   campart2[C][512], st_part[..][3]  cam_reduce_block / board_stats_block -> k_reduce_control's last workgroup  flag: ctrl->fin_count
+//   campart2, st_part, ctrl_snap      the reduction blocks riding in k_schur_gram<NV, true> -> every workgroup's control step   flag: stats_flag
+//                                     (read with PLAIN loads behind the flag: single-writer lines, see k_schur_gram)
 // (the solver workgroup ALSO reads cam_rt / intr of the candidate with plain loads in write_camera_record: its own
 // written-through stores, program order within one workgroup, never cached in its L1 before).
 // A hand-off that has not come after this long is a device fault, not a numerical event: the solver workgroup sets the
@@ -1532,17 +1534,28 @@ struct RawTc {
 // launch starts -- take the step themselves; the workgroups of LATER rounds of the grid (config 5 on one GPU: 1256 chunks,
 // 2.5 rounds) start when a first-round workgroup has finished, long after workgroup 0, and read the published outcome:
 // the step is paid once per launch, not once per round.
-// RIDE (round 5, one GPU, a candidate's evaluation): the reductions behind the evaluation -- k_reduce_stats' workgroups -- are the
-// FIRST n_stats workgroups of this grid instead of a launch of their own (5.2 us + a kernel boundary at config 4; 7.5 at config
-// 5): they are dispatched first, write their results through (handoff_store, as they always did), the last one of them takes the
-// snapshot of the LM state, and each counts itself in (S.stats_count, monotonic over the solve: stats_target = n_stats x the number of such launches
-// so far; the last arrival copies the count into S.stats_flag, a line of its own: 370 polling workgroups on the counter's line
-// held the arrivals up by 4.5 us).  Every other workgroup waits for that count in front of the control step -- the reduction
-// workgroups hold the lowest block indices, so they are resident or finished whatever else is -- and reads the finished sums and
-// the board statistics with handoff_load.  The snapshot is read through the scalar cache as before: nobody touches its lines in
-// this launch before the count is complete (the instrumented build's scope reads S.ctrl instead), the scalar caches and the
-// XCDs' L2s start a launch invalidated, one workgroup wrote all of it THROUGH -- the first touch of a waiting workgroup's XCD
-// fetches what was written.  (st_part / campart2 are pieces of lines written from several XCDs: handoff_load, no shortcut.)
+// RIDE (round 5; one GPU, a candidate's evaluation, a grid of ONE round): the reductions behind the evaluation -- k_reduce_stats' blocks,
+// 5.2 us + a kernel boundary at config 4 in front of a kernel whose head waits for exactly their results -- ride in this launch.
+// Workgroup j + 1 (j < n_stats = 16 C + ceil(B / 256)) takes reduction block j IN FRONT of its own chunk j (a grid of fewer chunks
+// than blocks has workgroups that do nothing else); nothing is added to the grid, so everything is resident at once -- as extra
+// workgroups the blocks pushed 132 chunks of config 4 into a second round, +5 us -- and the wait below cannot deadlock (the host
+// checks max(blocks, chunks) + 1 <= resident workgroups and launches k_reduce_stats otherwise; a block that does not arrive within
+// the hand-offs' time bound is a device fault and the solve is run again on separate launches: fault injection 3).  A block
+// writes its results through (handoff_store, as it always did), the last block also the snapshot of the LM state, and counts
+// itself in: S.stats_count, monotonic over the solve (stats_target = n_stats x the riding launches so far); the last arrival
+// copies the count into S.stats_flag, a line of its own, which is what everybody polls -- 370 workgroups polling the COUNTER's line
+// held the 143 read-modify-writes on it up by 4.5 us (and a workgroup keeps its slot until its atomic has returned).
+// In front of the wait every workgroup requests what the control step reads that the blocks do not write (control_early) and
+// then its chunk's RECORDS, from the buffer an accepted step makes current (S.ctrl->cur ^ 1: the state in front of the step;
+// whoever reads it after the extra workgroup's commit, or finds the step rejected, asks again behind the step): the 34 MB stream
+// while the blocks run.
+// Behind the flag the step reads the snapshot (through the scalar cache, as always), two finished sums per thread and the
+// statistics partials with PLAIN loads, not handoff_load (500 workgroups x 50 lines read through would queue at the memory side):
+// every one of those lines is written by ONE workgroup in this launch (campart2: 256 bytes per block; st_part: a 128-byte line per
+// block, kStStride; the snapshot) and by nobody else, nobody reads them in this launch before the flag (the instrumented build's
+// scope reads S.ctrl instead of the snapshot for that reason), and the XCDs' L2s and the CUs' vector and scalar caches start a
+// launch invalidated (what k_reduce_stats wrote has always reached the next launch's plain loads that way) -- so the first touch
+// of a line from an XCD fetches what was written through, or hits the writer's own written-through copy.
 template <int NV, bool RIDE = false>
 __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
 {
