@@ -62,7 +62,7 @@ PREHEAT_MS = float(os.environ.get("TSCM_BENCH_PREHEAT_MS", "60"))
 FLOP_MFMA_PER_CORNER = 836           # Gram contraction 2P(P+1)+4P with P=19
 FLOP_VALU_PER_CORNER = 600           # hand-structured residual + analytic Jacobian
 FLOP_PER_CORNER = FLOP_MFMA_PER_CORNER + FLOP_VALU_PER_CORNER
-BYTES_PER_CORNER = 16.0 + 168.0 / 54.0
+BYTES_PER_CORNER = 16.0 + 168.0 / 54.0   # 9x6 board; main() recomputes it for --board (168 B of pose / intrinsic reads per VIEW)
 FP64_PEAK_TFLOPS = 78.6              # MI355X FP64 vector = matrix peak (AMD datasheet; not in MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3             # MI355X FP32 vector (packed) = FP32 matrix peak, same datasheet
 HBM_PEAK_GBS = 8000.0
@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json config index (4 = headline)")
     ap.add_argument("--poses-fixed", action="store_true",
                     help="hold every board / view pose block constant (the intrinsics-only form of config 2)")
+    ap.add_argument("--board", default="9x6", metavar="CxR",
+                    help="inner corners of the chessboard (default 9x6: BASELINE's workload and the headline; 11x8 is the reference's own "
+                         "board, main.cpp:190-191).  The board keeps its 360 mm extent, the views / frames of --config are unchanged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exec-flags", type=int, default=0,
                     help="tscm_options.exec_flags for every solve (A/B runs: 4 = TSCM_EXEC_GRAM_16X16, 1 = separate T reduction)")
@@ -323,7 +326,9 @@ def main():
         device, exchange, n_dev = local_rank, "stub", world
     else:
         from tscm_calib_amd import api, lib
-        full = synth.make_config(args.config, poses_fixed=args.poses_fixed)
+        cols, rows = (int(x) for x in args.board.lower().split("x"))
+        board_kw = {} if (cols, rows) == (9, 6) else dict(cols=cols, rows=rows, pitch=360.0 / (max(cols, rows) - 1))
+        full = synth.make_config(args.config, poses_fixed=args.poses_fixed, **board_kw)
         Solver = api.Solver
         n_dev = lib.lib().tscm_device_count()
         exchange = os.environ.get("TSCM_BENCH_EXCHANGE", "rccl" if n_dev >= world else "").lower()
@@ -413,18 +418,24 @@ def main():
     if rank == 0:
         avg_ms = kms / max(launches, 1)
         flops = n_local * FLOP_PER_CORNER
+        bytes_per_corner = 16.0 + 168.0 / full.n_points
+        # k_eval_gram4<KS, MULTI>: ceil(n / 56) passes per view of KS k-steps each (tscm_eval_gram4.h: g4_plan)
+        g4_passes = -(-full.n_points // 56)
+        g4_ks = -(-(-(-full.n_points // g4_passes)) // 4)
+        g4_name = f"k_eval_gram4<{g4_ks},{'true' if g4_passes > 1 else 'false'}>"
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS
         roof = {
-            "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else ("k_eval_gram<58>" if (args.exec_flags & 4) else "k_eval_gram4"), "bound": "mfma",
+            "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else ("k_eval_gram (16x16x4 MFMA)" if (args.exec_flags & 4) else g4_name), "bound": "mfma",
             "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
             "traffic": None, "launches": launches, "timed_launches": launches, "launches_timed_every": stride, "avg_launch_ms": avg_ms,
             # share of the step the dominant kernel accounts for; the iteration-0 evaluation of every solve is in the
             # timed region (and among the timed launches) but is not a step
             "share_of_step": (avg_ms * (args.steps + math.ceil(args.steps / ITERS_PER_SOLVE)) / (1e3 * elapsed)) if elapsed > 0 else 0.0,
             "iteration0_evals_in_timed_region": math.ceil(args.steps / ITERS_PER_SOLVE),
-            "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * BYTES_PER_CORNER,
-            "hbm_frac_if_bandwidth_bound": (n_local * BYTES_PER_CORNER / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+            "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * bytes_per_corner,
+            "ps_per_corner": 1e9 * avg_ms / max(n_local, 1),
+            "hbm_frac_if_bandwidth_bound": (n_local * bytes_per_corner / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
             # the whole STEP against the same peak: the algorithmic flop of one LM iteration of the whole job (one fused
             # evaluation of every corner; the Schur / solve / back-substitution launches add < 1 % and are not counted)
             # over the wall time of a step on all N GPUs -- LM iterations/s follows this figure, not the kernel's `frac`
@@ -449,7 +460,7 @@ def main():
                         peak_measured_valu_f64=pv, measured_floor_ms=floor_ms,
                         frac_of_measured_ceiling=floor_ms / avg_ms if avg_ms > 0 else 0.0)
             pmc = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
-            if os.path.exists(pmc) and world == 1:
+            if os.path.exists(pmc) and world == 1 and args.board.lower() == "9x6":
                 try:
                     rec = json.load(open(pmc)).get(f"config{args.config}", {})
                     # the PMC passes are separate runs: their figure only describes THIS kernel if the sources are unchanged
@@ -467,8 +478,8 @@ def main():
                 except Exception:
                     pass
         out = {
-            "metric": "LM iterations/sec at 4 cams x 10k views (joint intrinsics+extrinsics, fp64)" if args.config == 4 and not stub
-                      else f"LM iterations/sec, BASELINE config {args.config} (not the headline workload)",
+            "metric": "LM iterations/sec at 4 cams x 10k views (joint intrinsics+extrinsics, fp64)" if args.config == 4 and not stub and args.board.lower() == "9x6"
+                      else f"LM iterations/sec, BASELINE config {args.config}, {args.board} board (not the headline workload)",
             "value": args.steps / elapsed,
             "unit": "LM iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -481,7 +492,7 @@ def main():
             "rccl_ranks": rccl_ranks, "exchange_ranks": exchange_ranks,
             "config": {"workload": f"BASELINE config {args.config}: {full.n_cameras} cams x "
                                    f"{full.meta.get('views_per_cam')} views/cam, {full.n_boards} frames, "
-                                   f"{full.n_corners} corners (9x6 board, sigma=0.1 px, seed {full.meta.get('seed')})"
+                                   f"{full.n_corners} corners ({args.board.lower()} board, sigma=0.1 px, seed {full.meta.get('seed')})"
                                    + (", all board poses constant" if args.poses_fixed else ""),
                        "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)" if exchange != "ipc" or n_dev >= world
                                       else f"frames sharded over {world} rank processes on {n_dev} GPU(s) (IPC exchange: a run of the multi-process path, not a scaling measurement)"},

@@ -558,6 +558,45 @@ def test_gram_on_4x4_blocks_and_on_the_16x16_tile_agree_bit_for_bit(hip_device, 
     assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
+@pytest.mark.parametrize("cols,rows", [(11, 8), (8, 6), (6, 5), (7, 6), (9, 7), (12, 9), (14, 10), (17, 12), (5, 4), (3, 3), (2, 2), (19, 3), (8, 7)])
+def test_gram4_serves_every_board_size_with_the_bits_of_the_16x16_tile(hip_device, cols, rows):
+    """Round 6: k_eval_gram4<KS, MULTI> is the default for EVERY board (rounds 3-5: 49..56 corners only) -- ceil(n / 4)
+    k-steps for boards of up to 56 corners, ceil(n / 56) balanced passes of a multiple of four corners above that (the
+    reference's 11 x 8: main.cpp:190-191 -> 2 x 44).  The k-steps of a view contract the same groups of four rows in the
+    same order as k_eval_gram<0>'s 64-row passes (TSCM_EXEC_GRAM_16X16), so the whole solve must agree bit for bit --
+    full views and ragged ones (prefixes of the corner list, an empty view), and both against the oracle."""
+    n = cols * rows
+    p = synth.make_problem(4, 10, 700 + n, cols=cols, rows=rows, pitch=360.0 / max(cols, rows))
+    rng = np.random.default_rng(n)
+    q = p.copy()
+    q.view_count[::3] = rng.integers(max(1, n // 3), n + 1, size=q.view_count[::3].shape[0])
+    if n >= 12:
+        q.view_count[7] = 0
+    for prob in (p, q):
+        a, b, o = prob.copy().normalised(), prob.copy().normalised(), prob.copy().normalised()
+        with api.Solver(a) as s:
+            sa = s.solve(max_num_iterations=5)
+        with api.Solver(b) as s:
+            sb = s.solve(max_num_iterations=5, exec_flags=lib.EXEC_GRAM_16X16)
+        so = orc.solve(o, max_num_iterations=5)
+        assert sa["num_iterations"] == sb["num_iterations"] == so["num_iterations"]
+        assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
+        assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+        for x, y in zip(sa["iterations"], so["iterations"]):
+            assert x["step_is_successful"] == y["step_is_successful"]
+            assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
+        assert max(H.param_rel_err(a, o).values()) < 1e-6
+
+
+def test_gram4_two_passes_on_the_reference_board_at_size(hip_device):
+    """The reference's own board (11 x 8 = 88 corners, main.cpp:190-191) at config-3 size (4 cameras x 500 views,
+    176,000 corners): natural solve against the oracle, trace and every parameter block."""
+    p = synth.make_config(3, cols=11, rows=8, pitch=36.0)
+    pg, po, gs, os_ = _solve_both(p)
+    _cmp_trace(gs, os_)
+    assert max(H.param_rel_err(pg, po).values()) < 1e-6
+
+
 @pytest.mark.parametrize("cfg", [1, 3])
 def test_backsub_inside_the_solve_launch_and_as_a_launch_of_its_own_agree_bit_for_bit(hip_device, cfg):
     """One GPU, <= 4 cameras: the back-substitution workgroups ride in the reduced solve's launch, load their operands

@@ -27,14 +27,33 @@
 //     share a bank pair, the xor puts them on complementary halves);
 //   * a corner's lane writes row (t, k) = (lane / 4, lane % 4) of a column: 16 lanes x 8 bytes on 32 distinct banks
 //     (k-step stride 68 doubles = 8 dwords mod 32).
-// Boards of up to 56 corners (one pass, 14 k-steps); larger boards and the fp32 tier stay with k_eval_gram / _f32.
+//
+// Every board size (round 6; rounds 3-5: boards of 49..56 corners only, everything else ran k_eval_gram<0>).  A pass holds
+// 4 KS <= 56 rows, KS a template parameter, so a board of n <= 56 corners issues exactly ceil(n / 4) k-steps (6 x 5: 8, not
+// 14 zero-padded ones); larger boards -- the reference's own 11 x 8 (main.cpp:190-191) -- take ceil(n / 56) BALANCED passes
+// per view (88 = 2 x 44 -> KS = 11), the accumulators carried across the passes, one epilogue per view (MULTI).  The
+// corners of a pass are a multiple of four, so the k-steps of a view contract the same groups of four rows in the same
+// order as k_eval_gram<0>'s 64-row passes do: same bits.
 #pragma once
 // (included from tscm_kernels.h inside namespace tscm)
 
 constexpr int kG4Stride = 68;                   // doubles per k-step of the tile
-constexpr int kG4KS = 14;                       // k-steps: 56 rows
-constexpr int kG4Tile = kG4KS * kG4Stride;      // 952 doubles per wave (also covers the 512-double camera-tile exchange)
-__host__ __device__ inline int eval_gram4_lds_doubles(int n_points) { return kG4Tile + 2 * n_points; }
+constexpr int kG4MaxKS = 14;                    // k-steps of a pass: at most 56 rows
+// doubles of LDS per wave: the tile (>= the 512-double camera-tile exchange), then the board points
+__host__ __device__ constexpr int g4_tile_doubles(int ks) { return ks * kG4Stride > 512 ? ks * kG4Stride : 512; }
+__host__ __device__ inline int eval_gram4_lds_doubles(int n_points, int ks) { return g4_tile_doubles(ks) + 2 * n_points; }
+// pass plan of a board of n corners: ceil(n / 56) passes of `per` corners each (a multiple of four; the last pass takes what is left)
+struct G4Plan { int passes, per, ks; };
+__host__ __device__ inline G4Plan g4_plan(int n_points)
+{
+    G4Plan g;
+    g.passes = (n_points + 4 * kG4MaxKS - 1) / (4 * kG4MaxKS);
+    if (g.passes < 1) g.passes = 1;
+    g.ks = ((n_points + g.passes - 1) / g.passes + 3) / 4;
+    if (g.ks < 1) g.ks = 1;
+    g.per = 4 * g.ks;
+    return g;
+}
 
 // tile columns of this kernel
 constexpr int kG4Wb = 0, kG4R = 3, kG4Tc = 4, kG4Al = 7, kG4Wc = 8, kG4F = 11, kG4One = 12, kG4Xi = 13, kG4Lam = 14;
@@ -54,7 +73,7 @@ __device__ __forceinline__ constexpr int g4_cgroup(int b, int q) { return q == 0
 __device__ __forceinline__ int g4_elem(int c, int k) { return 4 * c + (k ^ ((c >> 3) << 1)); }     // within a k-step
 
 // one k-step: three operand vectors, three instructions; operands requested D k-steps ahead
-template <int KS, int D, int T = 0>
+template <int KS, int D, bool ACC, int T = 0>
 __device__ __forceinline__ void gram4_steps(unsigned aN, unsigned aR, unsigned aB, double (&n)[KS], double (&r)[KS], double (&b)[KS], double (&acc)[3])
 {
     if constexpr (T < KS) {
@@ -65,15 +84,15 @@ __device__ __forceinline__ void gram4_steps(unsigned aN, unsigned aR, unsigned a
         }
         constexpr int newer = 3 * (KS - 1 - T < D ? KS - 1 - T : D);      // requests younger than this k-step's three
         lgkm_wait<newer + 2>(n[T]);
-        if constexpr (T == 0) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], n[T], 0.0, 0, 0, 0);
+        if constexpr (T == 0 && !ACC) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], n[T], 0.0, 0, 0, 0);
         else acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], n[T], acc[0], 0, 0, 0);
         lgkm_wait<newer + 1>(r[T]);
-        if constexpr (T == 0) acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], r[T], 0.0, 0, 0, 0);
+        if constexpr (T == 0 && !ACC) acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], r[T], 0.0, 0, 0, 0);
         else acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], r[T], acc[1], 0, 0, 0);
         lgkm_wait<newer>(b[T]);
-        if constexpr (T == 0) acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], b[T], 0.0, 0, 0, 0);
+        if constexpr (T == 0 && !ACC) acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], b[T], 0.0, 0, 0, 0);
         else acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(n[T], b[T], acc[2], 0, 0, 0);
-        gram4_steps<KS, D, T + 1>(aN, aR, aB, n, r, b, acc);
+        gram4_steps<KS, D, ACC, T + 1>(aN, aR, aB, n, r, b, acc);
     }
 }
 template <int KS, int D, int T = 0>
@@ -86,12 +105,14 @@ __device__ __forceinline__ void gram4_prime(unsigned aN, unsigned aR, unsigned a
         gram4_prime<KS, D, T + 1>(aN, aR, aB, n, r, b);
     }
 }
+// ACC: the accumulators carry the earlier passes of the view (otherwise the first k-step starts from C = 0)
+template <int KS, bool ACC>
 __device__ __forceinline__ void gram4_full(unsigned aN, unsigned aR, unsigned aB, double (&acc)[3])
 {
-    constexpr int D = 2;      // (round 5: 1, 2, 3 and 4 k-steps ahead measure the same to 0.1 us -- the MFMA phases do not wait for the LDS)
-    double n[kG4KS], r[kG4KS], b[kG4KS];
-    gram4_prime<kG4KS, D>(aN, aR, aB, n, r, b);
-    gram4_steps<kG4KS, D>(aN, aR, aB, n, r, b, acc);
+    constexpr int D = KS < 2 ? KS : 2;      // (round 5: 1, 2, 3 and 4 k-steps ahead measure the same to 0.1 us -- the MFMA phases do not wait for the LDS)
+    double n[KS], r[KS], b[KS];
+    gram4_prime<KS, D>(aN, aR, aB, n, r, b);
+    gram4_steps<KS, D, ACC>(aN, aR, aB, n, r, b, acc);
 }
 
 // t_b entry of this lane's quad: lanes j = 0, 1, 2 of a quad hold the t_c0, t_c1, t_c2 entries of one tile column; lane
@@ -102,8 +123,12 @@ __device__ __forceinline__ double quad_tb(double x, double c0, double c1, double
     return fma(c2, x2, fma(c0, x0, c1 * x1));
 }
 
+// KS: k-steps of a pass (4 KS rows >= the corners of a pass); MULTI: boards of more than 56 corners, P.g4_per corners per pass
+template <int KS, bool MULTI>
 __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S, int cand)
 {
+    static_assert(KS >= 1 && KS <= kG4MaxKS, "a pass holds at most 56 rows");
+    constexpr int kTile = g4_tile_doubles(KS);
     KTL(0);
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
 #ifdef TSCM_WAVE_TIMELINE
@@ -122,10 +147,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
 #endif
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lds_wave = eval_gram4_lds_doubles(P.n_points);
+    const int lds_wave = eval_gram4_lds_doubles(P.n_points, KS);
     double *lds = lds_all + (size_t)wave * lds_wave;
     double *Fl = lds;                          // the tile: holds the u-rows, then the v-rows
-    double *bxy = lds + kG4Tile;
+    double *bxy = lds + kTile;
     const int lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
     // Head in TWO dependent round trips (round 5; it was six: control block | board points, twice | view range | camera
@@ -141,7 +166,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     double *const cc_buf[2] = { S.cconst[0], S.cconst[1] };
     double *const rec_buf[2] = { S.rec[0], S.rec[1] };
     double camU[3] = { 0.0, 0.0, 0.0 }, camV[3] = { 0.0, 0.0, 0.0 };
-    for (int i = lane; i < kG4Tile; i += 64) Fl[i] = 0.0;     // rows of lanes without a corner, the zero column, the padding
+    for (int i = lane; i < KS * kG4Stride; i += 64) Fl[i] = 0.0;     // rows of lanes without a corner, the zero column, the padding
     int prev_nv = 0;
     double pf_u = 0.0, pf_v = 0.0;
     int warm = 0;
@@ -197,6 +222,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         if (b == 2 && i == 3 && j < 3) o6 = W(7, 3 + j);
     }
     if (lane < P.n_points) *reinterpret_cast<d2 *>(bxy + 2 * lane) = my_xy;
+    if constexpr (MULTI) {
+        for (int j = lane + 64; j < P.n_points; j += 64) *reinterpret_cast<d2 *>(bxy + 2 * j) = *reinterpret_cast<const d2 *>(P.board_xy + 2 * j);
+    }
+    const int per = MULTI ? P.g4_per : 4 * KS;          // corners of a pass
     asm volatile("" :: "s"(kw0), "s"(kw1), "s"(kw2), "s"(kw3), "s"(kw4), "s"(kw5), "s"(kw6), "s"(kw7), "s"(kw8));
 #ifdef TSCM_WAVE_TIMELINE
     tl_w[0] = wall_clock64();
@@ -213,6 +242,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     asm volatile("" : "+v"(m_cnt), "+v"(m_slot));
     for (int view = vbase; view < vend; ++view) {
         const int cnt = __builtin_amdgcn_readlane(m_cnt, view - vbase);
+        const int off = off_next;               // (MULTI: the later passes' observations)
         off_next += cnt;
         wave_lds_fence();                       // the previous view's MFMA phase has finished with the tile
 #if TSCM_PRIO
@@ -224,18 +254,23 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         const bool tail_steps = left <= 2 && ve - vb <= 16;
         set_prio(tail_steps ? left + 1 : 3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));
 #endif
-        TL_STAMP(ts0);
 #ifdef TSCM_WAVE_TIMELINE
         if (tl_on && tl_nv < kTlViews) g_tlv[(size_t)(4 + kTlViews) * chunk + 4 + tl_nv] = wall_clock64();
         ++tl_nv;
 #endif
         const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);
         auto VC = [&](int k) { return vcs[k]; };
-        const bool valid = lane < cnt;
+        double accU[3] = { 0.0, 0.0, 0.0 }, accV[3] = { 0.0, 0.0, 0.0 };
+        int pbv = 0;                            // first corner of the pass (MULTI)
+        do {
+        const int pb = MULTI ? pbv : 0;
+        TL_STAMP(ts0);
+        if constexpr (MULTI) { if (pb) wave_lds_fence(); }      // ... and so has the previous pass's
+        const bool valid = lane < (MULTI ? min(per, cnt - pb) : cnt);
         double fv[16];                          // v-rows wait in registers until the u-rows have been consumed (index = tile column)
         auto PUT = [&](int c, double u, double v) { (c < 8 ? fu_lo : fu_hi)[4 * c] = u; fv[c] = v; };
         if (valid) {
-            const double x = bxy[2 * lane], y = bxy[2 * lane + 1];
+            const double x = bxy[2 * (pb + lane)], y = bxy[2 * (pb + lane) + 1];
             // semantic column -> tile column of this kernel
             constexpr int tcol[15] = { kG4Wb, kG4Wb + 1, kG4Wb + 2, kG4Tc, kG4Tc + 1, kG4Tc + 2, kG4Wc, kG4Wc + 1, kG4Wc + 2,
                                        kG4F, kG4One, kG4Xi, kG4Lam, kG4Al, kG4R };
@@ -248,11 +283,15 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
             // prefetch of the next view (see k_eval_gram): observations, and the constant record into the L2
             const int vn = min(view + 1, vend - 1);
             const int cn = view + 1 < vend ? __builtin_amdgcn_readlane(m_cnt, vn - vbase) : 0;
-            warm = __builtin_amdgcn_raw_buffer_load_b32(r_vc, lane < 4 ? 64 * lane : (int)0xffffe000u, (int)(8u * (unsigned)kVStride * (unsigned)vn), 0);
-            pf_u = buf_load_f64(r_u, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
-            pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
+            if (!MULTI || pb == 0) warm = __builtin_amdgcn_raw_buffer_load_b32(r_vc, lane < 4 ? 64 * lane : (int)0xffffe000u, (int)(8u * (unsigned)kVStride * (unsigned)vn), 0);
+            // MULTI: the next pass of this view, or the first pass of the next one
+            const bool more = MULTI && pb + per < cnt;
+            const int ncnt = MULTI ? (more ? min(per, cnt - pb - per) : min(per, cn)) : cn;
+            const unsigned noff = more ? (unsigned)(off + pb + per) : (unsigned)off_next;
+            pf_u = buf_load_f64(r_u, lane < ncnt ? 8u * lane : 0xffffe000u, 8u * noff);
+            pf_v = buf_load_f64(r_v, lane < ncnt ? 8u * lane : 0xffffe000u, 8u * noff);
         }
-        prev_nv = cnt;
+        prev_nv = MULTI ? min(per, max(cnt - pb, 0)) : cnt;
         wave_lds_fence();
 #if TSCM_PRIO
         if (tail_steps && left == 0) set_prio(0);
@@ -261,8 +300,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
 #ifdef TSCM_WAVE_TIMELINE
         if (tl_nv == 1) tl_w[1] = wall_clock64();
 #endif
-        double accU[3] = { 0.0, 0.0, 0.0 }, accV[3] = { 0.0, 0.0, 0.0 };
-        gram4_full(aN, aR, aB, accU);
+        gram4_full<KS, MULTI>(aN, aR, aB, accU);
         wave_lds_fence();
         TL_STAMP(ts2);
         if (valid) {
@@ -271,8 +309,12 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         }
         wave_lds_fence();
         TL_STAMP(ts3);
-        gram4_full(aN, aR, aB, accV);
+        gram4_full<KS, MULTI>(aN, aR, aB, accV);
         TL_STAMP(ts4);
+        TL_ADD(0, ts0, ts1); TL_ADD(1, ts1, ts2); TL_ADD(2, ts2, ts3); TL_ADD(3, ts3, ts4);
+        pbv += per;
+        } while (MULTI && pbv < cnt);
+        TL_STAMP(ts4e);
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
 #pragma unroll
         for (int q = 0; q < 3; ++q) { camU[q] += accU[q]; camV[q] += accV[q]; }
@@ -300,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
             buf_store_f64(r_rec, o7b, offG, tb1);
         }
 #ifdef TSCM_WAVE_TIMELINE
-        { TL_STAMP(ts5); TL_ADD(0, ts0, ts1); TL_ADD(1, ts1, ts2); TL_ADD(2, ts2, ts3); TL_ADD(3, ts3, ts4); TL_ADD(4, ts4, ts5); }
+        { TL_STAMP(ts5); TL_ADD(4, ts4e, ts5); }
         if (view + 1 == ve) tl_w[3] = wall_clock64();
 #endif
     }

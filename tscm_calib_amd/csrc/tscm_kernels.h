@@ -217,6 +217,7 @@ struct DevProblem {
     // and every tile is rewritten in full each iteration.
     const short *bid_lut;              // [C*C] tile of block (mi, mj), mi <= mj; -1 = no board is seen by both
     int bid_part_small[kSmallBids + 1]; // bid_part_ptr by value (rigs of <= kMaxCamLds cameras: no memory round trip in front of the partial tiles)
+    int g4_per;                        // k_eval_gram4<KS, true>: corners of a pass (boards of more than 56 corners: g4_plan)
 };
 
 struct DevState {

@@ -92,6 +92,21 @@ struct tscm_comm {
     int rank = 0, world = 1, device = 0;
 };
 
+// the Gram kernels share one signature; k_eval_gram4 is instantiated per k-step count of a pass (tscm_eval_gram4.h: g4_plan)
+typedef void (*EvalKernel)(DevProblem, DevState, int);
+static EvalKernel g4_kernel(int ks, bool multi)
+{
+    static const EvalKernel single[kG4MaxKS] = {
+        k_eval_gram4<1, false>, k_eval_gram4<2, false>, k_eval_gram4<3, false>, k_eval_gram4<4, false>, k_eval_gram4<5, false>,
+        k_eval_gram4<6, false>, k_eval_gram4<7, false>, k_eval_gram4<8, false>, k_eval_gram4<9, false>, k_eval_gram4<10, false>,
+        k_eval_gram4<11, false>, k_eval_gram4<12, false>, k_eval_gram4<13, false>, k_eval_gram4<14, false> };
+    // several passes: ceil(n / passes) >= 29 corners per pass, i.e. at least 8 k-steps
+    static const EvalKernel passes[kG4MaxKS] = {
+        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k_eval_gram4<8, true>, k_eval_gram4<9, true>, k_eval_gram4<10, true>,
+        k_eval_gram4<11, true>, k_eval_gram4<12, true>, k_eval_gram4<13, true>, k_eval_gram4<14, true> };
+    return (multi ? passes : single)[ks - 1];
+}
+
 struct tscm_solver {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -148,7 +163,8 @@ struct tscm_solver {
     bool graph_order = false;           // this solve: k_solve_nd also for a rig of up to 4 cameras (TSCM_EXEC_GRAPH_REDUCED_ORDER / _DENSE_REDUCED_ORDER there)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
-    size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4 (boards of <= 56 corners)
+    size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4
+    EvalKernel eval4 = nullptr;         // ... and its instantiation for this problem's board (g4_kernel)
     // dominant-kernel timing
     int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel (and every n-th exchange) with HIP events
     unsigned ev_count[3] = { 0, 0, 0 }; // occurrences so far, by kind: 0 dominant kernel, 1 exchange of T, 2 exchange of H_stage
@@ -400,8 +416,17 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     const size_t lds_eval_bytes = sizeof(double) * (std::max<size_t>((size_t)16 * rp, 512) + kCst + 2 * (size_t)p->n_points);
     // k_eval_gram runs 4 single-chunk waves per workgroup (they share only the final camera-tile sum)
     if (4 * lds_eval_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds_eval_bytes)));
+    // the default Gram kernel: k_eval_gram4 instantiated for this board's pass plan (KS k-steps per pass, ceil(n / 56) passes per view)
+    const G4Plan g4 = g4_plan(p->n_points);
+    const EvalKernel eval4 = g4_kernel(g4.ks, g4.passes > 1);
+    size_t lds_eval4 = 4 * sizeof(double) * (size_t)eval_gram4_lds_doubles(p->n_points, g4.ks);
+#ifdef TSCM_G4_LDS_PAD      // occupancy experiments (tools/wave_timeline.py): fewer workgroups per CU, same kernel
+    lds_eval4 += TSCM_G4_LDS_PAD;
+#endif
+    if (lds_eval4 > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board with too many corners for the Gram kernel's LDS (more than about 2,000)");
+    if (lds_eval4 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(eval4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval4));
     int wgs_per_cu = 0;         // resident workgroups per CU (register- and LDS-limited)
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void *>(rp == 58 ? k_eval_gram<58> : k_eval_gram<0>), 256, 4 * lds_eval_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void *>(eval4), 256, lds_eval4));
 #ifdef TSCM_EVAL_WAVES          // occupancy experiments: chunk tables for this many waves per SIMD
     const int waves_per_cu = 4 * TSCM_EVAL_WAVES;
 #else
@@ -543,7 +568,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     DevState &S = s->S;
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
     P.rank = rank; P.world = world;
-    P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double));
+    P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double)); P.g4_per = g4.per;
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
     P.n_bchunks = (int)bc_begin.size(); P.n_tiles = n_tiles;
     std::vector<double> bxy(p->board_xy, p->board_xy + 2 * (size_t)p->n_points);
@@ -712,11 +737,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
 
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, rp == 58);
-    s->lds_eval4 = 4 * sizeof(double) * (size_t)eval_gram4_lds_doubles(p->n_points);
-#ifdef TSCM_G4_LDS_PAD      // occupancy experiments (tools/wave_timeline.py): fewer workgroups per CU, same kernel
-    s->lds_eval4 += TSCM_G4_LDS_PAD;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval4));
-#endif
+    s->lds_eval4 = lds_eval4; s->eval4 = eval4;
     // reduced solve: up to 8 cameras k_solve_nd on the plan of the camera-pair graph (tscm_nd_plan.h), larger rigs in global memory
     s->solve_variant = C <= 4 ? 0 : C <= kMaxCamLds ? 1 : 3;
     if (s->solve_variant == 0) {
@@ -886,8 +907,7 @@ static int timed_begin(tscm_solver *s, int kind, hipStream_t stream, hipEvent_t 
 // the events take the start and end time stamps of this kernel's packet on the solver's stream) -- two hipEventRecord
 // around it are two more packets with a drain each, 8.5 us per timed launch at config 4 and 3 % of the driver's
 // 20-step run
-template <typename K>
-static void launch_eval_kernel(K kernel, dim3 grid, size_t lds, tscm_solver *s, hipEvent_t e0, hipEvent_t e1, int cand)
+static void launch_eval_kernel(EvalKernel kernel, dim3 grid, size_t lds, tscm_solver *s, hipEvent_t e0, hipEvent_t e1, int cand)
 {
     if (e0) hipExtLaunchKernelGGL(kernel, grid, dim3(256), (std::uint32_t)lds, s->stream, e0, e1, 0, s->P, s->S, cand);
     else hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s->stream, s->P, s->S, cand);
@@ -903,7 +923,7 @@ static int launch_eval(tscm_solver *s, int cand)
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
     if (s->f32_jacobian && P.rp == 58) launch_eval_kernel(k_eval_gram_f32<14>, grid, s->lds_eval32, s, e0, e1, cand);
     else if (s->f32_jacobian) launch_eval_kernel(k_eval_gram_f32<0>, grid, s->lds_eval32, s, e0, e1, cand);
-    else if (P.rp == 58 && !s->gram16) launch_eval_kernel(k_eval_gram4, grid, s->lds_eval4, s, e0, e1, cand);
+    else if (!s->gram16) launch_eval_kernel(s->eval4, grid, s->lds_eval4, s, e0, e1, cand);       // every board size (round 6)
     else if (P.rp == 58) launch_eval_kernel(k_eval_gram<58>, grid, s->lds_eval, s, e0, e1, cand);
     else launch_eval_kernel(k_eval_gram<0>, grid, s->lds_eval, s, e0, e1, cand);
     return 0;
