@@ -23,7 +23,9 @@
 //     adjacent: K / 2 ds_read_b128 per operand and view instead of 2 x K ds_read_b32.  Boards of up to 56 corners
 //     (K = KB = 14 at compile time): the position is the lane itself, 58 positions per column -- 116 dwords = 4 * 29, the 16
 //     columns of one kq cover the 64 banks, and a workgroup's four tiles + ONE copy of the board points are 30.6 KB.
-//     Other boards: K = min(16, ceil(n_points / 4)) at run time, KB = 16, 66 positions per column;
+//     Every other board (round 6): the pass plan of k_eval_gram4 (g4_plan) -- K = KS k-steps at compile time, exactly
+//     ceil(n / 4) of them up to 56 corners, ceil(n / 56) balanced passes above (11 x 8 = 2 x 44: 22 k-steps per view where the
+//     64-row passes of rounds 1-5 ran 32); KB = K rounded up to even (16-byte block starts), 4 KB + 2 positions per column;
 //   * the u- and v-row MFMAs alternate: two independent accumulators, so the 40-cycle dependent latency of the
 //     instruction (32 to issue) is not paid 2 K times per view.
 // Measured (round 4, config 4, same box, alternating): 46.0 -> 43.5 us per launch; five workgroups per CU (86 VGPRs and
@@ -35,9 +37,9 @@
 // tile geometry: KB row positions per kq block (corner j at position KB (j / K) + j % K: the identity when KB = K),
 // P2 positions per tile column with 2 P2 = 4 * odd dwords (the 16 columns of an operand fetch cover the 64 banks)
 template <int KS> struct F32Tile {
-    static constexpr int KB = KS ? KS : 16;
-    static constexpr int P2 = KS == 14 ? 58 : 66;
-    static constexpr int kDoubles = 16 * P2;        // per wave; also covers the 512-double camera-tile exchange
+    static constexpr int KB = KS + (KS & 1);
+    static constexpr int P2 = 4 * KB + 2;
+    static constexpr int kDoubles = 16 * P2 > 512 ? 16 * P2 : 512;        // per wave; at least the 512-double camera-tile exchange
     static_assert(4 * KB <= P2 && (2 * P2) % 8 == 4 && (KB * 8) % 16 == 0, "block starts are 16-byte aligned, columns 4 * odd dwords apart");
 };
 
@@ -45,16 +47,21 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // dynamic LDS of a workgroup, in doubles: the four waves' tiles, then ONE copy of the board points
-__host__ __device__ inline int eval_f32_lds_doubles(int n_points, bool ks14) { return 4 * (ks14 ? F32Tile<14>::kDoubles : F32Tile<0>::kDoubles) + 2 * n_points; }
+__host__ __device__ inline int eval_f32_lds_doubles(int n_points, int ks)
+{
+    const int kb = ks + (ks & 1), tile = 16 * (4 * kb + 2);
+    return 4 * (tile > 512 ? tile : 512) + 2 * n_points;
+}
 
 #ifndef TSCM_F32_WGS
 #define TSCM_F32_WGS 4
 #endif
 
-// KS: k-steps of a pass at compile time (14: boards of 53..56 corners, the usual 9 x 6 .. 7 x 8), or 0: min(16, ceil(n_points / 4)) at run time
-template <int KS>
+// KS: k-steps of a pass; MULTI: boards of more than 56 corners, P.g4_per corners per pass (the pass plan of k_eval_gram4: g4_plan)
+template <int KS, bool MULTI>
 __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem P, DevState S, int cand)
 {
+    static_assert(KS >= 1 && KS <= kG4MaxKS, "a pass holds at most 56 rows");
     // the control block is read together with the static chunk tables (one memory round trip, not two);
     // the early exit is taken right before the first view
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
     int warm = 0;
     // k-steps of a pass (kernel-uniform) and this lane's row position as a corner; as an MFMA lane (column, kq): the rows
     // of its K k-steps are positions KB kq .. KB kq + K - 1 of tile column col (B operand) and pi(col) (A operand)
-    const int K = KS ? KS : __builtin_amdgcn_readfirstlane(min(16, (P.n_points + 3) >> 2));
+    constexpr int K = KS;
+    const int per = MULTI ? P.g4_per : 4 * KS;                            // corners of a pass
     f2 *fw = T2 + (KB == KS ? lane : KB * (lane / K) + lane % K);         // (lanes >= 4 K never hold a corner)
     typedef const f4 __attribute__((address_space(3))) *lds_f4;
     const lds_f4 pB = (lds_f4)(T2 + col * kP2 + KB * kq);
@@ -139,13 +147,13 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
         const cptr4 cst = (cptr4)(S.vconst + (size_t)kVStride * view);                 // this view's constants, doubles
         const fptr4 cs = (fptr4)(S.vconst + (size_t)kVStride * view + kVFloatOff);     // ... and floats
         d4 accU = { 0.0, 0.0, 0.0, 0.0 }, accV = { 0.0, 0.0, 0.0, 0.0 };
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
+        for (int c0 = 0; c0 < cnt; c0 += per) {
             const int j = c0 + lane;
-            const bool valid = j < cnt;
+            const bool valid = lane < (MULTI ? min(per, cnt - c0) : cnt);
             auto PUT = [&](int c, float u, float v) { fw[c * kP2] = f2{ u, v }; };
             if (valid) {
                 const double x = bxy[2 * j], y = bxy[2 * j + 1];
-                const double ou = c0 ? buf_load_f64(r_u, 8u * j, 8u * (unsigned)off) : pf_u, ov = c0 ? buf_load_f64(r_v, 8u * j, 8u * (unsigned)off) : pf_v;
+                const double ou = pf_u, ov = pf_v;
                 // ---- fp64: board -> world -> camera, triple sphere, residual (multi_calib.h:158-193) ----
                 const double X = fma(x, cst[0], fma(y, cst[3], cst[6]));
                 const double Y = fma(x, cst[1], fma(y, cst[4], cst[7]));
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
 #pragma unroll
                 for (int c = 0; c < kTcols; ++c) PUT(c, 0.f, 0.f);
             }
-            if (c0 == 0) {
+            {
                 // Prefetch of the next view, issued once the current view's observations have been consumed: the
                 // loads reuse the same registers (no copy that would have to wait for them), and everything
                 // between here and their use at the top of the next view is four unconditional stores.
@@ -228,25 +236,29 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
                 const int vn = min(view + 1, vend - 1);
                 const int cn = view + 1 < vend ? __builtin_amdgcn_readlane(m_cnt, vn - vbase) : 0;
                 // pull the next view's 384-byte constant record into the L2 (one tracked load, lanes 0..5)
-                warm = __builtin_amdgcn_raw_buffer_load_b32(r_vc, lane < 6 ? 64 * lane : (int)0xffffe000u, (int)(8u * (unsigned)kVStride * (unsigned)vn), 0);
-                pf_u = buf_load_f64(r_u, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
-                pf_v = buf_load_f64(r_v, lane < cn ? 8u * lane : 0xffffe000u, 8u * (unsigned)off_next);
+                if (!MULTI || c0 == 0) warm = __builtin_amdgcn_raw_buffer_load_b32(r_vc, lane < 6 ? 64 * lane : (int)0xffffe000u, (int)(8u * (unsigned)kVStride * (unsigned)vn), 0);
+                // MULTI: the next pass of this view, or the first pass of the next one
+                const bool more = MULTI && c0 + per < cnt;
+                const int ncnt = MULTI ? (more ? min(per, cnt - c0 - per) : min(per, cn)) : cn;
+                const unsigned noff = more ? (unsigned)(off + c0 + per) : (unsigned)off_next;
+                pf_u = buf_load_f64(r_u, lane < ncnt ? 8u * lane : 0xffffe000u, 8u * noff);
+                pf_v = buf_load_f64(r_v, lane < ncnt ? 8u * lane : 0xffffe000u, 8u * noff);
             }
             wave_lds_fence();
-            const int nv = min(64, cnt - c0);
+            const int nv = min(per, cnt - c0);
             prev_nv = nv;
             f4 aU = { 0.f, 0.f, 0.f, 0.f }, aV = { 0.f, 0.f, 0.f, 0.f };
             {
                 // rows of lanes without a corner are zero: all K k-steps run whatever the view's corner count
-                f4 A[4], B[4];
+                f4 A[4] = {}, B[4] = {};
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { A[m] = pA[m]; B[m] = pB[m]; }
+                for (int m = 0; m < 4; ++m) if (2 * m < K) { A[m] = pA[m]; B[m] = pB[m]; }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         const f4 a = A[m], b = B[m];
-                        if (h == 0) { A[m] = pA[4 + m]; B[m] = pB[4 + m]; }      // the second half's operands, behind their last use
+                        if (h == 0 && 8 + 2 * m < K) { A[m] = pA[4 + m]; B[m] = pB[4 + m]; }      // the second half's operands, behind their last use
                         const int t = 8 * h + 2 * m;
                         if (t < K) {
                             aU = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, aU, 0, 0, 0);
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem 
             // one pass (<= 64 corners) of fp32 accumulation, then fp64
 #pragma unroll
             for (int r = 0; r < 4; ++r) { accU[r] += (double)aU[r]; accV[r] += (double)aV[r]; }
-            if (KS) break;                   // (n_points <= 4 KS: one pass)
+            if (!MULTI) break;               // (n_points <= 4 KS: one pass)
         }
         asm volatile("" :: "v"(warm));       // the warming load retires here, before this view's record stores
         camU += accU; camV += accV;

@@ -38,22 +38,10 @@
 // (included from tscm_kernels.h inside namespace tscm)
 
 constexpr int kG4Stride = 68;                   // doubles per k-step of the tile
-constexpr int kG4MaxKS = 14;                    // k-steps of a pass: at most 56 rows
+// (kG4MaxKS, g4_plan: tscm_kernels.h, in front of the fp32-Jacobian tier's kernel, which runs on the same pass plan)
 // doubles of LDS per wave: the tile (>= the 512-double camera-tile exchange), then the board points
 __host__ __device__ constexpr int g4_tile_doubles(int ks) { return ks * kG4Stride > 512 ? ks * kG4Stride : 512; }
 __host__ __device__ inline int eval_gram4_lds_doubles(int n_points, int ks) { return g4_tile_doubles(ks) + 2 * n_points; }
-// pass plan of a board of n corners: ceil(n / 56) passes of `per` corners each (a multiple of four; the last pass takes what is left)
-struct G4Plan { int passes, per, ks; };
-__host__ __device__ inline G4Plan g4_plan(int n_points)
-{
-    G4Plan g;
-    g.passes = (n_points + 4 * kG4MaxKS - 1) / (4 * kG4MaxKS);
-    if (g.passes < 1) g.passes = 1;
-    g.ks = ((n_points + g.passes - 1) / g.passes + 3) / 4;
-    if (g.ks < 1) g.ks = 1;
-    g.per = 4 * g.ks;
-    return g;
-}
 
 // tile columns of this kernel
 constexpr int kG4Wb = 0, kG4R = 3, kG4Tc = 4, kG4Al = 7, kG4Wc = 8, kG4F = 11, kG4One = 12, kG4Xi = 13, kG4Lam = 14;

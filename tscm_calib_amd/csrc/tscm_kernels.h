@@ -896,6 +896,21 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     }
 }
 
+// Pass plan of the Gram kernels k_eval_gram4 / k_eval_gram_f32 (round 6: every board size): a pass holds 4 KS <= 56 rows
+constexpr int kG4MaxKS = 14;                    // k-steps of a pass: at most 56 rows
+// pass plan of a board of n corners: ceil(n / 56) passes of `per` corners each (a multiple of four; the last pass takes what is left)
+struct G4Plan { int passes, per, ks; };
+__host__ __device__ inline G4Plan g4_plan(int n_points)
+{
+    G4Plan g;
+    g.passes = (n_points + 4 * kG4MaxKS - 1) / (4 * kG4MaxKS);
+    if (g.passes < 1) g.passes = 1;
+    g.ks = ((n_points + g.passes - 1) / g.passes + 3) / 4;
+    if (g.ks < 1) g.ks = 1;
+    g.per = 4 * g.ks;
+    return g;
+}
+
 #include "tscm_eval_f32.h"
 
 // per-camera raw tile (GU | GV) reduction: one block per (camera, slice of 32 of the 512 raw entries).  Eight threads per

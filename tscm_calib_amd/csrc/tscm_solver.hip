@@ -106,6 +106,17 @@ static EvalKernel g4_kernel(int ks, bool multi)
         k_eval_gram4<11, true>, k_eval_gram4<12, true>, k_eval_gram4<13, true>, k_eval_gram4<14, true> };
     return (multi ? passes : single)[ks - 1];
 }
+static EvalKernel f32_kernel(int ks, bool multi)     // the fp32-Jacobian tier on the same pass plan
+{
+    static const EvalKernel single[kG4MaxKS] = {
+        k_eval_gram_f32<1, false>, k_eval_gram_f32<2, false>, k_eval_gram_f32<3, false>, k_eval_gram_f32<4, false>, k_eval_gram_f32<5, false>,
+        k_eval_gram_f32<6, false>, k_eval_gram_f32<7, false>, k_eval_gram_f32<8, false>, k_eval_gram_f32<9, false>, k_eval_gram_f32<10, false>,
+        k_eval_gram_f32<11, false>, k_eval_gram_f32<12, false>, k_eval_gram_f32<13, false>, k_eval_gram_f32<14, false> };
+    static const EvalKernel passes[kG4MaxKS] = {
+        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k_eval_gram_f32<8, true>, k_eval_gram_f32<9, true>, k_eval_gram_f32<10, true>,
+        k_eval_gram_f32<11, true>, k_eval_gram_f32<12, true>, k_eval_gram_f32<13, true>, k_eval_gram_f32<14, true> };
+    return (multi ? passes : single)[ks - 1];
+}
 
 struct tscm_solver {
     int device = 0;
@@ -164,7 +175,7 @@ struct tscm_solver {
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
     size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4
-    EvalKernel eval4 = nullptr;         // ... and its instantiation for this problem's board (g4_kernel)
+    EvalKernel eval4 = nullptr, eval32 = nullptr;   // ... and its instantiation for this problem's board (g4_kernel), the fp32-Jacobian tier's (f32_kernel)
     // dominant-kernel timing
     int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel (and every n-th exchange) with HIP events
     unsigned ev_count[3] = { 0, 0, 0 }; // occurrences so far, by kind: 0 dominant kernel, 1 exchange of T, 2 exchange of H_stage
@@ -736,8 +747,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_h_ctrl), s->h_ctrl, 0));
 
     s->lds_eval = 4 * lds_eval_bytes;
-    s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, rp == 58);
-    s->lds_eval4 = lds_eval4; s->eval4 = eval4;
+    s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, g4.ks);
+    s->lds_eval4 = lds_eval4; s->eval4 = eval4; s->eval32 = f32_kernel(g4.ks, g4.passes > 1);
     // reduced solve: up to 8 cameras k_solve_nd on the plan of the camera-pair graph (tscm_nd_plan.h), larger rigs in global memory
     s->solve_variant = C <= 4 ? 0 : C <= kMaxCamLds ? 1 : 3;
     if (s->solve_variant == 0) {
@@ -921,8 +932,7 @@ static int launch_eval(tscm_solver *s, int cand)
     if (int rc = timed_pair(s, 0, &e0, &e1)) return rc;
     const dim3 grid(P.n_chunks / 4);
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
-    if (s->f32_jacobian && P.rp == 58) launch_eval_kernel(k_eval_gram_f32<14>, grid, s->lds_eval32, s, e0, e1, cand);
-    else if (s->f32_jacobian) launch_eval_kernel(k_eval_gram_f32<0>, grid, s->lds_eval32, s, e0, e1, cand);
+    if (s->f32_jacobian) launch_eval_kernel(s->eval32, grid, s->lds_eval32, s, e0, e1, cand);
     else if (!s->gram16) launch_eval_kernel(s->eval4, grid, s->lds_eval4, s, e0, e1, cand);       // every board size (round 6)
     else if (P.rp == 58) launch_eval_kernel(k_eval_gram<58>, grid, s->lds_eval, s, e0, e1, cand);
     else launch_eval_kernel(k_eval_gram<0>, grid, s->lds_eval, s, e0, e1, cand);
@@ -1341,7 +1351,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     for (tscm_solver *s : run.m) {
         s->f32_jacobian = opt.jacobian_fp32 != 0;
         if (s->f32_jacobian && s->lds_eval32 > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(s->P.rp == 58 ? k_eval_gram_f32<14> : k_eval_gram_f32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(s->eval32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval32));
     }
 
     // control block (identical on every rank), counter of the fused T reduction, start point: one launch (k_begin_solve)
