@@ -70,10 +70,12 @@ BENCH_OPTS = dict(function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_to
                   min_trust_region_radius=0.0, check_every=ITERS_PER_SOLVE)
 CPU_BASELINE_ITERS = 6               # 1 thread: 4 s per iteration of the full config 4 on the boxes seen so far -- ~24 s of CPU work
 EVENT_STRIDE_MAX = 8                 # an event pair holds the stream for ~11 us (6.4 in front of the launch, 4.6 behind it: kernel
-                                     # trace of the driver's command, profiles/r05_eval_fixed_cost.txt): long runs time every 8th launch
-MIN_TIMED_LAUNCHES = 4               # ... short runs time more of them, so that at least this many are measured.  (8 until round 5:
-                                     # at --steps 20 that was every second launch, 11 pairs = 6 us per step of measurement inside the
-                                     # timed region; the kernel's duration varies by +-0.3 us from launch to launch, 4-5 samples carry it)
+                                     # trace of the driver's command, profiles/r05_eval_fixed_cost.txt): every 8th launch is timed
+MIN_TIMED_LAUNCHES = 4               # (TSCM_BENCH_EVENTS_IN_TIMED=1 only) short runs time more of them, so that at least this many are measured
+# Round 6: the dominant kernel is timed during the untimed PREHEAT loop -- the same launches on the same data, ~70 of them -- and
+# the timed region carries no event pair at all (rounds 1-5: five pairs = 55 us inside the driver's 20 timed steps, 2.75 us per
+# step of self-inflicted measurement).  `roofline.timed_in` says which.  TSCM_BENCH_EVENTS_IN_TIMED=1 restores the old protocol.
+EVENTS_IN_TIMED = os.environ.get("TSCM_BENCH_EVENTS_IN_TIMED") == "1"
 
 
 def event_stride(steps: int) -> int:
@@ -385,23 +387,32 @@ def main():
     natural = solver.solve_resident(reset=True, **extra)
     # the hot path itself for PREHEAT_MS before the W warmup steps (untimed): the fp64 ceilings above leave the device
     # at sustained clocks, this keeps it there through the host-side work in between
+    # HIP events around every stride-th launch of the dominant kernel -- and, with a communicator, around every stride-th all-reduce
+    # of each kind -- DURING THE PREHEAT (round 6), not inside the timed region
+    no_events = bool(os.environ.get("TSCM_BENCH_NO_EVENTS"))
+    stride = 0 if no_events else (event_stride(args.steps) if EVENTS_IN_TIMED else EVENT_STRIDE_MAX)
+    if not EVENTS_IN_TIMED:
+        solver.kernel_time(enable=stride)
+        solver.exchange_time()
     t_pre = time.perf_counter()
     while not stub and (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS:
         run_iterations(solver, ITERS_PER_SOLVE, **extra)
+    if not EVENTS_IN_TIMED:
+        launches, kms = solver.kernel_time(enable=False)
+        (n_xt, ms_xt), (n_xh, ms_xh) = solver.exchange_time()
     if args.warmup > 0:
         run_iterations(solver, args.warmup, **extra)
-    # HIP events around every stride-th launch of the dominant kernel (each pair holds the stream for ~6 us) -- and,
-    # with a communicator, around every stride-th all-reduce of each kind
-    stride = 0 if os.environ.get("TSCM_BENCH_NO_EVENTS") else event_stride(args.steps)
-    solver.kernel_time(enable=stride)
-    solver.exchange_time()
+    if EVENTS_IN_TIMED:
+        solver.kernel_time(enable=stride)
+        solver.exchange_time()
     barrier()
     t0 = time.perf_counter()
     run_iterations(solver, args.steps, **extra)
     barrier()
     elapsed_local = time.perf_counter() - t0
-    launches, kms = solver.kernel_time(enable=False)
-    (n_xt, ms_xt), (n_xh, ms_xh) = solver.exchange_time()
+    if EVENTS_IN_TIMED:
+        launches, kms = solver.kernel_time(enable=False)
+        (n_xt, ms_xt), (n_xh, ms_xh) = solver.exchange_time()
     elapsed = chan.allreduce_max(elapsed_local) if chan else elapsed_local
     if stub:
         n_local = int(full.n_corners / world)
@@ -414,6 +425,18 @@ def main():
             "allreduce_T_us": 1e3 * ms_xt / max(n_xt, 1), "allreduce_H_us": 1e3 * ms_xh / max(n_xh, 1),
             "allreduces_timed": [n_xt, n_xh]}
     per_rank = chan.gather(mine) if chan else [mine]
+
+    # what ONE call of the drop-in costs its caller (multi_calib.cpp:157-218: problem build + ceres::Solve): a warm
+    # tscm_solve_multi / tscm_solve_mono -- create (layout + H2D of the observations) + natural solve + write-back + destroy --
+    # behind the timed region, and where the creation of the bench's own solver (the first of the process) spent its time
+    one_shot = create_split = None
+    if rank == 0 and world == 1 and not stub:
+        create_split = solver.create_timing()
+        q1 = full.copy().normalised()
+        t1 = time.perf_counter()
+        r1 = api.refinement(q1, device, **extra)[1] if full.mono else api.calibrate(q1, device, **extra)
+        one_shot = {"seconds": time.perf_counter() - t1, "solve_seconds": r1["seconds_total"], "iterations": r1["num_iterations"] - 1,
+                    "note": "warm call of tscm_solve_multi / _mono: create + H2D + natural solve + write-back + destroy"}
 
     if rank == 0:
         avg_ms = kms / max(launches, 1)
@@ -429,9 +452,13 @@ def main():
             "kernel": "k_eval_gram_f32" if args.jacobian_fp32 else ("k_eval_gram (16x16x4 MFMA)" if (args.exec_flags & 4) else g4_name), "bound": "mfma",
             "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
             "traffic": None, "launches": launches, "timed_launches": launches, "launches_timed_every": stride, "avg_launch_ms": avg_ms,
+            # where the event pairs sat: "preheat" = the untimed loop in front of the W warmup steps (same launches, same data; the
+            # K timed steps carry no event), "steps" = inside the timed region (rounds 1-5)
+            "timed_in": "steps" if EVENTS_IN_TIMED else "preheat",
             # share of the step the dominant kernel accounts for; the iteration-0 evaluation of every solve is in the
             # timed region (and among the timed launches) but is not a step
             "share_of_step": (avg_ms * (args.steps + math.ceil(args.steps / ITERS_PER_SOLVE)) / (1e3 * elapsed)) if elapsed > 0 else 0.0,
+            "event_pairs_in_timed_region": launches if EVENTS_IN_TIMED else 0,
             "iteration0_evals_in_timed_region": math.ceil(args.steps / ITERS_PER_SOLVE),
             "alg_flop_per_launch": flops, "alg_bytes_per_launch": n_local * bytes_per_corner,
             "ps_per_corner": 1e9 * avg_ms / max(n_local, 1),
@@ -503,7 +530,9 @@ def main():
             "natural_solve": {"termination": natural["message"], "iterations": natural["num_iterations"] - 1,
                               "rmse_px": natural["rmse"], "seconds": natural["seconds_total"],
                               "device_seconds": natural["seconds_solve"],
-                              "create_seconds_incl_H2D_of_observations": t_create},
+                              "create_seconds_incl_H2D_of_observations": t_create,
+                              # (the bench's solver is the first of its process: runtime_init carries HIP's start-up)
+                              "create_split": create_split, "one_shot": one_shot},
             "roofline": roof,
         }
         if world > 1 or multi:

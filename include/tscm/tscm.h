@@ -24,7 +24,8 @@ extern "C" {
 #endif
 
 #define TSCM_ABI_VERSION 6   /* 2: tscm_problem.board_pose_constant; 3: tscm_options.exec_flags (both appended;  */
-                             /*    zero-initialised structs keep their meaning); 4: unknown exec_flags bits are  */
+                             /*    until ABI 5 a zero-initialised options struct kept its meaning -- from ABI 6   */
+                             /*    a zeroed struct has struct_size 0 and is REFUSED); 4: unknown exec_flags bits are  */
                              /*    refused, TSCM_EXEC_DENSE_REDUCED_ORDER, the fault injection of the tests is   */
                              /*    an entry point of its own (tscm_solver_debug_withhold_handoff), no option;    */
                              /* 5: tscm_comm_ipc_open / tscm_comm_ipc_connect, tscm_device_peak_fp32_mfma,       */
@@ -34,7 +35,9 @@ extern "C" {
                              /*    has and refuses a size it does not know -- an options struct of ABI <= 5 is   */
                              /*    refused instead of misread; TSCM_E_PEER; a late device-side hand-off re-runs  */
                              /*    the solve on separate launches before it is an error; TSCM_EXEC_SEPARATE_STATS */
-                             /*    (no struct changed; a library without the bit refuses it)                     */
+                             /*    (no struct changed; a library without the bit refuses it); round 6, still 6:  */
+                             /*    the rank-divergence guard of the sharded solver and its test hook             */
+                             /*    tscm_solver_debug_perturb_exchange (an entry point more, no struct changed)   */
 
 enum {
     TSCM_OK = 0,
@@ -45,8 +48,9 @@ enum {
     TSCM_E_UNSUPPORTED = -5,  /* problem shape outside what the kernels support       */
     TSCM_E_NOMEM = -6,
     TSCM_E_PEER = -7          /* the IPC exchange back-end: a peer rank did not arrive within its time bound, or its */
-                              /* memory could not be mapped (the communicator is unusable afterwards, like an        */
-                              /* aborted RCCL communicator)                                                          */
+                              /* memory could not be mapped; any back-end: the ranks disagree about the LM state     */
+                              /* (rank-divergence guard).  The communicator is unusable afterwards, like an aborted  */
+                              /* RCCL communicator                                                                   */
 };
 
 /* ceres::TerminationType values the reference looks at (TS.cpp:281). */
@@ -216,6 +220,12 @@ void tscm_default_options(tscm_options *opt, int mono);
  */
 int tscm_solver_create(const tscm_problem *problem, int device, tscm_solver **out);
 int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded multi-GPU, see below */
+/* Where the wall time of this solver's creation went, seconds: out[0] runtime_init (device selection, stream, device properties --
+ * the first call of a process pays HIP's initialisation here), [1] host_layout (view / board orders, chunk tables, Schur work
+ * lists), [2] gather (the observations into device view order), [3] h2d (device allocations and uploads), [4] kernel_setup
+ * (occupancy queries, function attributes, elimination plans, final synchronisation).  What one call of the reference's
+ * MultiCalib::calibrate() spends before ceres::Solve: the problem build of multi_calib.cpp:157-207. */
+int tscm_solver_create_timing(const tscm_solver *s, double out[5]);
 /* A hand-off between workgroups of one launch (evaluation's reductions -> control step; Schur-complement tiles -> reduced
  * solve -> back-substitution) that does not
  * come within its time bound (0.5 s: a debugger, a co-tenant, a context switch -- or a fault) stops the solve on the
@@ -230,6 +240,15 @@ int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded mu
  * the Schur-complement launch never counts itself in. */
 int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on);
 int tscm_solver_reruns(const tscm_solver *s);                /* solves of `s` that were run again so far (>= 0) */
+/* Rank-divergence guard (ABI 6, round 6; SURVEY 8e: "reductions must be order-deterministic ... so all replicas take the same
+ * accept/reject decision" -- the reference itself is single-threaded, multi_calib.cpp:209-212).  The ranks of a communicator run
+ * the reduced solve and the control step redundantly on all-reduced data; every rank folds its LM state and the replicated
+ * results of its reduced solve into a 52-bit word that travels in the all-reduce of the evaluation (no extra collective, no
+ * extra launch), and the control step behind it compares all ranks' words: a mismatch stops the solve on every rank in the
+ * same step with TSCM_E_PEER ("ranks disagree at iteration k"); the communicator is unusable afterwards.
+ * TESTS ONLY: tscm_solver_debug_perturb_exchange(s, k, ulps): in the next solve of `s` the copy of the Schur-complement tiles
+ * this rank RECEIVES from the all-reduce of LM iteration k (1-based; 0: off) is moved by `ulps` units in the last place. */
+int tscm_solver_debug_perturb_exchange(tscm_solver *s, int iteration, int ulps);
 int tscm_solver_solve(tscm_solver *s, const tscm_options *opt, tscm_summary *summary);
 /* Same as _solve but parameters start from / are left in device memory (used by the
  * benchmark to time the minimiser loop with inputs resident in HBM). reset=1 reloads
@@ -323,7 +342,8 @@ int tscm_comm_create_local(int world, int device, tscm_comm **out /* [world] */)
 /* IPC  one process per rank like RCCL; the exchange is the library's own one-shot all-reduce over buffers the ranks map
  *      from each other (hipIpcMemHandle).  Ranks MAY share a device (RCCL refuses that): the multi-process path on a
  *      one-GPU box.  Every rank calls tscm_comm_ipc_open (max_doubles >= 256 * max(camera-pair blocks, cameras) + 8 +
- *      world: api.Comm.ipc computes it), the 64-byte handles are all-gathered by the caller (socket, file, MPI ...),
+ *      2 world: api.Comm.ipc computes it; a longer buffer travels in pieces), the TSCM_IPC_HANDLE_BYTES-byte handles are
+ *      all-gathered by the caller (socket, file, MPI ...),
  *      every rank calls tscm_comm_ipc_connect with all of them in rank order; then tscm_solver_set_comm as with RCCL.
  *      Exercised between processes on one device; RCCL is the production path across devices. */
 #define TSCM_IPC_HANDLE_BYTES 80      /* (64 until ABI 5) the HIP handle, then the device's PCI address and the buffer's kind */

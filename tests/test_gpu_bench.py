@@ -118,3 +118,21 @@ def test_a_rank_that_is_gone_is_reported_not_waited_for(hip_device):
     assert out.returncode == 0 and len(lines) == 1, (out.stdout + out.stderr)[-3000:]
     assert lines[0]["peer_failure_detected"] and lines[0]["code"] == -7 and 5 < lines[0]["seconds"] < 60
     assert lines[0]["again_code"] == -7 and lines[0]["again_seconds"] < 2.0
+
+
+def test_rank_processes_that_receive_different_bits_stop_in_the_same_step(hip_device):
+    """The rank-divergence guard across PROCESSES (IPC back-end, 3 ranks on this device): rank 1's received copy of the
+    Schur-complement tiles is moved by one unit in the last place at LM iteration 3; every rank's solve must end with
+    TSCM_E_PEER "ranks disagree ... at iteration 3" (not a hang, not three different answers), and the next solve on the
+    dead communicator fails at once."""
+    tool = os.path.join(os.path.dirname(BENCH), "tools", "ipc_check.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, tool, "--world", "3", "--config", "3", "--iterations", "10", "--perturb-rank", "1", "--perturb-at", "3"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout + out.stderr)[-3000:]
+    ranks = lines[0]["ranks"]
+    assert len(ranks) == 3
+    for r in ranks:
+        assert r["disagreement_detected"] and r["code"] == -7 and "at iteration 3" in r["message"], r
+        assert r["again_code"] == -7 and r["seconds"] < 30

@@ -213,3 +213,38 @@ def test_group_api_misuse_is_refused(hip_device):
             c.close()
     with pytest.raises(TscmError):
         api.Solver(p, rank=2, world=2)
+
+
+# ------------------------------------------------------------------ rank-divergence guard (round 6)
+@pytest.mark.parametrize("world,bad_rank,at", [(2, 1, 2), (3, 0, 1), (8, 5, 3)])
+def test_ranks_that_receive_different_bits_stop_in_the_same_step(hip_device, world, bad_rank, at):
+    """"reductions must be order-deterministic ... so all replicas take the same accept/reject decision".  The ranks
+    run the reduced solve and the control step redundantly; if an all-reduce ever handed ONE rank other bits (here: its received
+    copy of T moved by one unit in the last place at iteration `at`), the ranks' states diverge silently.  The decision words that
+    travel with the evaluation's all-reduce must stop the solve on EVERY rank in that very iteration (TSCM_E_PEER), and the
+    group is unusable afterwards -- while the same group, unperturbed, still gives the bits of the unsharded solve's trace."""
+    from tscm_calib_amd import lib
+    p = H.small_rig(4, 30, seed=21)
+    q = p.copy().normalised()
+    with api.Group(q, world) as g:
+        ref = g.solve()                                      # the guard is silent on a healthy run
+    _ranks_agree(ref)
+    assert ref[0]["message"] == "Function tolerance reached." and ref[0]["num_iterations"] > at + 1
+    qa = p.copy().normalised()
+    with api.Group(qa, world) as g:
+        g.solvers[bad_rank].debug_perturb_exchange(at, 1)
+        with pytest.raises(lib.TscmError) as e:
+            g.solve()
+        assert e.value.code == -7 and f"disagree about the LM state at iteration {at}" in str(e.value), str(e.value)
+        with pytest.raises(lib.TscmError) as e2:             # unusable from here on
+            g.solve()
+        assert e2.value.code == -7 and "unusable" in str(e2.value)
+    assert np.array_equal(qa.intr, p.copy().normalised().intr)          # the failed solve wrote nothing back
+    # a fresh group, the same perturbation switched off again: nothing sticks to the library
+    q2 = p.copy().normalised()
+    with api.Group(q2, world) as g:
+        g.solvers[bad_rank].debug_perturb_exchange(at, 1)
+        g.solvers[bad_rank].debug_perturb_exchange(0, 0)
+        again = g.solve()
+    assert [it["cost"] for it in again[0]["iterations"]] == [it["cost"] for it in ref[0]["iterations"]]
+    assert np.array_equal(q.intr, q2.intr) and np.array_equal(q.cam_rt, q2.cam_rt) and np.array_equal(q.board_rt, q2.board_rt)

@@ -4,7 +4,7 @@
 # (tools/prof.sh: kernel trace of bench.py) and prints, per build and round, the LM rate and the MEDIAN duration of every
 # kernel of the solver over the several hundred launches of the run -- the HIP-event figure of tools/variants.sh averages
 # 13 launches and cannot tell builds apart that differ by less than a microsecond.  Restores the release build at the end.
-names=$1; n=${2:-2}; shift 2
+names=$1; n=${2:-2}; shift; [ $# -gt 0 ] && shift
 d=$GRAFT_REPO_ROOT/tscm_calib_amd/csrc
 cp $d/libtscm_hip.so /tmp/libtscm_release.so
 trap 'cp /tmp/libtscm_release.so $d/libtscm_hip.so' EXIT

@@ -68,6 +68,29 @@ def rank_main(args):
             print(json.dumps({"rank": rank, "peer_failure_detected": True, "code": e.code, "seconds": t1 - t0, "message": str(e)[:120],
                               "again_code": again, "again_seconds": time.perf_counter() - t1}), flush=True)
         os._exit(0)                                # (no collective clean-up with a peer that is gone)
+    if args.perturb_rank >= 0:
+        # rank-divergence guard: ONE rank's received copy of T is moved by one unit in the last place at iteration --perturb-at;
+        # EVERY rank must come back with TSCM_E_PEER "ranks disagree" from that very iteration, and the communicator is unusable afterwards
+        from tscm_calib_amd.lib import TscmError
+        if rank == args.perturb_rank:
+            solver.debug_perturb_exchange(args.perturb_at, 1)
+        t0 = time.perf_counter()
+        try:
+            solver.solve(**opts)
+            rec = {"rank": rank, "disagreement_detected": False}
+        except TscmError as e:
+            t1 = time.perf_counter()
+            try:
+                solver.solve(**opts)
+                again = 0
+            except TscmError as e2:
+                again = e2.code
+            rec = {"rank": rank, "disagreement_detected": True, "code": e.code, "seconds": t1 - t0, "message": str(e)[:160], "again_code": again}
+        recs = chan.gather(rec)
+        if rank == 0:
+            print(json.dumps({"world": world, "perturbed_rank": args.perturb_rank, "at_iteration": args.perturb_at, "ranks": recs}), flush=True)
+        chan.barrier()
+        os._exit(0)                                # (the communicator is dead: no collective clean-up)
     t0 = time.perf_counter()
     s = solver.solve(**opts)                       # in/out through full.cam_rt / intr / board_rt; gathers the boards over the communicator
     wall = time.perf_counter() - t0
@@ -130,12 +153,15 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--iterations", type=int, default=12, help="forced LM iterations (0: the natural solve)")
     ap.add_argument("--die-rank", type=int, default=-1, help="this rank exits before the solve: the others must report TSCM_E_PEER, not hang")
+    ap.add_argument("--perturb-rank", type=int, default=-1, help="rank-divergence guard: this rank's received T is moved by one ulp ...")
+    ap.add_argument("--perturb-at", type=int, default=2, help="... at this LM iteration: every rank must report TSCM_E_PEER 'ranks disagree'")
     args = ap.parse_args()
     if os.environ.get("TSCM_IPC_CHECK_RANK") == "1":
         return rank_main(args)
     rc = 0
     for w in [int(x) for x in args.world.split(",")]:
-        rc = rc or launch(w, ["--config", str(args.config), "--iterations", str(args.iterations), "--world", str(w), "--die-rank", str(args.die_rank)])
+        rc = rc or launch(w, ["--config", str(args.config), "--iterations", str(args.iterations), "--world", str(w), "--die-rank", str(args.die_rank),
+                                "--perturb-rank", str(args.perturb_rank), "--perturb-at", str(args.perturb_at)])
     sys.exit(rc)
 
 

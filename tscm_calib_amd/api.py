@@ -59,6 +59,17 @@ class Solver:
         the Schur-complement launch."""
         _l.check(_l.lib().tscm_solver_debug_withhold_handoff(self._h, int(on)))
 
+    def create_timing(self) -> dict:
+        """Where the wall time of this solver's creation went, seconds (tscm_solver_create_timing)."""
+        out = (C.c_double * 5)()
+        _l.check(_l.lib().tscm_solver_create_timing(self._h, out))
+        return dict(zip(("runtime_init", "host_layout", "gather", "h2d", "kernel_setup"), (float(x) for x in out)))
+
+    def debug_perturb_exchange(self, iteration: int, ulps: int = 1):
+        """Tests only (rank-divergence guard): in the NEXT solve the Schur-complement tiles this rank RECEIVES from the all-reduce of
+        LM iteration `iteration` are moved by `ulps` units in the last place (tscm_solver_debug_perturb_exchange)."""
+        _l.check(_l.lib().tscm_solver_debug_perturb_exchange(self._h, int(iteration), int(ulps)))
+
     def reruns(self) -> int:
         """Solves of this solver that were run again on separate launches after a late device-side hand-off."""
         n = _l.lib().tscm_solver_reruns(self._h)
@@ -143,7 +154,7 @@ class Comm:
         communicator will serve (sizes the exchange slots: 256 doubles per camera-pair block)."""
         h = C.c_void_p()
         mine = (C.c_ubyte * _l.IPC_HANDLE_BYTES)()
-        max_doubles = 256 * max(n_cameras * (n_cameras + 1) // 2, n_cameras) + 8 + world
+        max_doubles = 256 * max(n_cameras * (n_cameras + 1) // 2, n_cameras) + 8 + 2 * world
         _l.check(_l.lib().tscm_comm_ipc_open(rank, world, device, max_doubles, C.byref(h), mine))
         note = _l.lib().tscm_last_error().decode(errors="replace")      # (which kind of memory the exchange buffer got)
         c = Comm(None, rank, world, device, _handle=h)

@@ -124,6 +124,13 @@ __device__ __forceinline__ void buf_store_2f64(__amdgpu_buffer_rsrc_t r, unsigne
 #ifndef TSCM_PRIO
 #define TSCM_PRIO 10
 #endif
+// A/B switches of round 6 (experiment builds only: make variant EXTRA=-D...=0)
+#ifndef TSCM_AB_GUARD
+#define TSCM_AB_GUARD 1
+#endif
+#ifndef TSCM_AB_DONE_POLL
+#define TSCM_AB_DONE_POLL 1
+#endif
 __device__ __forceinline__ void set_prio(int p)
 {
     switch (p & 3) {
@@ -153,7 +160,9 @@ struct IterLog {
     double cost, cost_change, gradient_max_norm, gradient_norm, step_norm, relative_decrease, radius;
 };
 
-enum TermReason { kNone = 0, kMaxIter, kGradTol, kMinRadius, kParamTol, kFuncTol, kInvalidSteps };
+enum TermReason { kNone = 0, kMaxIter, kGradTol, kMinRadius, kParamTol, kFuncTol, kInvalidSteps, kRanksDisagree };
+// ctrl->fault (sticky): 1 = a device-side hand-off came late, 2 = the ranks of a communicator disagree about the LM state (decision_word)
+constexpr int kFaultHandoff = 1, kFaultRanksDisagree = 2;
 
 struct CtrlHead {
     // ---- header (polled by the host) ----
@@ -1145,6 +1154,8 @@ __device__ __forceinline__ void control_prefetch(const DevProblem &P, const DevS
     control_early_params(P, S, e);
     control_state(P, init, pre, head, e);
 }
+// GUARD: the step behind an all-reduce of H_stage (k_control, k_schur_gram's ctl = 2) checks the ranks' decision words first
+template <bool GUARD = false>
 __device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy,
                              bool writer = true, CtlOut *out = nullptr);
 
@@ -1159,6 +1170,32 @@ __device__ __forceinline__ double camera_tile_entry(const double *G, int t)
         if (m & 2) v += G[256 + ta * 16 + tb];
     }
     return v;
+}
+
+// Rank-divergence guard (round 6).  The sharded solver has every rank run the reduced solve and the control step REDUNDANTLY on
+// the all-reduced T and H_stage; that is only right while every rank receives the same bits from every all-reduce (ring and tree
+// sums do; a protocol that sums in a rank-relative order need not) and computes the same bits from them.  Nothing used to
+// notice if that ever failed -- two ranks one ulp apart may take different accept / reject or termination decisions: silently
+// different states behind equal numbers of collectives, or a 60 s watchdog abort.  Now every rank folds what the ranks must agree
+// on -- the LM state as its last control step left it AND the replicated results of its reduced solve (model cost change and step
+// norm of the camera step, the linear-solver failure flag) -- into an integer below 2^52 (exact as a double, exact through a sum
+// whose other terms are zero, whatever the order) and puts it into its own slot behind the gradient-max slots of H_stage
+// (k_finalize_eval); the all-reduce that carries the evaluation carries the words, and the control step behind it compares
+// every slot with the word of its own state: a mismatch raises ctrl->fault = kFaultRanksDisagree on every rank in the SAME step
+// (TSCM_E_PEER "ranks disagree at iteration k", communicator unusable).  No extra collective, no extra launch.
+__device__ __forceinline__ double decision_word(const CtrlHead &c)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    auto mix = [&](unsigned long long v) { h ^= v; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29; };
+    mix(((unsigned long long)(unsigned)c.iteration << 32) | (unsigned)c.lm_iterations);
+    mix(((unsigned long long)(unsigned)c.cur << 40) | ((unsigned long long)(unsigned)c.done << 32) | ((unsigned)c.term_reason << 16) | ((unsigned)c.lin_fail << 8) | (unsigned)c.num_invalid);
+    mix(((unsigned long long)(unsigned)c.num_successful << 32) | (unsigned)c.num_unsuccessful);
+    mix((unsigned long long)__double_as_longlong(c.radius));
+    mix((unsigned long long)__double_as_longlong(c.decrease_factor));
+    mix((unsigned long long)__double_as_longlong(c.x_cost));
+    mix((unsigned long long)__double_as_longlong(c.model_cam));
+    mix((unsigned long long)__double_as_longlong(c.stepsq_cam));
+    return (double)((h >> 12) | 1ull);           // 52 bits, never zero (zero = a slot nobody wrote)
 }
 
 // the per-workgroup scalar partials of the back-substitution and of the board statistics -> the kScal + world scalars
@@ -1197,10 +1234,24 @@ __device__ __forceinline__ void reduce_scalar_partials_from(const DevProblem &P,
     {
         const int n = S.n_st_blocks;
         double g4[4] = { 0, 0, 0, 0 }, s4[4] = { 0, 0, 0, 0 }, x4[4] = { 0, 0, 0, 0 };
+        // THROUGH: sc1 buffer loads (what handoff_load compiles to), lanes past the end parked beyond the buffer -- read through, a
+        // clamped index makes every one of a launch's 2,000 waves fetch the last line from the L2 twelve times (round 6: +0.45 us
+        // on k_schur_gram<2, true>); a parked lane costs no memory request and returns zero
+        const __amdgpu_buffer_rsrc_t r_st = make_rsrc(S.st_part, sizeof(double) * (size_t)kStStride * (size_t)n);
         for (int i = t; i < n; i += 4 * 256) {
             double q[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const double *src = S.st_part + kStStride * (size_t)min(i + 256 * u, n - 1); q[u][0] = THROUGH ? handoff_load(src) : src[0]; q[u][1] = THROUGH ? handoff_load(src + 1) : src[1]; q[u][2] = THROUGH ? handoff_load(src + 2) : src[2]; }
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (THROUGH) {
+                    const unsigned off = i + 256 * u < n ? 8u * (unsigned)kStStride * (unsigned)(i + 256 * u) : 0xffffe000u;
+                    const d2 a = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r_st, (int)off, 0, 16));
+                    q[u][0] = a[0]; q[u][1] = a[1];
+                    q[u][2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_st, (int)off, 16, 16));
+                } else {
+                    const double *src = S.st_part + kStStride * (size_t)min(i + 256 * u, n - 1);
+                    q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const bool in = i + 256 * u < n; g4[u] = fmax(g4[u], in ? q[u][0] : 0.0); s4[u] += in ? q[u][1] : 0.0; x4[u] += in ? q[u][2] : 0.0; }
         }
@@ -1229,6 +1280,10 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
 {
     KTL(2);
     const int done = S.ctrl->done, lin_fail = S.ctrl->lin_fail;
+    // this rank's decision word (see decision_word): the state every rank must share when the control step behind the all-reduce
+    // of H_stage is taken (requested with the two fields above: one round trip)
+    double word = 0.0;
+    if ((int)blockIdx.x == P.C && threadIdx.x == 0 && P.world > 1) word = decision_word(*S.ctrl);
     if (done) return;
     __shared__ double sm[256];
     __shared__ double G[512];
@@ -1241,6 +1296,7 @@ __global__ __launch_bounds__(256) void k_finalize_eval(DevProblem P, DevState S,
         S.H_stage[256 * cam + t] = camera_tile_entry(G, t);
     } else {
         reduce_scalar_partials<false>(P, S, have_backsub, lin_fail, S.H_stage + 256 * P.C, sm);
+        if (t == 0 && P.world > 1) for (int r = 0; r < P.world; ++r) S.H_stage[256 * P.C + kScal + P.world + r] = r == P.rank ? word : 0.0;
     }
 }
 
@@ -1291,6 +1347,7 @@ __device__ __forceinline__ void control_early(const DevProblem &P, const DevStat
     control_early_params(P, S, e);
     backsub_partials(S, have_backsub, e.mb, e.ss);
 }
+template <bool THROUGH>
 __device__ __forceinline__ void control_outcome_late(const DevProblem &P, const DevState &S, int init, const ControlEarly &e, double *Hl, double *sm, CtlOut *out, const CtrlHead *head)
 {
     const int t = threadIdx.x;
@@ -1298,9 +1355,10 @@ __device__ __forceinline__ void control_outcome_late(const DevProblem &P, const 
     control_state(P, init, pre, head, e);
     const int m = min(t >> 4, P.C - 1), a = t & 15;
     const int fa = min(a, 13), ta = f_tile(fa), tb = f_tile(kFR), mk = f_mask(fa) & f_mask(kFR);
-    const double gu = S.campart2[(size_t)512 * m + ta * 16 + tb], gv = S.campart2[(size_t)512 * m + 256 + ta * 16 + tb];
+    const double *pu = &S.campart2[(size_t)512 * m + ta * 16 + tb], *pv = &S.campart2[(size_t)512 * m + 256 + ta * 16 + tb];
+    const double gu = THROUGH ? handoff_load(pu) : *pu, gv = THROUGH ? handoff_load(pv) : *pv;
     double *scl = Hl + 256 * P.C;
-    reduce_scalar_partials_from<false>(P, S, e.mb, e.ss, pre.c.lin_fail, scl, sm);
+    reduce_scalar_partials_from<THROUGH>(P, S, e.mb, e.ss, pre.c.lin_fail, scl, sm);
     if (t < 16 * P.C && a < 14) Hl[256 * m + a * 16 + kFR] = ((mk & 1) ? gu : 0.0) + ((mk & 2) ? gv : 0.0);
     __syncthreads();
     control_step(P, S, init, pre, sm, Hl, scl, nullptr, /*writer=*/false, out);
@@ -1714,13 +1772,18 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
             __shared__ int s_late;
             if (threadIdx.x == 0) {
                 const long long t_start = wall_clock64();
-                int late = 0;
+                int late = 0, spins = 0;
                 while (__hip_atomic_load(S.stats_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stats_target) {
                     __builtin_amdgcn_s_sleep(4);
                     if (wall_clock64() - t_start > kHandoffTimeoutTicks) { late = 1; break; }
+                    // (a solve that was stopped -- a late hand-off in an EARLIER launch leaves stats_count behind its target for good --
+                    // must not make every launch still enqueued behind it spin for the full bound as well)
+                    // -- looked at every 256th poll only (about 30 us): polled every time by the 370 waiting workgroups, the control block's
+                    // line -- which the head of every workgroup reads and the writer workgroup commits to -- cost the launch 1.1 us (round 6)
+                    if (TSCM_AB_DONE_POLL && (++spins & 255) == 0 && __hip_atomic_load(&S.ctrl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { late = 2; break; }
                 }
-                if (late) {          // a device fault like any other late hand-off
-                    __hip_atomic_store(&S.ctrl->fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (late == 1) {     // a device fault like any other late hand-off
+                    __hip_atomic_store(&S.ctrl->fault, kFaultHandoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&S.ctrl->term_type, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&S.ctrl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1728,6 +1791,15 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
             }
             __syncthreads();
             if (s_late) return;
+            // Behind the flag this workgroup reads what OTHER workgroups of this launch wrote (advisor, round 5): the finished sums and
+            // the board statistics' lines are read THROUGH (handoff_load, like every other in-launch hand-off: control_outcome_late<true>,
+            // finish_evaluation<true>), and the scalar cache is dropped in front of the snapshot, which control_state reads through
+            // the constant address space although its last writer is a reduction block of this very launch.  (An acquire FENCE here
+            // -- measured, round 6 -- costs 12.5 us per launch at config 4: it waits for the 34 MB of records requested in front of
+            // the wait, which are the point of requesting them there.)
+#ifndef TSCM_AB_NO_DCACHE_INV
+            asm volatile("s_dcache_inv" ::: "memory");
+#endif
         }
         PHASE_STAMP(tsw);
 #ifdef TSCM_WAVE_TIMELINE
@@ -1758,11 +1830,16 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
             // communicator path: H_stage holds the all-reduced tiles and scalars -- k_control's work, by every workgroup
             ControlPre pre;
             control_prefetch(P, S, 0, pre, head);
-            control_step(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, &s_ctl);
+            control_step<true>(P, S, 0, pre, scratch, S.H_stage, S.H_stage + 256 * P.C, nullptr, /*writer=*/extra, &s_ctl);
         } else {
-            if (extra) finish_evaluation<false>(P, S, ctl_init, !ctl_init, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
-            else if (RIDE && cur_spec >= 0) control_outcome_late(P, S, ctl_init, early, scratch, scratch + kHl, &s_ctl, head);
-            else control_outcome<false>(P, S, ctl_init, !ctl_init, scratch, scratch + kHl, &s_ctl, head);
+#ifdef TSCM_AB_PLAIN_RIDE_LOADS      // (A/B builds: round 5's plain loads behind the flag)
+            constexpr bool TH = false;
+#else
+            constexpr bool TH = RIDE;
+#endif
+            if (extra) finish_evaluation<TH>(P, S, ctl_init, !ctl_init, true, scratch, scratch + kHl, scratch + kHl + kGall, &s_ctl, head);
+            else if (RIDE && cur_spec >= 0) control_outcome_late<TH>(P, S, ctl_init, early, scratch, scratch + kHl, &s_ctl, head);
+            else control_outcome<TH>(P, S, ctl_init, !ctl_init, scratch, scratch + kHl, &s_ctl, head);
         }
         if (extra) {
             // thread 0 took the serial part of the step and committed it: the outcome, written through, then the epoch
@@ -2659,6 +2736,7 @@ __global__ __launch_bounds__(NTH) void k_backsub_prep(DevProblem P, DevState S, 
 // writer = false: the step is taken redundantly (k_schur_gram: every workgroup runs it in its head, on the same inputs,
 // to the same bits -- no hand-off, no kernel of its own); only the writer touches global memory.  out: the new state for
 // the calling workgroup.
+template <bool GUARD>
 __device__ void control_step(const DevProblem &P, const DevState &S, int init, const ControlPre &pre, double *sm, const double *H, const double *sc, double *stage_copy,
                              bool writer, CtlOut *out)
 {
@@ -2672,6 +2750,12 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
     if (c.done) return;
     const Options &o = c.opt;
     const int tgt = init ? c.cur : (c.cur ^ 1);
+    // rank-divergence guard: every rank's decision word (in its slot of the all-reduced scalars) against this rank's own state
+    bool disagree = false;
+    if (GUARD && TSCM_AB_GUARD && P.world > 1 && t == 0) {
+        const double mine = decision_word(c);
+        for (int r = 0; r < P.world; ++r) disagree |= sc[kScal + P.world + r] != mine;
+    }
     // camera-side norms |x - Plus(x, -g)|_inf, its 2-norm, |x|^2 and the cost, one thread per parameter
     double gmax_c = 0.0, gsq_c = 0.0, xsq_c = 0.0, cost = 0.0;
 #pragma unroll
@@ -2708,6 +2792,11 @@ __device__ void control_step(const DevProblem &P, const DevState &S, int init, c
         if (writer) static_cast<CtrlHead &>(g) = c;
         if (out) { out->cur = c.cur; out->done = c.done; out->radius = c.radius; }
     };
+    if (GUARD && disagree) {
+        // some rank holds a different LM state or computed a different camera step: stop here, on every rank in the same step
+        // (each of them sees a slot that is not its own word), before another decision is taken on diverged states
+        c.done = 1; c.term_type = 2; c.term_reason = kRanksDisagree; c.fault = kFaultRanksDisagree; commit(); return;
+    }
     double gmax_b = 0.0;
     for (int r = 0; r < P.world; ++r) gmax_b = fmax(gmax_b, sc[kScal + r]);
     const double gmax_t = fmax(gmax_c, gmax_b);
@@ -2799,7 +2888,7 @@ __global__ __launch_bounds__(256) void k_control(DevProblem P, DevState S, int i
     __shared__ double sm[256];
     ControlPre pre;
     control_prefetch(P, S, init, pre, S.ctrl);
-    control_step(P, S, init, pre, sm, S.H_stage, S.H_stage + 256 * P.C, nullptr);
+    control_step<true>(P, S, init, pre, sm, S.H_stage, S.H_stage + 256 * P.C, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -53,6 +53,7 @@ static double wall() { return std::chrono::duration<double>(std::chrono::steady_
 // one-GPU box (RCCL refuses two ranks on one device) and serves hosts that drive several shards from one thread.
 struct tscm_local_group {
     int world = 0, device = 0, refs = 0;
+    bool dead = false;                  // the members' states diverged (rank-divergence guard): like an IPC / RCCL communicator after a failure
     hipStream_t stream = nullptr;
     double **d_ptrs = nullptr;           // [world] device array of the members' exchange buffers (rewritten per exchange)
 };
@@ -124,6 +125,13 @@ struct tscm_solver {
     DevProblem P{};
     DevState S{};
     std::vector<void *> allocs;
+    char *arena = nullptr;              // the block dev_alloc is carving pieces from, and how much of it is taken
+    size_t arena_used = 0;
+    // where tscm_solver_create's wall time went, seconds (tscm_solver_create_timing): [0] runtime_init -- device selection, stream,
+    // device properties: the first call of a process pays HIP's initialisation here; [1] host_layout -- view / board orders, chunk
+    // tables, Schur work lists; [2] gather -- the observations into device view order on the host; [3] h2d -- device allocations and
+    // uploads; [4] kernel_setup -- occupancy queries, function attributes, elimination plans, the operand map's kernel, final sync
+    double create_s[5] = { 0, 0, 0, 0, 0 };
     tscm_comm *comm = nullptr;
     // host copies of the layout
     int C = 0, B = 0, V = 0, N = 0, n_points = 0, n_pad = 0;     // B, V, N: this rank's boards / views / corners
@@ -157,6 +165,7 @@ struct tscm_solver {
     int eval_pending = 0;               // ... and an evaluation is waiting for it: 1 = reductions complete (one GPU), 2 = all-reduced H_stage (communicator); + 4: the solve's initial evaluation
     int t_epoch = 0;                    // fused launches of this solve so far (the hand-off counter is monotonic)
     int withhold = 0, withhold_next = 0; // this solve / the next one: fault injection (tscm_solver_debug_withhold_handoff)
+    int perturb_at = 0, perturb_at_next = 0, perturb_ulps = 0;   // this solve / the next one: LM iteration at which this rank's received T is moved (tscm_solver_debug_perturb_exchange)
     int n_reruns = 0;                   // solves that were run again on separate launches after a late hand-off
     bool no_rerun = false, no_rerun_next = false;      // fault injection: the late hand-off of this / the next solve stays an error
     tscm_comm *comm_reg = nullptr;      // what tscm_solver_set_comm registered; `comm` is what the current solve uses
@@ -186,13 +195,30 @@ struct tscm_solver {
     double t_ms[3] = { 0.0, 0.0, 0.0 };
 };
 
+// Device memory of a solver comes from a few large blocks (round 6: some ninety hipMalloc / hipFree pairs per solver were a
+// measurable part of what one call of the drop-in costs: tscm_solver_create_timing).  Every piece starts on a 256-byte boundary
+// (the alignment the kernels' 16-byte loads, the 128-byte hand-off lines and hipMalloc itself gave); a piece larger than half a
+// block gets an allocation of its own.
+constexpr size_t kArenaBlock = (size_t)32 << 20;
 template <typename T>
 static int dev_alloc(tscm_solver *s, T **p, size_t n)
 {
-    void *q = nullptr;
-    HIP_TRY(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
-    s->allocs.push_back(q);
-    *p = static_cast<T *>(q);
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes > kArenaBlock / 2) {
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, bytes));
+        s->allocs.push_back(q);
+        *p = static_cast<T *>(q);
+        return 0;
+    }
+    if (!s->arena || s->arena_used + bytes > kArenaBlock) {
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, kArenaBlock));
+        s->allocs.push_back(q);
+        s->arena = static_cast<char *>(q); s->arena_used = 0;
+    }
+    *p = reinterpret_cast<T *>(s->arena + s->arena_used);
+    s->arena_used += bytes;
     return 0;
 }
 
@@ -302,6 +328,9 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     *out = nullptr;
     if (int rc = validate(p)) return rc;
     if (world < 1 || rank < 0 || rank >= world) return fail(TSCM_E_INVALID, "rank / world out of range");
+    double t_mark = wall();
+    double lap_s[5] = { 0, 0, 0, 0, 0 };
+    auto lap = [&](int k) { const double t = wall(); lap_s[k] += t - t_mark; t_mark = t; };      // create_s: see tscm_solver
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TSCM_E_NO_DEVICE, "no HIP device available (the TSCM solver has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "device index out of range");
@@ -327,6 +356,9 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     s->own_stream = s->stream;
     const int C = s->C, B = s->B;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    lap(0);
 
     // ---- whole-problem facts (identical on every rank) -------------------------------------------
     std::vector<unsigned char> cam_const(C, 0), cam_active(C, 0);
@@ -410,12 +442,14 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         return fail(TSCM_E_UNSUPPORTED, "problem too large for 32-bit buffer offsets (more than 3.7 M views or 536 M corners on one GPU)");
     s->N = (int)N;
     s->h_view_obs = view_obs; s->h_view_count = view_count; s->h_view_cam = view_cam; s->h_view_board = view_board;
+    lap(1);
     std::vector<double> u((size_t)N), w((size_t)N);
     for (int i = 0; i < V; ++i) {
         const int v = order[i];
         std::memcpy(u.data() + view_obs[i], p->obs_u + p->view_offset[v], sizeof(double) * view_count[i]);
         std::memcpy(w.data() + view_obs[i], p->obs_v + p->view_offset[v], sizeof(double) * view_count[i]);
     }
+    lap(2);
 
     // ---- chunks of views (one wave each), never straddling a camera ----------------------------
     // one round of resident waves: LDS admits floor(160 KiB / lds_eval) single-wave workgroups per CU
@@ -443,8 +477,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
 #else
     const int waves_per_cu = 4 * std::max(1, std::min(4, wgs_per_cu));
 #endif
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    lap(4);
     const int target_chunks = std::max(64, prop.multiProcessorCount * waves_per_cu - 4 * C);
     const int per_chunk = std::max(1, (V + target_chunks - 1) / target_chunks);
     std::vector<int> chunk_vb, chunk_ve, chunk_cam, cam_chunk_ptr(C + 1, 0);
@@ -509,6 +542,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         // get equal numbers of workgroups: two per CU on big problems (a multiple of the CU count), never more than
         // kChunkBoards boards each, at least 16 (four waves of one group of four).
         const int target_bchunks = 2 * std::max(1, prop.multiProcessorCount);
+        lap(1);
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[1], reinterpret_cast<const void *>(k_schur_gram<1>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[2], reinterpret_cast<const void *>(k_schur_gram<2>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[3], reinterpret_cast<const void *>(k_schur_gram<3>), 256, 0));
@@ -516,6 +550,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[2], reinterpret_cast<const void *>(k_schur_gram<2, true>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[3], reinterpret_cast<const void *>(k_schur_gram<3, true>), 256, 0));
         for (int nv = 1; nv <= 3; ++nv) { s->schur_resident[nv] *= prop.multiProcessorCount; s->schur_resident_ride[nv] *= prop.multiProcessorCount; }
+        lap(4);
         const int per_bchunk = std::min<int>(kChunkBoards, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
         size_t i = 0;
         while (i < order_b.size()) {
@@ -574,6 +609,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     for (auto &pc : pchunks) { pc_begin.push_back(pc.begin); pc_end.push_back(pc.end); pc_tile.push_back(next_tile[pc.bid]++); }
     const size_t n_pairs = pair_i.size();
 
+    lap(1);
     // ---- upload --------------------------------------------------------------------------------
     DevProblem &P = s->P;
     DevState &S = s->S;
@@ -713,7 +749,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(s, &S.cconst[k], (size_t)kCStride * C))) return rc;
     if ((rc = dev_alloc(s, &S.campart, 512 * (size_t)(P.n_chunks / 4)))) return rc;
     if ((rc = dev_alloc(s, &S.campart2, 512 * (size_t)C))) return rc;
-    if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal + world))) return rc;
+    if ((rc = dev_alloc(s, &S.H_stage, 256 * (size_t)C + kScal + 2 * (size_t)world))) return rc;
     if ((rc = dev_alloc(s, &S.s_b, 6 * (size_t)B))) return rc;
     if ((rc = dev_alloc(s, &S.s_c, (size_t)s->n_pad))) return rc;
     if ((rc = dev_alloc(s, &S.fac, (size_t)kFac * B))) return rc;
@@ -739,13 +775,14 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     HIP_TRY(hipMemset(S.stats_count, 0, 256)); HIP_TRY(hipMemset(S.stats_flag, 0, 256));
     HIP_TRY(hipMemset(S.ctl_pub, 0, sizeof(CtlPub)));
     HIP_TRY(hipMemset(S.T, 0, sizeof(double) * 256 * (size_t)n_bids));
-    HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal + world)));
+    HIP_TRY(hipMemset(S.H_stage, 0, sizeof(double) * (256 * (size_t)C + kScal + 2 * (size_t)world)));
     HIP_TRY(hipMemset(S.campart2, 0, sizeof(double) * 512 * (size_t)C));
     HIP_TRY(hipMemset(S.ctrl, 0, sizeof(Ctrl)));
     HIP_TRY(hipMemset(S.ctrl_snap, 0, sizeof(CtrlHead)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctrl), sizeof(Ctrl)));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_h_ctrl), s->h_ctrl, 0));
 
+    lap(3);
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, g4.ks);
     s->lds_eval4 = lds_eval4; s->eval4 = eval4; s->eval32 = f32_kernel(g4.ks, g4.passes > 1);
@@ -823,7 +860,17 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     }
     if (s->lds_eval > 160 * 1024) return fail(TSCM_E_UNSUPPORTED, "board has too many corners for the LDS board-point tile");
     HIP_TRY(hipDeviceSynchronize());
+    lap(4);
+    for (int k = 0; k < 5; ++k) s->create_s[k] = lap_s[k];
     *out = sp.release();
+    return 0;
+}
+
+// where the wall time of this solver's tscm_solver_create went: out[0..4] = runtime_init, host_layout, gather, h2d, kernel_setup (seconds)
+extern "C" int tscm_solver_create_timing(const tscm_solver *s, double out[5])
+{
+    if (!s || !out) return fail(TSCM_E_INVALID, "NULL argument");
+    for (int k = 0; k < 5; ++k) out[k] = s->create_s[k];
     return 0;
 }
 
@@ -847,6 +894,25 @@ extern "C" int tscm_solver_debug_withhold_handoff(tscm_solver *s, int on)
     s->withhold_next = on == 3 ? 2 : on ? 1 : 0;      // (3: a reduction block riding in the Schur-complement launch, not a producer of the tiles)
     s->no_rerun_next = on == 2;          // 2: ... and the solve is NOT run again on separate launches (the error path itself)
     return 0;
+}
+
+// Fault injection for the rank-divergence guard: in the NEXT solve of this solver (a rank of a communicator), the copy of the
+// Schur-complement tiles T this rank RECEIVES from the all-reduce of LM iteration `iteration` (1-based) is moved by `ulps` units
+// in the last place in the (fx, fx) entry of its first tile (a free column of every rig; if that is zero, the first non-zero
+// entry) -- what a collective that does not hand every rank the same bits would do.
+extern "C" int tscm_solver_debug_perturb_exchange(tscm_solver *s, int iteration, int ulps)
+{
+    if (!s) return fail(TSCM_E_INVALID, "solver is NULL");
+    if (iteration < 0 || ulps < 0) return fail(TSCM_E_INVALID, "iteration and ulps must not be negative");
+    s->perturb_at_next = iteration; s->perturb_ulps = ulps;
+    return 0;
+}
+__global__ void k_debug_perturb(double *buf, size_t n, int ulps)
+{
+    const size_t fxfx = 6 * 16 + 6;          // F index 6 = fx (tscm_kernels.h)
+    if (fxfx < n && buf[fxfx] != 0.0) { buf[fxfx] = __longlong_as_double(__double_as_longlong(buf[fxfx]) + ulps); return; }
+    for (size_t i = 0; i < n; ++i)
+        if (buf[i] != 0.0) { buf[i] = __longlong_as_double(__double_as_longlong(buf[i]) + ulps); return; }
 }
 
 extern "C" int tscm_solver_reruns(const tscm_solver *s)
@@ -978,7 +1044,8 @@ extern "C" int tscm_solver_exchange_time(tscm_solver *s, int *n_T, double *ms_T,
 // loop in their own processes) or all ranks of a LOCAL group (one process, one device, one stream, lock step).
 // Per iteration the ranks exchange exactly two buffers, each with a sum all-reduce:
 //   T        n_bids * 256 doubles   the Schur complement tiles, after k_T_reduce
-//   H_stage  256 C + kScal + world  camera tiles, cost, model-cost / norm partials, failure flag, per-rank max slots
+//   H_stage  256 C + kScal + 2 world  camera tiles, cost, model-cost / norm partials, failure flag, per-rank max slots, per-rank
+//                                     decision words (rank-divergence guard: decision_word, tscm_kernels.h)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_xchg_sum(double *const *bufs, int world, size_t n)
 {
@@ -1066,7 +1133,7 @@ static int exchange(LmRun &run, bool t_buffer)
 {
     tscm_solver *s0 = run.m[0];
     if (!s0->comm) return 0;
-    const size_t n = t_buffer ? 256 * (size_t)s0->P.n_bids : 256 * (size_t)s0->P.C + kScal + s0->P.world;
+    const size_t n = t_buffer ? 256 * (size_t)s0->P.n_bids : 256 * (size_t)s0->P.C + kScal + 2 * (size_t)s0->P.world;
     if (n == 0) return 0;
     hipEvent_t e1 = nullptr;
     if (s0->comm->group) {
@@ -1127,7 +1194,7 @@ static int enqueue_eval(LmRun &run, int cand, int init, int have_backsub, bool h
 // all-reduce of T sits between the two
 static bool fused_reduce(const tscm_solver *s) { return s->fuse_reduce && s->solve_variant <= 1 && !s->comm && s->P.n_bids > 0 && s->P.n_bids <= kSmallBids; }
 
-static int enqueue_iteration(LmRun &run)
+static int enqueue_iteration(LmRun &run, int iteration)
 {
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
@@ -1150,6 +1217,8 @@ static int enqueue_iteration(LmRun &run)
         if (P.n_bids && !fused_reduce(s)) hipLaunchKernelGGL(k_T_reduce, dim3(P.n_bids * (256 / kTEntries)), dim3(kTEntries * kTSlices), 0, s->stream, P, S);
     }
     if (int rc = exchange(run, /*t_buffer=*/true)) return rc;
+    for (tscm_solver *s : run.m)          // (tests only: tscm_solver_debug_perturb_exchange)
+        if (s->perturb_at == iteration && s->comm && s->P.n_bids) hipLaunchKernelGGL(k_debug_perturb, dim3(1), dim3(1), 0, s->stream, s->S.T, 256 * (size_t)s->P.n_bids, s->perturb_ulps);
     for (tscm_solver *s : run.m) {
         const DevProblem &P = s->P;
         DevState &S = s->S;
@@ -1209,6 +1278,7 @@ static const char *reason_message(int r)
     case kParamTol: return "Parameter tolerance reached.";
     case kFuncTol: return "Function tolerance reached.";
     case kInvalidSteps: return "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps.";
+    case kRanksDisagree: return "The ranks of the communicator disagree about the state of the minimizer.";
     default: return "";
     }
 }
@@ -1274,8 +1344,8 @@ static int run_lm(LmRun &run, const tscm_options *opt_in, tscm_summary *sums, in
         const std::string first = g_err;
         bool late2 = false;
         rc = run_lm_inner(run, &o2, sums, reset, /*rerun=*/true, &late2);
-        if (rc == 0) g_err = "note: " + first + "; the solve was run again on separate launches and completed";
-        ++run.m[0]->n_reruns;
+        if (rc == 0) { g_err = "note: " + first + "; the solve was run again on separate launches and completed"; ++run.m[0]->n_reruns; }
+        else g_err = "re-run after [" + first + "] failed: " + g_err;          // (tscm_solver_reruns counts completed re-runs only)
     }
     tscm_comm *c = run.m[0]->comm;
     if (rc != 0 && rc != TSCM_E_INVALID && c && c->ipc && c->world > 1) c->ipc->dead = true;     // (its exchange counter may be behind the peers' now)
@@ -1330,6 +1400,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
             s->stats_epoch = 0;
         }
         s->withhold = s->withhold_next; s->withhold_next = 0;
+        s->perturb_at = s->perturb_at_next; s->perturb_at_next = 0;
         if (!rerun) { s->no_rerun = s->no_rerun_next; s->no_rerun_next = false; }
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
         s->nd = (opt.exec_flags & TSCM_EXEC_DENSE_REDUCED_ORDER) ? 1 : 0;
@@ -1338,6 +1409,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     }
     if (s0->comm && !s0->comm->group && !s0->comm->ipc && !s0->comm->comm) return fail(TSCM_E_RCCL, "the communicator was aborted by an earlier failure");
     if (s0->comm && s0->comm->ipc && s0->comm->ipc->dead) return fail(TSCM_E_PEER, "the IPC communicator is unusable after an earlier failure (a peer that did not arrive, or a failed solve)");
+    if (s0->comm && s0->comm->group && s0->comm->group->dead) return fail(TSCM_E_PEER, "the local group is unusable after its ranks disagreed about the LM state");
     if (s0->comm && s0->comm->group) {
         // a local group runs on ONE stream: lock step by stream order, no events
         tscm_local_group *g = s0->comm->group;
@@ -1388,7 +1460,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
     const int check_every = std::max(1, opt.check_every);
     bool done = false;
     for (int it = 1; it <= opt.max_num_iterations && !done; ++it) {
-        if ((rc = enqueue_iteration(run))) return rc;
+        if ((rc = enqueue_iteration(run, it))) return rc;
         if (it % check_every == 0 && it < opt.max_num_iterations) {
             // every rank takes the same decisions from the same all-reduced bits: polling one member is enough
             HIP_TRY(hipMemcpyAsync(s0->h_ctrl, s0->S.ctrl, 64, hipMemcpyDeviceToHost, s0->stream));
@@ -1426,6 +1498,14 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         Ctrl *h = s->h_ctrl;
         tscm_summary *sum = &sums[r];
         if ((rc = collect_timing(s))) return rc;
+        if (h->fault == kFaultRanksDisagree) {
+            // the rank-divergence guard (decision_word, tscm_kernels.h): every rank stopped in the same control step
+            if (s->comm && s->comm->group) s->comm->group->dead = true;
+            char msg[256];
+            std::snprintf(msg, sizeof(msg), "the ranks of the communicator disagree about the LM state at iteration %d (rank %d of %d: an all-reduce that did not hand "
+                          "every rank the same bits, or a replicated computation that diverged); the solve was stopped on every rank", h->iteration + 1, s->rank, s->world);
+            return fail(TSCM_E_PEER, msg);
+        }
         if (h->fault) { *late_handoff = true; return fail(TSCM_E_HIP, "a device-side hand-off (Schur-complement tiles -> reduced solve) did not arrive within its time bound: the solve was stopped"); }
         if (!h->done) return fail(TSCM_E_HIP, "device LM loop did not terminate");
         sum->termination_type = h->term_type;
@@ -1800,6 +1880,8 @@ extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_do
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(TSCM_E_NO_DEVICE, "no usable HIP device");
     HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;               // (queried before anything is allocated: an early return below must not leak device memory)
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
     std::unique_ptr<tscm_comm> c(new tscm_comm);
     std::unique_ptr<tscm_ipc> x(new tscm_ipc);
     c->rank = rank; c->world = world; c->device = device;
@@ -1829,8 +1911,6 @@ extern "C" int tscm_comm_ipc_open(int rank, int world, int device, size_t max_do
     {
         // behind the HIP handle: which device the buffer lives on (PCI address: ordinals differ between processes) and its kind
         IpcIdent id{};
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
         id.pci[0] = prop.pciDomainID; id.pci[1] = prop.pciBusID; id.pci[2] = prop.pciDeviceID; id.fine = x->fine ? 1 : 0;
         std::memcpy(handle + sizeof(h), &id, sizeof(id));
     }
