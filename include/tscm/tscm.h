@@ -226,6 +226,11 @@ int tscm_solver_set_comm(tscm_solver *s, tscm_comm *comm);   /* frame-sharded mu
  * (occupancy queries, function attributes, elimination plans, final synchronisation).  What one call of the reference's
  * MultiCalib::calibrate() spends before ceres::Solve: the problem build of multi_calib.cpp:157-207. */
 int tscm_solver_create_timing(const tscm_solver *s, double out[5]);
+/* TESTS ONLY (host code, no GPU needed): the device orders tscm_solver_create_sharded derives for rank `rank` of `world` --
+ * *n_views = its views with corners, dev2orig[n_views] = the caller's view index of every device view (camera-major, a camera's
+ * views by device board), board_perm[its boards] = the caller's board (relative to *b0) that becomes device board k (boards
+ * grouped by camera-set signature, unseen boards last).  Outputs other than n_views may be NULL. */
+int tscm_debug_layout_order(const tscm_problem *p, int rank, int world, int *n_views, int *dev2orig, int *board_perm, int *b0);
 /* A hand-off between workgroups of one launch (evaluation's reductions -> control step; Schur-complement tiles -> reduced
  * solve -> back-substitution) that does not
  * come within its time bound (0.5 s: a debugger, a co-tenant, a context switch -- or a fault) stops the solve on the

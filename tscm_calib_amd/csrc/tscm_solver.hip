@@ -22,6 +22,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace tscm;
@@ -272,6 +273,19 @@ extern "C" void tscm_default_options(tscm_options *o, int mono)
     o->exec_flags = 0;
 }
 
+// stable counting sort of `items` by key(item) in [0, n_keys): the orders tscm_solver_create needs are over small integer keys
+// (camera, board, signature class), so they are O(n) passes instead of comparison sorts through lambdas (round 6: the layout of
+// config 5's 160,000 views took 8.8 ms of every tscm_solve_multi call)
+template <typename K>
+static void counting_sort(std::vector<int> &items, int n_keys, K key)
+{
+    std::vector<int> start((size_t)n_keys + 1, 0), out(items.size());
+    for (int x : items) start[(size_t)key(x) + 1]++;
+    for (int k = 0; k < n_keys; ++k) start[k + 1] += start[k];
+    for (int x : items) out[start[key(x)]++] = x;
+    items.swap(out);
+}
+
 static int validate(const tscm_problem *p)
 {
     if (!p) return fail(TSCM_E_INVALID, "problem is NULL");
@@ -316,6 +330,104 @@ static void shard_owner(const tscm_problem *p, int world, std::vector<int> &owne
         owner[b] = std::min(r, world - 1);
         before += per_board[b];
     }
+}
+
+// The device orders of a rank's views and boards (host only: no HIP call), shared by tscm_solver_create_sharded and the CPU
+// test's entry point tscm_debug_layout_order: `order` = this rank's views with corners in device order (camera-major, a camera's
+// views by device board), board_perm[k] = caller's board (relative to b0) that is device board k, dev_board = its inverse.
+static int layout_orders(const tscm_problem *p, int b0, int b1, std::vector<int> &order, std::vector<int> &board_perm, std::vector<int> &dev_board)
+{
+    const int C = p->n_cameras, B = b1 - b0;
+    // ---- device view order: this rank's views with corners, sorted by (camera, board) -----------
+    order.clear();
+    for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0 && p->view_board[v] >= b0 && p->view_board[v] < b1) order.push_back(v);
+    // (camera, board) order: LSD -- stable by board, then stable by camera
+    counting_sort(order, b1 - b0, [&](int v) { return p->view_board[v] - b0; });
+    counting_sort(order, C, [&](int v) { return p->view_camera[v]; });
+    for (size_t i = 1; i < order.size(); ++i)
+        if (p->view_camera[order[i]] == p->view_camera[order[i - 1]] && p->view_board[order[i]] == p->view_board[order[i - 1]])
+            return fail(TSCM_E_INVALID, "two views with the same (camera, board)");
+    const int V = (int)order.size();
+    // ---- device board order: boards grouped by camera-set signature (number of views, then the cameras), unseen boards
+    // last.  The Schur kernels work on chunks of boards of ONE signature; with this numbering a chunk is a contiguous
+    // range of boards AND of record slots, so its kernels derive every address from one small descriptor instead of
+    // chasing per-board index tables (each dependent global load costs about a microsecond at the head of a kernel).
+    dev_board.assign((size_t)B, -1);            // caller's board (relative to b0) -> device board
+    {
+        std::vector<int> ptr(B + 1, 0), cams(V);
+        for (int i = 0; i < V; ++i) ptr[p->view_board[order[i]] - b0 + 1]++;
+        for (int b = 0; b < B; ++b) ptr[b + 1] += ptr[b];
+        std::vector<int> fill(B, 0);
+        for (int i = 0; i < V; ++i) { const int b = p->view_board[order[i]] - b0; cams[ptr[b] + fill[b]++] = p->view_camera[order[i]]; }   // `order` is camera-major: sorted
+        std::vector<int> perm(B);
+        std::iota(perm.begin(), perm.end(), 0);
+        auto sig_before = [&](int x, int y) {
+            const int nx = ptr[x + 1] - ptr[x], ny = ptr[y + 1] - ptr[y];
+            if ((nx == 0) != (ny == 0)) return ny == 0;           // boards without views go last
+            if (nx != ny) return nx < ny;
+            for (int k = 0; k < nx; ++k) if (cams[ptr[x] + k] != cams[ptr[y] + k]) return cams[ptr[x] + k] < cams[ptr[y] + k];
+            return false;
+        };
+        // the distinct signatures are few (camera sets that occur): one representative board each, sorted; every board finds its
+        // class through a hash of its camera list, then ONE stable counting pass -- the order a stable sort by signature gives
+        {
+            auto sig_hash = [&](int b) {
+                unsigned long long h = 1469598103934665603ull ^ (unsigned long long)(ptr[b + 1] - ptr[b]);
+                for (int k = ptr[b]; k < ptr[b + 1]; ++k) h = (h ^ (unsigned long long)(cams[k] + 1)) * 1099511628211ull;
+                return h;
+            };
+            auto same_sig = [&](int x, int y) { return !sig_before(x, y) && !sig_before(y, x); };
+            std::unordered_map<unsigned long long, std::vector<int>> by_hash;     // hash -> representatives (collisions kept apart)
+            std::vector<int> reps, rep_of(B);
+            for (int b = 0; b < B; ++b) {
+                std::vector<int> &cand = by_hash[sig_hash(b)];
+                int r = -1;
+                for (int c : cand) if (same_sig(reps[c], b)) { r = c; break; }
+                if (r < 0) { r = (int)reps.size(); reps.push_back(b); cand.push_back(r); }
+                rep_of[b] = r;
+            }
+            std::vector<int> cls(reps.size());
+            std::iota(cls.begin(), cls.end(), 0);
+            std::sort(cls.begin(), cls.end(), [&](int x, int y) { return sig_before(reps[x], reps[y]); });
+            std::vector<int> rank_of(reps.size());
+            for (size_t k = 0; k < cls.size(); ++k) rank_of[cls[k]] = (int)k;
+            counting_sort(perm, (int)reps.size(), [&](int b) { return rank_of[rep_of[b]]; });
+        }
+        board_perm = perm;
+        for (int i = 0; i < B; ++i) dev_board[perm[i]] = i;
+    }
+    // views of one camera sorted by device board
+    counting_sort(order, std::max(B, 1), [&](int v) { return dev_board[p->view_board[v] - b0]; });
+    counting_sort(order, C, [&](int v) { return p->view_camera[v]; });
+    return 0;
+}
+
+extern "C" int tscm_debug_layout_order(const tscm_problem *p, int rank, int world, int *n_views_out, int *dev2orig, int *board_perm_out, int *b0_out)
+{
+    if (int rc = validate(p)) return rc;
+    if (world < 1 || rank < 0 || rank >= world || !n_views_out) return fail(TSCM_E_INVALID, "bad arguments");
+    std::vector<int> owner;
+    shard_owner(p, world, owner);
+    int b0 = 0, b1 = 0;
+    while (b0 < p->n_boards && owner[b0] < rank) ++b0;
+    b1 = b0;
+    while (b1 < p->n_boards && owner[b1] == rank) ++b1;
+    std::vector<int> order, perm, dev_board;
+    if (int rc = layout_orders(p, b0, b1, order, perm, dev_board)) return rc;
+    *n_views_out = (int)order.size();
+    if (b0_out) *b0_out = b0;
+    if (dev2orig) std::copy(order.begin(), order.end(), dev2orig);
+    if (board_perm_out) std::copy(perm.begin(), perm.end(), board_perm_out);
+    return 0;
+}
+
+// the caller's observation arrays (device copy, as they were) -> device view order: one wave per view
+__global__ __launch_bounds__(256) void k_gather_obs(const double *raw_u, const double *raw_v, const int *src_off, const int *dst_off, const int *count, int V, double *u, double *v)
+{
+    const int view = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (view >= V) return;
+    const int so = src_off[view], d0 = dst_off[view], n = count[view];
+    for (int j = lane; j < n; j += 64) { u[d0 + j] = raw_u[so + j]; v[d0 + j] = raw_v[so + j]; }
 }
 
 // Every rank is handed the WHOLE problem description (the view tables are small) and keeps the observations, records
@@ -388,45 +500,10 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     }
     s->N_total = N_total;
 
-    // ---- device view order: this rank's views with corners, sorted by (camera, board) -----------
-    std::vector<int> order;
-    for (int v = 0; v < p->n_views; ++v) if (p->view_count[v] > 0 && p->view_board[v] >= b0 && p->view_board[v] < b1) order.push_back(v);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (p->view_camera[a] != p->view_camera[b]) return p->view_camera[a] < p->view_camera[b];
-        return p->view_board[a] < p->view_board[b];
-    });
-    for (size_t i = 1; i < order.size(); ++i)
-        if (p->view_camera[order[i]] == p->view_camera[order[i - 1]] && p->view_board[order[i]] == p->view_board[order[i - 1]])
-            return fail(TSCM_E_INVALID, "two views with the same (camera, board)");
+    // ---- device view order and device board order (layout_orders) ----------------------------------
+    std::vector<int> order, dev_board;
+    if (int rc0 = layout_orders(p, b0, b1, order, s->board_perm, dev_board)) return rc0;
     const int V = (int)order.size();
-    // ---- device board order: boards grouped by camera-set signature (number of views, then the cameras), unseen boards
-    // last.  The Schur kernels work on chunks of boards of ONE signature; with this numbering a chunk is a contiguous
-    // range of boards AND of record slots, so its kernels derive every address from one small descriptor instead of
-    // chasing per-board index tables (each dependent global load costs about a microsecond at the head of a kernel).
-    std::vector<int> dev_board(B, -1);          // caller's board (relative to b0) -> device board
-    {
-        std::vector<int> ptr(B + 1, 0), cams(V);
-        for (int i = 0; i < V; ++i) ptr[p->view_board[order[i]] - b0 + 1]++;
-        for (int b = 0; b < B; ++b) ptr[b + 1] += ptr[b];
-        std::vector<int> fill(B, 0);
-        for (int i = 0; i < V; ++i) { const int b = p->view_board[order[i]] - b0; cams[ptr[b] + fill[b]++] = p->view_camera[order[i]]; }   // `order` is camera-major: sorted
-        std::vector<int> perm(B);
-        std::iota(perm.begin(), perm.end(), 0);
-        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
-            const int nx = ptr[x + 1] - ptr[x], ny = ptr[y + 1] - ptr[y];
-            if ((nx == 0) != (ny == 0)) return ny == 0;           // boards without views go last
-            if (nx != ny) return nx < ny;
-            for (int k = 0; k < nx; ++k) if (cams[ptr[x] + k] != cams[ptr[y] + k]) return cams[ptr[x] + k] < cams[ptr[y] + k];
-            return false;
-        });
-        s->board_perm = perm;
-        for (int i = 0; i < B; ++i) dev_board[perm[i]] = i;
-    }
-    // views of one camera sorted by device board
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (p->view_camera[a] != p->view_camera[b]) return p->view_camera[a] < p->view_camera[b];
-        return dev_board[p->view_board[a] - b0] < dev_board[p->view_board[b] - b0];
-    });
     s->V = V; s->dev2orig = order;
     std::vector<int> view_cam(V), view_board(V), view_obs(V), view_count(V);
     long N = 0;
@@ -443,11 +520,25 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     s->N = (int)N;
     s->h_view_obs = view_obs; s->h_view_count = view_count; s->h_view_cam = view_cam; s->h_view_board = view_board;
     lap(1);
-    std::vector<double> u((size_t)N), w((size_t)N);
+    // The observations in device view order.  One GPU: the caller's arrays go to the device AS THEY ARE (one pageable copy each, no
+    // host pass over them) and a kernel moves every view's corners into place (k_gather_obs) -- the host gather was 3 ms of a
+    // 9 ms create at config 4 and 35 of 62 at config 5.  A rank of a sharded solver keeps only its own boards' views: it gathers
+    // those on the host and uploads its share.  (Also the fallback for a caller whose view_offset table leaves the arrays sparse.)
+    long raw_lo = 0, raw_hi = 0;
     for (int i = 0; i < V; ++i) {
-        const int v = order[i];
-        std::memcpy(u.data() + view_obs[i], p->obs_u + p->view_offset[v], sizeof(double) * view_count[i]);
-        std::memcpy(w.data() + view_obs[i], p->obs_v + p->view_offset[v], sizeof(double) * view_count[i]);
+        const long o = p->view_offset[order[i]];
+        if (i == 0 || o < raw_lo) raw_lo = o;
+        if (i == 0 || o + view_count[i] > raw_hi) raw_hi = o + view_count[i];
+    }
+    const bool device_gather = world == 1 && V > 0 && raw_hi - raw_lo <= 2 * N && (unsigned long long)(raw_hi - raw_lo) * sizeof(double) < 0xffffe000ull;
+    std::vector<double> u, w;
+    if (!device_gather) {
+        u.resize((size_t)N); w.resize((size_t)N);
+        for (int i = 0; i < V; ++i) {
+            const int v = order[i];
+            std::memcpy(u.data() + view_obs[i], p->obs_u + p->view_offset[v], sizeof(double) * view_count[i]);
+            std::memcpy(w.data() + view_obs[i], p->obs_v + p->view_offset[v], sizeof(double) * view_count[i]);
+        }
     }
     lap(2);
 
@@ -524,7 +615,8 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         }
         return false;
     };
-    std::stable_sort(order_b.begin(), order_b.end(), sig_less);
+    // (device boards ARE numbered in signature order, unseen boards last: order_b is sorted as it stands)
+    if (!std::is_sorted(order_b.begin(), order_b.end(), sig_less)) std::stable_sort(order_b.begin(), order_b.end(), sig_less);
     // Every partial tile belongs to one camera-pair block; tiles of a block are numbered contiguously
     // (two passes: count, then assign) so that k_T_reduce streams them without indirection.
     struct ChunkT { int begin, end, nv, bid[6]; };
@@ -625,8 +717,29 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     if ((rc = dev_upload(s, &P.view_board, view_board))) return rc;
     if ((rc = dev_upload(s, &P.view_obs, view_obs))) return rc;
     if ((rc = dev_upload(s, &P.view_count, view_count))) return rc;
-    if ((rc = dev_upload(s, &P.obs_u, u))) return rc;
-    if ((rc = dev_upload(s, &P.obs_v, w))) return rc;
+    if (!device_gather) {
+        if ((rc = dev_upload(s, &P.obs_u, u))) return rc;
+        if ((rc = dev_upload(s, &P.obs_v, w))) return rc;
+    } else {
+        double *du = nullptr, *dv = nullptr, *raw = nullptr;
+        int *src = nullptr;
+        if ((rc = dev_alloc(s, &du, (size_t)N))) return rc;
+        if ((rc = dev_alloc(s, &dv, (size_t)N))) return rc;
+        const size_t n_raw = (size_t)(raw_hi - raw_lo);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&raw), 2 * n_raw * sizeof(double)));          // (temporary: freed below)
+        std::unique_ptr<double, void (*)(double *)> raw_guard(raw, [](double *q) { (void)hipFree(q); });
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&src), (size_t)V * sizeof(int)));
+        std::unique_ptr<int, void (*)(int *)> src_guard(src, [](int *q) { (void)hipFree(q); });
+        std::vector<int> src_off((size_t)V);
+        for (int i = 0; i < V; ++i) src_off[i] = (int)(p->view_offset[order[i]] - raw_lo);
+        HIP_TRY(hipMemcpy(src, src_off.data(), (size_t)V * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(raw, p->obs_u + raw_lo, n_raw * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(raw + n_raw, p->obs_v + raw_lo, n_raw * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_gather_obs, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, 0, raw, raw + n_raw, src, P.view_obs, P.view_count, V, du, dv);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        P.obs_u = du; P.obs_v = dv;
+    }
     if ((rc = dev_upload(s, &P.chunk_vb, chunk_vb))) return rc;
     if ((rc = dev_upload(s, &P.chunk_ve, chunk_ve))) return rc;
     if ((rc = dev_upload(s, &P.chunk_cam, chunk_cam))) return rc;
