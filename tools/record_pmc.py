@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-ROUND = int(os.environ.get("TSCM_ROUND", "5"))       # which round's evidence this is (keys `sq_round<N>`, `..._all_kernels_round<N>`)
+ROUND = int(os.environ.get("TSCM_ROUND", "6"))       # which round's evidence this is (keys `sq_round<N>`, `..._all_kernels_round<N>`)
 
 
 def per_kernel(d, counter):
@@ -51,6 +51,12 @@ def main():
                       "read_bytes_corrected": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
     path = os.path.join(ROOT, "profiles", "pmc_eval_gram.json")
     doc = json.load(open(path))
+    # records of past rounds are append-only: a block of THIS round may be re-recorded, one of another round never
+    for key in (f"config{config}_all_kernels_round{ROUND}",):
+        if key in doc and doc[key].get("round", ROUND) != ROUND:
+            raise SystemExit(f"{key} belongs to another round: refusing to overwrite it (set TSCM_ROUND)")
+    if sq_dirs and f"sq_round{ROUND}" in doc.get(f"config{config}", {}) and doc[f"config{config}"][f"sq_round{ROUND}"].get("round", ROUND) != ROUND:
+        raise SystemExit(f"config{config}.sq_round{ROUND} belongs to another round: refusing to overwrite it")
     ev = next(v for k, v in kernels.items() if k.startswith("k_eval_gram"))
     n_corners = {4: 2160000, 5: 8640000}.get(config)
     keep = {k: v for k, v in doc.get(f"config{config}", {}).items() if k.startswith("sq")}       # SQ counter blocks are recorded separately
@@ -73,9 +79,10 @@ def main():
                     tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
             for c in tot:
                 sq[c] = tot[c] / n[c]
+        sq["round"] = ROUND
         sq["passes"] = "tools/pmc.sh, one rocprofv3 --pmc pass per directory: " + ", ".join(os.path.basename(d) for d in sq_dirs) + "; per k_eval_gram dispatch"
         doc[f"config{config}"][f"sq_round{ROUND}"] = sq
-    doc[f"config{config}_all_kernels_round{ROUND}"] = {"kernel_src_sha": sha, "per_launch": kernels}
+    doc[f"config{config}_all_kernels_round{ROUND}"] = {"kernel_src_sha": sha, "round": ROUND, "per_launch": kernels}
     json.dump(doc, open(path, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:34s} read {v['read_bytes_corrected'] / 1e6:7.2f} MB  write {v['write_bytes'] / 1e6:7.2f} MB")

@@ -16,6 +16,11 @@ print('$f: steps %d %.0f it/s  %.1f us/step  %s %.2f us (%d timed) frac %.3f ite
 if [ "$part" = "1" ]; then
   bash tools/prof.sh $t > $o/${t}_prof.txt 2>&1
   bash tools/prof.sh ${t}_c5 --config 5 > $o/${t}_c5_prof.txt 2>&1
+  # the performance regression guard next to the bit guard: kernel medians of configs 4 and 5 against tools/regress_perf.expected (3 % band)
+  python3 tools/regress_perf.py $o/${t}_kernel_medians.csv $o/${t}_c5_kernel_medians.csv > $o/${t}_regress_perf.txt 2>&1 || echo "ROUND-END PASS FAILED: regress_perf (see $o/${t}_regress_perf.txt)"
+  cat $o/${t}_regress_perf.txt
+  python3 tools/regress_bits.py --check > $o/${t}_regress_bits.txt 2>&1 || echo "ROUND-END PASS FAILED: regress_bits"
+  tail -3 $o/${t}_regress_bits.txt
   bash tools/prof.sh ${t}_f32 --jacobian-fp32 > $o/${t}_f32_prof.txt 2>&1
   bash tools/prof.sh ${t}_c5_f32 --config 5 --jacobian-fp32 > $o/${t}_c5_f32_prof.txt 2>&1
   bash tools/pmc.sh ${t}_fetch FETCH_SIZE > $o/pmc_${t}_fetch.txt 2>&1
@@ -62,7 +67,7 @@ else
   cp $o/${t}_shards8_config5_kernel_medians.csv $p/${tag}_shards8_config5_kernel_medians.csv
   cp $o/${t}_shards_config4_bench.json $p/${tag}_shards_config4_bench.json
   cp $o/${t}_shards_config5_bench.json $p/${tag}_shards_config5_bench.json
-  for f in kernel_timeline c5_kernel_timeline:config5_kernel_timeline wave_timeline phase_timeline ipc_check; do [ -f $o/${t}_${f%%:*}.txt ] && cp $o/${t}_${f%%:*}.txt $p/${tag}_${f##*:}.txt; done
+  for f in kernel_timeline c5_kernel_timeline:config5_kernel_timeline wave_timeline phase_timeline ipc_check regress_perf regress_bits; do [ -f $o/${t}_${f%%:*}.txt ] && cp $o/${t}_${f%%:*}.txt $p/${tag}_${f##*:}.txt; done
   for f in bench:final_bench bench_driver:final_bench_driver_command bench_100:final_bench_100 bench_100_f32:fp32_config4_bench c5_bench:config5_bench c5_bench_f32:fp32_config5_bench c1_bench:config1_bench c2_bench:config2_bench c3_bench:config3_bench; do
     [ -f $o/${t}_${f%%:*}.json ] && grep '^{' $o/${t}_${f%%:*}.json > $p/${tag}_${f##*:}.json
   done
