@@ -130,7 +130,7 @@ typedef struct tscm_options {
 } tscm_options;
 
 /* tscm_options.exec_flags.  They select code paths for A/B runs and for tests that a one-GPU box would otherwise never
- * run; none of them changes the mathematics, all but the last two give the same bits.  Bits outside TSCM_EXEC_ALL are
+ * run; none of them changes the mathematics, all but _DENSE_ / _GRAPH_REDUCED_ORDER give the same bits.  Bits outside TSCM_EXEC_ALL are
  * refused with TSCM_E_INVALID (a caller built against an options struct without the field passes garbage here). */
 enum {
     TSCM_EXEC_SEPARATE_T_REDUCE = 1,       /* keep the Schur-complement tile reduction a launch of its own instead of   */
@@ -149,7 +149,11 @@ enum {
                                            /* dense k_solve_reduced (which is faster there: tests and A/B runs)               */
     TSCM_EXEC_SEPARATE_STATS = 128,        /* keep the reductions behind a candidate's evaluation (k_reduce_stats) a launch of  */
                                            /* their own instead of the first workgroups of the next Schur-complement launch    */
-    TSCM_EXEC_ALL = 255
+    TSCM_EXEC_MFMA_REDUCED_SOLVE = 256,    /* rigs of up to 4 cameras: the reduced camera system factored by ONE wave with rank-4  */
+                                           /* updates on the matrix cores (six 16 x 16 accumulator tiles) instead of 256 threads on  */
+                                           /* 4 x 4 register tiles with a barrier per panel.  Round 6: built, the SAME bits, 1 us     */
+                                           /* slower at config 4 -- an experiment switch, not the default (HISTORY A.7)              */
+    TSCM_EXEC_ALL = 511
 };
 
 /* ceres::IterationSummary subset */

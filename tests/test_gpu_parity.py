@@ -481,7 +481,7 @@ def test_unknown_exec_flags_are_refused(hip_device):
     p = H.small_rig(4, 4, seed=1).normalised()
     with api.Solver(p) as s:
         with pytest.raises(TscmError) as e:
-            s.solve(exec_flags=0x100)
+            s.solve(exec_flags=0x200)          # (0x100 is TSCM_EXEC_MFMA_REDUCED_SOLVE since round 6)
         assert e.value.code == -1
         s.solve()
 
@@ -595,6 +595,23 @@ def test_gram4_two_passes_on_the_reference_board_at_size(hip_device):
     pg, po, gs, os_ = _solve_both(p)
     _cmp_trace(gs, os_)
     assert max(H.param_rel_err(pg, po).values()) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["config1", "config3", "rig2", "rig3", "mixed"])
+def test_reduced_solve_on_one_wave_with_mfma_updates_gives_the_same_bits(hip_device, case):
+    """TSCM_EXEC_MFMA_REDUCED_SOLVE (round 6, an experiment switch): the reduced camera system of a rig of up to four cameras as six
+    16 x 16 accumulator tiles of ONE wave, a panel of 4 columns = the K of v_mfma_f64_16x16x4, the right-hand side as row 47.  The
+    instruction accumulates its four products in order, the panel solve and the 4 x 4 factor perform the operations of the
+    256-thread kernel in the same order: the whole solve is bit-identical (1 to 4 cameras: 2 to 12 panels, every tile column)."""
+    p = {"config1": lambda: synth.make_config(1), "config3": lambda: synth.make_config(3), "rig2": lambda: H.small_rig(2, 10, 4),
+         "rig3": lambda: H.small_rig(3, 10, 4), "mixed": lambda: H.mixed_visibility_rig(seed=5, n_frames=24)}[case]()
+    a, b = p.copy().normalised(), p.copy().normalised()
+    run = (lambda q, **kw: api.refinement(q, **kw)[1]) if p.mono else (lambda q, **kw: api.calibrate(q, **kw))
+    sa = run(a)
+    sb = run(b, exec_flags=lib.EXEC_MFMA_REDUCED_SOLVE)
+    assert sa["num_iterations"] == sb["num_iterations"] and sa["message"] == sb["message"]
+    assert sa["iterations"] == sb["iterations"]
+    assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
 @pytest.mark.parametrize("cfg", [1, 3])

@@ -1630,8 +1630,12 @@ struct RawTc {
 // scope reads S.ctrl instead of the snapshot for that reason), and the XCDs' L2s and the CUs' vector and scalar caches start a
 // launch invalidated (what k_reduce_stats wrote has always reached the next launch's plain loads that way) -- so the first touch
 // of a line from an XCD fetches what was written through, or hits the writer's own written-through copy.
+#ifndef TSCM_SCHUR_OCC
+#define TSCM_SCHUR_OCC 2        // workgroups per CU the NV <= 2 instantiation that serves grids of several rounds is compiled for.  3 (round 6, measured): the
+                                // compiler meets 168 VGPRs with 196 bytes of scratch per lane and the kernel takes 63.7 us instead of 51.9 at config 5
+#endif
 template <int NV, bool RIDE = false>
-__global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
+__global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
 {
 #ifdef TSCM_WAVE_TIMELINE
     KtlScope ktl_scope(3, ctl && !RIDE ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));      // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
@@ -1654,7 +1658,11 @@ __global__ __launch_bounds__(256, RIDE && NV <= 2 ? 2 : 1) void k_schur_gram(Dev
     // 3 x 3 block t_b x t_c of W (9 NV): the t_b x t_b block is built from those in phase 0b with each view's R_c
     constexpr int NE = 24 + 9 * NV, NJ = (NE + 15) / 16;
     // (one block, so that the control step in the head can borrow all of it: facl first, 16-byte aligned)
-    struct __attribute__((aligned(16))) Lds { double facl[kChunkBoards][kFac]; double sumE[kChunkBoards][NE]; double tiles[4][NT][256]; };
+    // (round 6: the waves' partial tiles share the space of the E sums, which are dead behind phase 0b's barrier -- 53.2 KB instead of 74.8 at NV = 2: three workgroups per CU fit)
+    struct __attribute__((aligned(16))) Lds {
+        double facl[kChunkBoards][kFac];
+        union { double sumE[kChunkBoards][NE]; double tiles[4][NT][256]; double head_rest[256 * kMaxCamLds + kScal + 8 + 512 * kMaxCamLds + 256 - kChunkBoards * kFac]; };      // (head_rest: what the control step in the head borrows beyond facl)
+    };
     __shared__ Lds lds_blk;
     double (&sumE)[kChunkBoards][NE] = lds_blk.sumE;
     double (&facl)[kChunkBoards][kFac] = lds_blk.facl;

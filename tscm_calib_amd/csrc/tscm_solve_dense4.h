@@ -6,6 +6,7 @@
 // 11.5-11.8 us for the factorisation against 10.5 us for the 12 panels here, so rigs of up to four cameras stay with this
 // kernel and k_solve_nd takes the rigs of five to eight, where the structure pays (13 phases instead of 25).
 #pragma once
+#include <type_traits>
 
 // T(i, j) for padded columns i, j of the camera side; the lower blocks are the transposed upper ones
 __device__ __forceinline__ double load_T_small(const DevProblem &P, const double *T, int i, int j)
@@ -122,7 +123,8 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64) void k_solve_map(DevProblem
 // megabytes, when they release -- and a launch with its 5 us is gone.
 // n_prod: workgroups 1 .. n_prod are the T reduction (FUSED); n_bs > 0: workgroups behind them are the back-substitution
 // of this step (backsub_body<256, true>): their loads are in flight and their registers full while the solver works
-template <int TS, int G = 16, int NPD = 64, bool FUSED = false>
+// MF (round 6): the factorisation on ONE wave with the matrix in the accumulator layout of v_mfma_f64_16x16x4 -- see "MF" below
+template <int TS, int G = 16, int NPD = 64, bool FUSED = false, bool MF = false>
 __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve_reduced(DevProblem P, DevState S, int epoch, int withhold, int n_prod, int n_bs, int with_floats)
 {
     constexpr int NT = (G * G + 63) / 64 * 64;      // whole waves; threads past G * G own no tile
@@ -256,6 +258,134 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
 #ifdef TSCM_PHASE_PROFILE
     const long long cy1 = clock64();
 #endif
+    if constexpr (MF) {
+    // ---- MF: right-looking Cholesky of the 48 x 48 system on ONE wave, rank-4 updates on the matrix cores (round 6) ----------
+    // The compact system of a rig of up to four cameras has at most 46 free columns: padded to 48 it is SIX lower 16 x 16 tiles --
+    // 48 accumulator registers of one wave in the D layout of v_mfma_f64_16x16x4_f64 (lane (col, kq), register r: row kq + 4 r).
+    // A panel is 4 columns = exactly the instruction's K, so the trailing update of a panel is one MFMA per tile that is still
+    // alive (6 | 3 | 1 by tile column: 40 for the 12 panels) instead of 64 FMAs per thread and panel behind a workgroup barrier.
+    // Per panel: the lanes that hold the panel's columns put them into LDS (12 stores); every lane takes ITS ROW of the panel
+    // and the 4 x 4 diagonal block (broadcast reads), factors the block itself -- the same 30 operations on every lane, no
+    // hand-off -- and solves its row (x = a L_kk^-T); the rows go back to LDS in row-major order, which is both the factor the
+    // back-substitution reads and, fetched as lane (row, k), the A / B operand of the update.  The right-hand side rides along as
+    // row 47 (w = L^-1 b falls out of the updates, as with the 4 x 4 tiles of rounds 1-5); columns past the last free one are
+    // identity.  No workgroup barrier inside the factorisation; the other three waves wait at the one behind it.
+        static_assert(TS == 4 && G == 16 && N >= 48, "six 16 x 16 tiles");
+        constexpr int N48 = 48;
+        for (int i = tid; i < N48 * LD; i += NT) Lm[i] = 0.0;
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < TS; ++r)
+#pragma unroll
+                for (int c = 0; c < TS; ++c)
+                    // (free rows / columns only: the padding behind them is identity by construction below, and row 47 belongs to the
+                    // right-hand side -- the last tile row's padding rows must not race with it)
+                    if ((ri != cj || c <= r) && TS * ri + r < P.n_act && TS * cj + c < P.n_act) { Lm[(TS * ri + r) * LD + TS * cj + c] = a[r][c]; Lm[(TS * cj + c) * LD + TS * ri + r] = a[r][c]; }
+        } else if (rhsrow) {
+#pragma unroll
+            for (int c = 0; c < TS; ++c) Lm[(N48 - 1) * LD + TS * cj + c] = a[0][c];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int lane = tid, col = lane & 15, kq = lane >> 4;
+            const int n_act = P.n_act;
+            auto ld_tile = [&](int I, int Jc) { d4 v; for (int r = 0; r < 4; ++r) v[r] = Lm[(16 * I + kq + 4 * r) * LD + 16 * Jc + col]; return v; };
+            d4 acc00 = ld_tile(0, 0), acc10 = ld_tile(1, 0), acc20 = ld_tile(2, 0), acc11 = ld_tile(1, 1), acc21 = ld_tile(2, 1), acc22 = ld_tile(2, 2);
+            double *Pn = Xb;                                   // [48][4]: the panel's columns, row-major
+            const int row = min(lane, N48 - 1);
+            int fail = 0;
+            auto dump = [&](const d4 &v, int I, int pc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pn[(16 * I + kq + 4 * r) * 4 + pc] = v[r];
+            };
+            auto step = [&](auto Jtag, int q) {
+                constexpr int J = decltype(Jtag)::value;
+                const int tk = 4 * J + q;                      // panel: columns 4 tk .. 4 tk + 3 = columns 4 q .. of tile column J
+                wave_lds_fence();                              // (the previous panel's reads of Pn are done)
+                if ((col >> 2) == q) {
+                    const int pc = col & 3;
+                    if constexpr (J == 0) { dump(acc00, 0, pc); dump(acc10, 1, pc); dump(acc20, 2, pc); }
+                    if constexpr (J == 1) { dump(acc11, 1, pc); dump(acc21, 2, pc); }
+                    if constexpr (J == 2) { dump(acc22, 2, pc); }
+                }
+                wave_lds_fence();
+                // my row of the panel and the diagonal block
+                const d2 a01 = *reinterpret_cast<const d2 *>(Pn + 4 * row), a23 = *reinterpret_cast<const d2 *>(Pn + 4 * row + 2);
+                double D[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const d2 u = *reinterpret_cast<const d2 *>(Pn + 4 * (4 * tk + i)), v = *reinterpret_cast<const d2 *>(Pn + 4 * (4 * tk + i) + 2);
+                    D[i][0] = u[0]; D[i][1] = u[1]; D[i][2] = v[0]; D[i][3] = v[1];
+                }
+                double l[4][4], il[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool real = 4 * tk + c < n_act;
+                    double d = D[c][c];
+#pragma unroll
+                    for (int u = 0; u < c; ++u) d -= l[c][u] * l[c][u];
+                    if (real && !(d > 0.0)) { fail = 1; d = 1.0; }
+                    if (!real) d = 1.0;
+                    const double isd = fast_rsqrt(d);
+                    l[c][c] = d * isd; il[c] = isd;
+#pragma unroll
+                    for (int r = c + 1; r < 4; ++r) {
+                        double v = D[r][c];
+#pragma unroll
+                        for (int u = 0; u < c; ++u) v -= l[r][u] * l[c][u];
+                        l[r][c] = real ? v * isd : 0.0;
+                    }
+                }
+                const double a4[4] = { a01[0], a01[1], a23[0], a23[1] };
+                double x[4];
+                const int rel = row - 4 * tk;                  // < 0: a row that is finished; 0..3: a row of the diagonal block
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double v = a4[c];
+#pragma unroll
+                    for (int u = 0; u < c; ++u) v -= x[u] * l[c][u];
+                    x[c] = (rel < 0 || (rel < 4 && c > rel)) ? 0.0 : v * il[c];
+                }
+                if (lane < N48) {
+                    *reinterpret_cast<d2 *>(Lm + row * LD + 4 * tk) = d2{ x[0], x[1] };
+                    *reinterpret_cast<d2 *>(Lm + row * LD + 4 * tk + 2) = d2{ x[2], x[3] };
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) idg[4 * tk + c] = il[c];
+                }
+                if (lane == N48 - 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) wp[4 * tk + c] = 4 * tk + c < n_act ? x[c] : 0.0;
+                }
+                wave_lds_fence();
+                // the rows as MFMA operands: lane (r, k) <- X[16 I + r][k]; the update A_IJ -= X_I X_J^T of every tile still alive
+                double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+                if constexpr (J == 0) x0 = Lm[(col) * LD + 4 * tk + kq];
+                if constexpr (J <= 1) x1 = Lm[(16 + col) * LD + 4 * tk + kq];
+                x2 = Lm[(32 + col) * LD + 4 * tk + kq];
+                if constexpr (J == 0) {
+                    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0, x0, acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, x0, acc10, 0, 0, 0);
+                    acc20 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x0, acc20, 0, 0, 0);
+                }
+                if constexpr (J <= 1) {
+                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, x1, acc11, 0, 0, 0);
+                    acc21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x1, acc21, 0, 0, 0);
+                }
+                acc22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x2, acc22, 0, 0, 0);
+            };
+            for (int tk = 0; tk < NP; ++tk) {
+                const int q = tk & 3;
+                if (tk < 4) step(std::integral_constant<int, 0>{}, q);
+                else if (tk < 8) step(std::integral_constant<int, 1>{}, q);
+                else step(std::integral_constant<int, 2>{}, q);
+            }
+            if (fail) s_fail = 1;
+        }
+        __syncthreads();
+    } else {
     // ---- factorisation: one barrier per panel, diagonal tiles factored one panel ahead ---------------------
     // State at the top of step tk: L_kk (factor of diagonal tile tk) and 1 / diag are in Lm / idg; the tiles of
     // column tk (rows below the diagonal, the rhs row among them), updated through panel tk-1, are in Ar; the
@@ -418,6 +548,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
             for (int c = 0; c < TS; ++c) Lm[(ri * TS + r) * LD + cj * TS + c] = a[r][c];
     }
     __syncthreads();
+    }   // (!MF)
     PHASE_STAMP(ts2);
 #ifdef TSCM_PHASE_PROFILE
     const long long cy2 = clock64();

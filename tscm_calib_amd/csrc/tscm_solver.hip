@@ -184,6 +184,7 @@ struct tscm_solver {
     bool graph_order = false;           // this solve: k_solve_nd also for a rig of up to 4 cameras (TSCM_EXEC_GRAPH_REDUCED_ORDER / _DENSE_REDUCED_ORDER there)
     bool f32_jacobian = false;          // this solve runs k_eval_gram_f32 (tscm_options.jacobian_fp32)
     bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
+    bool solve_tiles = true;            // this solve: k_solve_reduced<.., MF = false> (the default; TSCM_EXEC_MFMA_REDUCED_SOLVE clears it)
     size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4
     EvalKernel eval4 = nullptr, eval32 = nullptr;   // ... and its instantiation for this problem's board (g4_kernel), the fp32-Jacobian tier's (f32_kernel)
     // dominant-kernel timing
@@ -911,7 +912,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         const size_t NN = 64, TT = 4, NPD = 64;
         s->lds_dense4 = sizeof(double) * (NN * (NN + 2) + 2 * (NN / TT) * (TT * TT + 2) + 2 * NN + 3 * NPD);
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_reduced<4, 16, 64, true>), 256, std::max(s->lds_dense4, s->lds_bs)));
+        // (the riders share the launch with either solver workgroup: the smaller of the two occupancies)
+        int per_cu_tiles = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_solve_reduced<4, 16, 64, true, true>), 256, std::max(s->lds_dense4, s->lds_bs)));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_tiles, reinterpret_cast<const void *>(k_solve_reduced<4, 16, 64, true, false>), 256, std::max(s->lds_dense4, s->lds_bs)));
+        per_cu = std::min(per_cu, per_cu_tiles);
         s->dense4_resident = per_cu * prop.multiProcessorCount;
     }
     if (s->solve_variant <= 1) {
@@ -1340,10 +1345,14 @@ static int enqueue_iteration(LmRun &run, int iteration)
             // up to 4 cameras, one dense block: the same launch shape with k_solve_reduced as the solver workgroup
             const int n_prod = fused_reduce(s) ? P.n_bids * (256 / kFusedEntries) : 0;
             const int n_bs = s->fuse_backsub && s->bs_threads == 256 && S.n_bs_blocks <= s->dense4_resident - 1 - n_prod ? S.n_bs_blocks : 0;       // all of them, or none: see below
-            if (n_prod || n_bs)
-                hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
-                                   P, S, ++s->t_epoch, s->withhold == 1 ? 1 : 0, n_prod, n_bs, wf);
-            else hipLaunchKernelGGL((k_solve_reduced<4, 16, 64>), dim3(1), dim3(256), s->lds_dense4, s->stream, P, S, 0, 0, 0, 0, 0);
+            // (TSCM_EXEC_MFMA_REDUCED_SOLVE: the factorisation on one wave with MFMA rank-4 updates -- MF; same bits, measured slower)
+            if (n_prod || n_bs) {
+                if (s->solve_tiles) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true, false>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
+                                                       P, S, ++s->t_epoch, s->withhold == 1 ? 1 : 0, n_prod, n_bs, wf);
+                else hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, true, true>), dim3(1 + n_prod + n_bs), dim3(256), std::max(s->lds_dense4, n_bs ? s->lds_bs : (size_t)0), s->stream,
+                                        P, S, ++s->t_epoch, s->withhold == 1 ? 1 : 0, n_prod, n_bs, wf);
+            } else if (s->solve_tiles) hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, false, false>), dim3(1), dim3(256), s->lds_dense4, s->stream, P, S, 0, 0, 0, 0, 0);
+            else hipLaunchKernelGGL((k_solve_reduced<4, 16, 64, false, true>), dim3(1), dim3(256), s->lds_dense4, s->stream, P, S, 0, 0, 0, 0, 0);
             if (!n_bs && S.n_bs_blocks && s->bs_threads == 128) hipLaunchKernelGGL(k_backsub_prep<128>, dim3(S.n_bs_blocks), dim3(128), s->lds_bs, s->stream, P, S, wf);
             if (!n_bs && S.n_bs_blocks && s->bs_threads == 256) hipLaunchKernelGGL(k_backsub_prep<256>, dim3(S.n_bs_blocks), dim3(256), s->lds_bs, s->stream, P, S, wf);
             continue;
@@ -1516,6 +1525,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         s->perturb_at = s->perturb_at_next; s->perturb_at_next = 0;
         if (!rerun) { s->no_rerun = s->no_rerun_next; s->no_rerun_next = false; }
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
+        s->solve_tiles = !(opt.exec_flags & TSCM_EXEC_MFMA_REDUCED_SOLVE) || s->P.n_act > 46;      // (MF needs row 47 for the right-hand side)
         s->nd = (opt.exec_flags & TSCM_EXEC_DENSE_REDUCED_ORDER) ? 1 : 0;
         s->graph_order = (opt.exec_flags & TSCM_EXEC_GRAPH_REDUCED_ORDER) != 0 || (s->solve_variant == 0 && s->nd);
         s->t_epoch = 0;
