@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     constexpr int kTile = g4_tile_doubles(KS);
     KTL(0);
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     const long long tl_t0 = wall_clock64();
     const int tl_iter = S.ctrl->iteration;
     long long tl_ph[5] = { 0, 0, 0, 0, 0 };      // shader clocks per phase, summed over the chunk: geometry, MFMA u, copy, MFMA v, epilogue
@@ -127,12 +127,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     // on; written at the end of the kernel), [3] last record stored, [4 + i] start of view i (i < kTlViews)
     long long tl_w[4] = { 0, 0, 0, 0 };
     int tl_nv = 0;
-#define TL_STAMP(var) const long long var = (long long)__builtin_readcyclecounter()
-#define TL_ADD(k, a, b) tl_ph[k] += (b) - (a)
-#else
-#define TL_STAMP(var)
-#define TL_ADD(k, a, b)
-#endif
+    )
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lds_wave = eval_gram4_lds_doubles(P.n_points, KS);
@@ -215,10 +210,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     }
     const int per = MULTI ? P.g4_per : 4 * KS;          // corners of a pass
     asm volatile("" :: "s"(kw0), "s"(kw1), "s"(kw2), "s"(kw3), "s"(kw4), "s"(kw5), "s"(kw6), "s"(kw7), "s"(kw8));
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     tl_w[0] = wall_clock64();
     const bool tl_on = lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves;
-#endif
+    )
     for (int vbase = vb; vbase < ve; vbase += 64) {
     const int vend = min(ve, vbase + 64);
     int m_cnt = 0, m_slot = 0;
@@ -242,10 +237,10 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         const bool tail_steps = left <= 2 && ve - vb <= 16;
         set_prio(tail_steps ? left + 1 : 3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));
 #endif
-#ifdef TSCM_WAVE_TIMELINE
+        TL_ONLY(
         if (tl_on && tl_nv < kTlViews) g_tlv[(size_t)(4 + kTlViews) * chunk + 4 + tl_nv] = wall_clock64();
         ++tl_nv;
-#endif
+        )
         const cptr4 vcs = (cptr4)(S.vconst + (size_t)kVStride * view);
         auto VC = [&](int k) { return vcs[k]; };
         double accU[3] = { 0.0, 0.0, 0.0 }, accV[3] = { 0.0, 0.0, 0.0 };
@@ -285,9 +280,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         if (tail_steps && left == 0) set_prio(0);
 #endif
         TL_STAMP(ts1);
-#ifdef TSCM_WAVE_TIMELINE
-        if (tl_nv == 1) tl_w[1] = wall_clock64();
-#endif
+        TL_ONLY(if (tl_nv == 1) tl_w[1] = wall_clock64();)
         gram4_full<KS, MULTI>(aN, aR, aB, accU);
         wave_lds_fence();
         TL_STAMP(ts2);
@@ -329,13 +322,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
             buf_store_f64(r_rec, o7a, offG, T0);          // E^T r once more, compact (k_reduce_stats reads it there)
             buf_store_f64(r_rec, o7b, offG, tb1);
         }
-#ifdef TSCM_WAVE_TIMELINE
+        TL_ONLY(
         { TL_STAMP(ts5); TL_ADD(4, ts4e, ts5); }
         if (view + 1 == ve) tl_w[3] = wall_clock64();
-#endif
+        )
     }
     }   // block of <= 64 views
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) {
         g_timeline[4 * chunk] = (long long)__builtin_amdgcn_s_getreg(63492);
         g_timeline[4 * chunk + 1] = (long long)__builtin_amdgcn_s_getreg(6164);
@@ -344,7 +337,7 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         for (int k = 0; k < 5; ++k) g_phase[5 * chunk + k] = tl_ph[k];
         for (int k = 0; k < 4; ++k) g_tlv[(size_t)(4 + kTlViews) * chunk + k] = tl_w[k];
     }
-#endif
+    )
     // the camera tile leaves in the 16x16 layout and column numbering of k_eval_gram (both triangles: every entry is
     // written by the lane that holds it and, mirrored, by the same lane; the doubly held pairs carry the same bits)
     wave_lds_fence();
@@ -362,7 +355,5 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
         part[t] = (lds_all[t] + lds_all[st + t]) + (lds_all[2 * st + t] + lds_all[3 * st + t]);
         part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
     }
-#ifdef TSCM_WAVE_TIMELINE
-    if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) g_tlv[(size_t)(4 + kTlViews) * chunk + 2] = wall_clock64();     // [2]: the wave's very end (camera tile handed on)
-#endif
+    TL_ONLY(if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) g_tlv[(size_t)(4 + kTlViews) * chunk + 2] = wall_clock64();)     // [2]: the wave's very end (camera tile handed on)
 }

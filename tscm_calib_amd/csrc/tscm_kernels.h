@@ -68,13 +68,8 @@ constexpr int kMaxCamLds = 8;      // n_pad = 16*C <= 128: reduced system solved
 constexpr int kMaxCam = 32;        // larger rigs: k_solve_reduced_big factors the system in global memory (n_pad <= 512)
 constexpr int kMaxLog = 256;
 
-// phase stamps of the fused kernels (make PHASES=1: -DTSCM_PHASE_PROFILE; s_memrealtime, 10 ns ticks; one line per
-// launch from workgroups 0 and 200 -- profiling builds only)
-#if defined(TSCM_PHASE_PROFILE) || defined(TSCM_WAVE_TIMELINE)
-#define PHASE_STAMP(var) const long long var = wall_clock64()
-#else
-#define PHASE_STAMP(var)
-#endif
+// (PHASE_STAMP, TL_*, PH_ONLY, KTL*: tscm_instrument.h -- every line of instrumentation in the kernels goes through its macros)
+#include "tscm_instrument.h"
 
 // LDS hand-off inside ONE wave (64-thread workgroups): DS operations of a wave are serviced in
 // issue order, so no s_barrier / vmcnt(0) drain is needed -- only the compiler must keep the
@@ -616,40 +611,7 @@ __device__ __forceinline__ void corner_geometry(double x, double y, double ou, d
     PUT(gcR, ou - (fx * mx + CC(41)), ov - (fy * my + CC(42)));
 }
 
-#ifdef TSCM_WAVE_TIMELINE
-constexpr int kTimelineWaves = 8192;
-__device__ long long g_timeline[4 * kTimelineWaves];     // per wave of k_eval_gram: HW_ID, XCC_ID, start, end (10 ns ticks)
-__device__ long long g_phase[5 * kTimelineWaves];        // per wave of k_eval_gram4: shader clocks per phase, summed over its views
-constexpr int kTlViews = 12;
-__device__ long long g_tlv[(4 + kTlViews) * kTimelineWaves];   // per wave of k_eval_gram4: wall-clock stamps of its head, tail and views (see there)
-// per workgroup of the six kernels of an LM iteration (iteration 5): start, end of its thread 0 in 10 ns ticks
-// (tscm_debug_kernel_timeline, tools/kernel_timeline.py: launch gaps, dispatch ramps and tails between the kernels)
-constexpr int kKtlKernels = 6, kKtlGroups = 2048;
-__device__ long long g_ktl[2 * kKtlKernels * kKtlGroups];
-struct KtlScope {
-    long long t0; int id; bool on; int blk;
-    __device__ KtlScope(int id_, const CtrlHead *c) : t0(wall_clock64()), id(id_), on(c->iteration == 5), blk((int)blockIdx.x) {}
-    __device__ ~KtlScope()
-    {
-        if (on && threadIdx.x == 0 && blk < kKtlGroups) {
-            g_ktl[2 * (id * kKtlGroups + blk)] = t0;
-            g_ktl[2 * (id * kKtlGroups + blk) + 1] = wall_clock64();
-        }
-    }
-};
-#define KTL(id) KtlScope ktl_scope(id, S.ctrl)
-// per workgroup of k_schur_gram / k_backsub_prep (iteration 5): stamps of its phases (tscm_debug_phase_stamps, tools/phase_timeline.py)
-constexpr int kPhStamps = 8;
-__device__ long long g_phs[3 * kPhStamps * kKtlGroups];       // [0] k_schur_gram, [1] back-substitution, [2] k_schur_gram<NV, true>'s reduction blocks
-__device__ long long g_ktlx[32];         // stamps inside the workgroup that runs the control step (thread 0): kept in LDS
-__shared__ long long s_ktlx[32];         // and written out at the end (a global store in front of a barrier is waited for)
-#define KTLX(i, on) do { if ((on) && threadIdx.x == 0) s_ktlx[i] = wall_clock64(); } while (0)
-#define KTLX_FLUSH() do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 32; ++q_) g_ktlx[q_] = s_ktlx[q_]; } while (0)
-#else
-#define KTL(id)
-#define KTLX(i, on)
-#define KTLX_FLUSH()
-#endif
+#include "tscm_instrument.h"       // (second pass: the timeline buffers, behind CtrlHead and wall_clock64)
 #ifndef TSCM_EXP
 #define TSCM_EXP 3     // bit 0: full tiles through gram_full (0 = round 2's paired loop, for A/B runs), bit 1: first MFMA with C = 0
 #endif
@@ -715,13 +677,13 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
     // the control block is read together with the static chunk tables (one memory round trip, not two);
     // the early exit is taken right before the first view
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     // profiling builds only (make EXTRA=-DTSCM_WAVE_TIMELINE): start / end time and hardware slot of every wave of the
     // launches of LM iteration 5 into g_timeline; tscm_debug_wave_timeline copies it out, tools/wave_timeline.py groups
     // the waves by SIMD
     const long long tl_t0 = wall_clock64();
     const int tl_iter = S.ctrl->iteration;
-#endif
+    )
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: keeps chunk/view/cnt in SGPRs
     double *lds = lds_all + (size_t)wave * P.lds_wave;     // every wave works in its own LDS region
@@ -883,14 +845,14 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
         store_view_record(r_rec, lane, accU, accV, ccs, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase), rl);
     }
     }   // block of <= 64 views
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) {
         g_timeline[4 * chunk] = (long long)__builtin_amdgcn_s_getreg(63492);     // HW_ID
         g_timeline[4 * chunk + 1] = (long long)__builtin_amdgcn_s_getreg(6164);  // XCC_ID
         g_timeline[4 * chunk + 2] = tl_t0;
         g_timeline[4 * chunk + 3] = wall_clock64();
     }
-#endif
+    )
     // the four waves of the workgroup (same camera) sum their tiles through LDS in a fixed order
     wave_lds_fence();
 #pragma unroll
@@ -1637,9 +1599,7 @@ struct RawTc {
 template <int NV, bool RIDE = false>
 __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
 {
-#ifdef TSCM_WAVE_TIMELINE
-    KtlScope ktl_scope(3, ctl && !RIDE ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));      // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
-#endif
+    TL_ONLY(KtlScope ktl_scope(3, ctl && !RIDE ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));)     // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
     PHASE_STAMP(tsk);
     // head of the kernel: the control block and the chunk descriptor travel together (one memory round trip), every
     // other address follows from them arithmetically -- the second round trip already brings the data
@@ -1722,9 +1682,7 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
     };
     int ctrl_done, cur;
     double radius, dmin, dmax;
-#ifdef TSCM_WAVE_TIMELINE
-    long long t_waited = 0, t_reduced = 0;
-#endif
+    TL_ONLY(long long t_waited = 0, t_reduced = 0;)
     if (RIDE && !extra && jblk < n_stats) {
         // a reduction block of the evaluation in front of this launch (k_reduce_stats' body; the candidate's evaluation) before
         // the workgroup's own chunk
@@ -1743,13 +1701,13 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
         PHASE_STAMP(tr2);
         if (threadIdx.x == 0 && !(withhold && blk == 1) && __hip_atomic_fetch_add(S.stats_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stats_target - 1)
             __hip_atomic_store(S.stats_flag, stats_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the last one: everybody's results are complete
-#ifdef TSCM_WAVE_TIMELINE
+        TL_ONLY(
         t_reduced = wall_clock64();
         if (threadIdx.x == 0 && ktl_scope.on && blk < kKtlGroups) {
             long long *o = g_phs + (size_t)kPhStamps * (2 * kKtlGroups + blk);
             o[0] = tsk; o[1] = tr1; o[2] = tr2; o[3] = t_reduced; o[4] = blk < nc;
         }
-#endif
+        )
         __syncthreads();                                          // (the LDS goes on to the requests' consumers)
     }
     if (RIDE && jblk >= n_chunks) return;                         // (a grid of fewer chunks than reduction blocks)
@@ -1810,9 +1768,7 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
 #endif
         }
         PHASE_STAMP(tsw);
-#ifdef TSCM_WAVE_TIMELINE
-        t_waited = tsw;
-#endif
+        TL_ONLY(t_waited = tsw;)
         if (head->done) return;
         if (!extra && bid >= first_round) {
             // a later round of the grid: the outcome is published (or about to be)
@@ -1994,16 +1950,16 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         S.pairpart[(size_t)256 * P.bc_tile[6 * chunk + t] + tid] = (tiles[0][t][tid] + tiles[1][t][tid]) + (tiles[2][t][tid] + tiles[3][t][tid]);
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     if (threadIdx.x == 0 && ktl_scope.on && (int)blockIdx.x < kKtlGroups) {
         long long *o = g_phs + (size_t)kPhStamps * blockIdx.x;
         o[0] = tsk; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = ts3; o[5] = wall_clock64(); o[6] = nbd; o[7] = (bid >= first_round ? 1 : 0) | ((RIDE && t_waited ? t_waited - tsk : 0) << 1) | ((RIDE && t_reduced ? t_reduced - tsk : 0) << 32);      // (bit 0: a later round; above: ticks until the riding reductions had arrived)
     }
-#endif
-#ifdef TSCM_PHASE_PROFILE
+    )
+    PH_ONLY(
     if (threadIdx.x == 0 && (cblk == 0 || cblk == 200))
         printf("schur_gram wg %d: boards %d  head %lld  E sums %lld  factor %lld  gram %lld  tiles %lld [10 ns]\n", (int)blockIdx.x, nbd, ts0 - tsk, ts1 - ts0, ts2 - ts1, ts3 - ts2, wall_clock64() - ts3);
-#endif
+    )
 }
 
 // Fallback for boards seen by more than three cameras: explicit list of view pairs, pre-sorted by
@@ -2245,9 +2201,7 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
     // ---- build the lower triangle and the rhs row; the first panel goes straight to LDS -------------
     // wave w owns rows w, w + 16, ...; 16 rows are in flight per trip (one memory round trip per 16 x 64 entries),
     // lanes run along the columns: T (both triangles filled in by k_T_reduce) and A are read / written row-wise
-#ifdef TSCM_BIG_PROFILE
-    long long tp0 = wall_clock64(), tp_diag = 0, tp_solve = 0, tp_upd = 0;
-#endif
+    BIG_ONLY(long long tp0 = wall_clock64(), tp_diag = 0, tp_solve = 0, tp_upd = 0;)
     for (int kb = 0; wave + 16 * kb <= N; kb += 16) {
         const int rmax = min(N, wave + 16 * (kb + 15));
         for (int c = lane; c <= rmax && c < N; c += 64) {
@@ -2283,17 +2237,13 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
         }
     }
     __syncthreads();
-#ifdef TSCM_BIG_PROFILE
-    long long tp1 = wall_clock64();
-#endif
+    BIG_ONLY(long long tp1 = wall_clock64();)
     // ---- factorisation -------------------------------------------------------------------------------
     for (int tk = 0; tk < NP; ++tk) {
         const int k0 = tk * 16, m0 = k0 + 16;
         double *pc = pbuf + (tk & 1) * (16 * XP);            // this panel (index row - k0)
         double *pn = pbuf + ((tk & 1) ^ 1) * (16 * XP);      // next panel (index row - m0)
-#ifdef TSCM_BIG_PROFILE
-        const long long q0 = wall_clock64();
-#endif
+        BIG_ONLY(const long long q0 = wall_clock64();)
         if (wave == 0) {
             // Cholesky of the 16x16 diagonal block in REGISTERS: lane r holds row r, the pivot and the column entries
             // travel through v_readlane (no LDS hand-off on the column-to-column dependent chain)
@@ -2318,9 +2268,7 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
             }
         }
         lds_barrier();
-#ifdef TSCM_BIG_PROFILE
-        const long long q1 = wall_clock64();
-#endif
+        BIG_ONLY(const long long q1 = wall_clock64();)
         // panel rows m0 .. N: x = a L_kk^{-T}, one thread per row, in place in LDS (+ the final L row to global)
         for (int r = m0 + tid; r <= N; r += kBigNT) {
             double x[16];
@@ -2337,9 +2285,7 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
             for (int c = 0; c < 16; ++c) { A[big_idx(r, k0 + c)] = x[c]; pc[c * XP + (r - k0)] = x[c]; }
         }
         lds_barrier();
-#ifdef TSCM_BIG_PROFILE
-        const long long q2 = wall_clock64();
-#endif
+        BIG_ONLY(const long long q2 = wall_clock64();)
         // trailing update A_IJ -= X_I X_J^T on 16x16 blocks (four v_mfma_f64_16x16x4 each); block (I, J) belongs to
         // wave (I % 4, J % 4) for the whole factorisation; block row NP is the rhs row (rows past N: scratch).
         // kBigBatch blocks of a block row are in flight per trip; the blocks of the next panel's columns land in LDS.
@@ -2383,14 +2329,10 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
             }
         }
         lds_barrier();
-#ifdef TSCM_BIG_PROFILE
-        { const long long q3 = wall_clock64(); tp_diag += q1 - q0; tp_solve += q2 - q1; tp_upd += q3 - q2; }
-#endif
+        BIG_ONLY({ const long long q3 = wall_clock64(); tp_diag += q1 - q0; tp_solve += q2 - q1; tp_upd += q3 - q2; })
     }
     __syncthreads();
-#ifdef TSCM_BIG_PROFILE
-    long long tp2 = wall_clock64();
-#endif
+    BIG_ONLY(long long tp2 = wall_clock64();)
     // ---- back-substitution L^T y = w (w = row N of the factor) -------------------------------------
     for (int i = tid; i < N; i += kBigNT) wv[i] = A[big_idx(N, i)];
     // rows of L for the first (= last) panel; thread i keeps L[k0 + c][i], wave 0 also the diagonal block
@@ -2447,14 +2389,12 @@ __global__ __launch_bounds__(kBigNT) void k_solve_reduced_big(DevProblem P, DevS
     tail_prefetch(P, S, cur, H, tail_ops);
     for (int i = tid; i < na; i += kBigNT) yv[s_map[i]] = wv[i];          // back to padded columns
     __syncthreads();
-#ifdef TSCM_BIG_PROFILE
-    long long tp3 = wall_clock64();
-#endif
+    BIG_ONLY(long long tp3 = wall_clock64();)
     reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred);
-#ifdef TSCM_BIG_PROFILE
+    BIG_ONLY(
     if (tid == 0) printf("big solve N=%d  build %lld  factor %lld (diag %lld solve %lld update %lld)  backsub %lld  tail %lld  [10 ns ticks]\n", N,
                          tp1 - tp0, tp2 - tp1, tp_diag, tp_solve, tp_upd, tp3 - tp2, wall_clock64() - tp3);
-#endif
+    )
 }
 
 // Back-substitution of the board steps (SchurEliminator::BackSubstitute) AND the per-view constants of the candidate
@@ -2715,16 +2655,16 @@ __device__ __forceinline__ void backsub_body(const DevProblem &P, const DevState
         }
         __syncthreads();
     }
-#ifdef TSCM_WAVE_TIMELINE
+    TL_ONLY(
     if (threadIdx.x == 0 && S.ctrl->iteration == 5 && blk < kKtlGroups) {
         long long *o = g_phs + (size_t)kPhStamps * (kKtlGroups + blk);
         o[0] = ts0; o[1] = ts0; o[2] = ts1; o[3] = ts2; o[4] = wall_clock64(); o[5] = o[4]; o[6] = nbl; o[7] = 0;
     }
-#endif
-#ifdef TSCM_PHASE_PROFILE
+    )
+    PH_ONLY(
     if (threadIdx.x == 0 && (blk == 0 || blk == 200))
         printf("backsub_prep wg %d: W.yhat %lld  board solve %lld  view constants %lld [10 ns]\n", blk, ts1 - ts0, ts2 - ts1, wall_clock64() - ts2);
-#endif
+    )
 }
 
 template <int NTH>

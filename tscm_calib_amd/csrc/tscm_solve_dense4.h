@@ -131,10 +131,10 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
     if constexpr (FUSED) {
         static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
         if ((int)blockIdx.x > n_prod) {
-#ifdef TSCM_WAVE_TIMELINE
+            TL_ONLY(
             KtlScope ktl_bs(5, S.ctrl);
             ktl_bs.blk = (int)blockIdx.x - 1 - n_prod;
-#endif
+            )
             backsub_body<256, true>(P, S, with_floats, (int)blockIdx.x - 1 - n_prod, n_bs, epoch, epoch * n_prod);
             return;
         }
@@ -255,9 +255,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
         }
     }
     PHASE_STAMP(ts1);
-#ifdef TSCM_PHASE_PROFILE
-    const long long cy1 = clock64();
-#endif
+    PH_ONLY(const long long cy1 = clock64();)
     if constexpr (MF) {
     // ---- MF: right-looking Cholesky of the 48 x 48 system on ONE wave, rank-4 updates on the matrix cores (round 6) ----------
     // The compact system of a rig of up to four cameras has at most 46 free columns: padded to 48 it is SIX lower 16 x 16 tiles --
@@ -465,10 +463,10 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
     for (int tk = 0; tk < NP; ++tk) {
         const double *Ar = Xb + (tk & 1) * (G * XT);
         double *ArN = Xb + ((tk + 1) & 1) * (G * XT);
-#ifdef TSCM_PHASE_PROFILE
+        PH_ONLY(
         __shared__ long long s_ph[8];
         if (tk == 3 && (dthread || tid == 11 * G + 5)) s_ph[dthread ? 0 : 4] = wall_clock64();
-#endif
+        )
         if (dthread && tk + 1 < NP) {
             // (all LDS operands requested before the first use: one exposed latency instead of one per group)
             PanelFactor f;
@@ -487,13 +485,9 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
                     for (int q = 0; q < TS; ++q) v -= x[r][q] * x[c][q];
                     t[r][c] = v;
                 }
-#ifdef TSCM_PHASE_PROFILE
-            if (tk == 3) { asm volatile("" : "+v"(t[3][3])); s_ph[1] = wall_clock64(); }
-#endif
+            PH_ONLY(if (tk == 3) { asm volatile("" : "+v"(t[3][3])); s_ph[1] = wall_clock64(); })
             factor_diag(t, tk + 1);
-#ifdef TSCM_PHASE_PROFILE
-            if (tk == 3) s_ph[2] = wall_clock64();
-#endif
+            PH_ONLY(if (tk == 3) s_ph[2] = wall_clock64();)
         }
         if ((mine || rhsrow) && ri > tk && cj >= tk && !(ri == cj && ri == tk + 1)) {
             PanelFactor f;
@@ -532,13 +526,9 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
             const bool col = cj == tk + 1 && ri > tk + 1 && (mine || rhsrow), dg = ri == tk + 2 && cj == tk + 2 && mine;
             if (col || dg) publish_tile(col ? ArN + ri * XT : s_dt[(tk + 1) & 1], a);
         }
-#ifdef TSCM_PHASE_PROFILE
-        if (tk == 3 && tid == 11 * G + 5) { asm volatile("" : "+v"(a[3][3])); s_ph[5] = wall_clock64(); }
+        PH_ONLY(if (tk == 3 && tid == 11 * G + 5) { asm volatile("" : "+v"(a[3][3])); s_ph[5] = wall_clock64(); })
         if (tk + 1 < NP) __syncthreads();
-        if (tk == 3 && tid == 0) { s_ph[6] = wall_clock64(); printf("  panel 3: D x,t %lld  factor %lld | update %lld | to barrier exit %lld\n", s_ph[1] - s_ph[0], s_ph[2] - s_ph[1], s_ph[5] - s_ph[4], s_ph[6] - s_ph[0]); }
-#else
-        if (tk + 1 < NP) __syncthreads();
-#endif
+        PH_ONLY(if (tk == 3 && tid == 0) { s_ph[6] = wall_clock64(); printf("  panel 3: D x,t %lld  factor %lld | update %lld | to barrier exit %lld\n", s_ph[1] - s_ph[0], s_ph[2] - s_ph[1], s_ph[5] - s_ph[4], s_ph[6] - s_ph[0]); })
     }
     // ---- publish L (the diagonal tiles are there already), back-substitute L^T y = w with one wave -----------
     if (cj < ri && mine) {
@@ -550,9 +540,7 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
     __syncthreads();
     }   // (!MF)
     PHASE_STAMP(ts2);
-#ifdef TSCM_PHASE_PROFILE
-    const long long cy2 = clock64();
-#endif
+    PH_ONLY(const long long cy2 = clock64();)
     TailOperands tail_ops;
     tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
     if (tid < 64) {
@@ -600,8 +588,6 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
     __syncthreads();
     PHASE_STAMP(ts3);
     reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred, FUSED && n_bs > 0 ? epoch : 0);
-#ifdef TSCM_PHASE_PROFILE
-    if (tid == 0) printf("solve_reduced: ctrl %lld operands %lld  factor %lld (%lld shader clocks)  backsub %lld  tail %lld [10 ns]\n", ts0b - ts0, ts1 - ts0b, ts2 - ts1, cy2 - cy1, ts3 - ts2, wall_clock64() - ts3);
-#endif
+    PH_ONLY(if (tid == 0) printf("solve_reduced: ctrl %lld operands %lld  factor %lld (%lld shader clocks)  backsub %lld  tail %lld [10 ns]\n", ts0b - ts0, ts1 - ts0b, ts2 - ts1, cy2 - cy1, ts3 - ts2, wall_clock64() - ts3);)
 }
 

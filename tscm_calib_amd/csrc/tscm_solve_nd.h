@@ -48,10 +48,10 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     static_assert(NT == kFusedEntries * kTSlices, "the T reduction runs in the solver's workgroup shape");
     if constexpr (FUSED) {
         if ((int)blockIdx.x > n_prod) {
-#ifdef TSCM_WAVE_TIMELINE
+            TL_ONLY(
             KtlScope ktl_bs(5, S.ctrl);
             ktl_bs.blk = (int)blockIdx.x - 1 - n_prod;
-#endif
+            )
             backsub_body<256, true>(P, S, with_floats, (int)blockIdx.x - 1 - n_prod, n_bs, epoch, epoch * n_prod);
             return;
         }
@@ -281,10 +281,10 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
         }
     }
     __syncthreads();
-#ifdef TSCM_PHASE_PROFILE
+    PH_ONLY(
     __shared__ long long s_pht[kNdMaxPhases + 1];
     if (tid == 0) s_pht[0] = wall_clock64();
-#endif
+    )
     // ---- factorisation: two barriers per phase ----------------------------------------------------------------------------------
     // State at the top of phase t: the factors of its panels are in Ld; every tile is updated through phase t - 1;
     // s_dt[(t + 1) & 1] holds the diagonal tiles of phase t + 1 (updated through t - 1), s_dr[t & 1] the raw tiles (panel of
@@ -384,9 +384,7 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
         }
         __syncthreads();                                      // barrier B
         sp = spn;
-#ifdef TSCM_PHASE_PROFILE
-        if (tid == 0) s_pht[ph + 1] = wall_clock64();
-#endif
+        PH_ONLY(if (tid == 0) s_pht[ph + 1] = wall_clock64();)
     }
     PHASE_STAMP(ts2);
     // ---- the packed factor (row-major by (row panel, column panel), tiles transposed: a lane of the back-substitution reads one
@@ -404,9 +402,7 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
         }
     __syncthreads();
     PHASE_STAMP(ts2b);
-#ifdef TSCM_PHASE_PROFILE
-    __shared__ long long s_bst[kNdMaxPhases + 2];
-#endif
+    PH_ONLY(__shared__ long long s_bst[kNdMaxPhases + 2];)
     TailOperands tail_ops;
     tail_prefetch(P, S, cur, H, tail_ops);        // in flight during the back-substitution (the tiles' registers are free now)
     if (tid < 64) {
@@ -478,15 +474,11 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
                 // (y_k is read by other lanes of THIS wave in the next phase: LDS operations of a wave are served in order, only
                 // the compiler must not move them -- a fence here would also wait for the tail's global prefetch)
                 asm volatile("" ::: "memory");
-#ifdef TSCM_PHASE_PROFILE
-                if (tid == 0) s_bst[ph] = wall_clock64();
-#endif
+                PH_ONLY(if (tid == 0) s_bst[ph] = wall_clock64();)
             };
             BsOps oa, ob;
             prefetch(oa, n_phases - 1);
-#ifdef TSCM_PHASE_PROFILE
-            if (tid == 0) s_bst[n_phases] = wall_clock64();
-#endif
+            PH_ONLY(if (tid == 0) s_bst[n_phases] = wall_clock64();)
             for (int ph = n_phases - 1; ph >= 0; ph -= 2) {
                 phase(oa, ob, ph);
                 if (ph > 0) phase(ob, oa, ph - 1);
@@ -535,7 +527,7 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
     __syncthreads();
     PHASE_STAMP(ts3);
     reduced_solution_tail(P, S, cur, s_fail, tail_ops, yv, s_sc, s_yh, s_act, sred, FUSED && n_bs > 0 ? epoch : 0);
-#ifdef TSCM_PHASE_PROFILE
+    PH_ONLY(
     if (tid == 0) {
         printf("solve_nd: ctrl %lld  T wait %lld  operands %lld  to first phase %lld  factor %lld (%d phases)  backsub %lld  tail %lld [10 ns]\n", tsA - ts0, tsB - tsA, ts1 - tsB, s_pht[0] - ts1, ts2 - s_pht[0], n_phases, ts3 - ts2, wall_clock64() - ts3);
         for (int ph = 0; ph < n_phases; ++ph) printf("  phase %d: %lld\n", ph, s_pht[ph + 1] - s_pht[ph]);
@@ -543,5 +535,5 @@ __global__ __launch_bounds__(kNdThreads, FUSED ? TSCM_ND_WGS_PER_CU : 1) void k_
         for (int ph = n_phases - 1; ph >= 0; --ph) printf(" %lld", s_bst[ph] - s_bst[ph + 1]);
         printf("\n");
     }
-#endif
+    )
 }
