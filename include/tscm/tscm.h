@@ -153,7 +153,9 @@ enum {
                                            /* updates on the matrix cores (six 16 x 16 accumulator tiles) instead of 256 threads on  */
                                            /* 4 x 4 register tiles with a barrier per panel.  Round 6: built, the SAME bits, 1 us     */
                                            /* slower at config 4 -- an experiment switch, not the default (HISTORY A.7)              */
-    TSCM_EXEC_ALL = 511
+    TSCM_EXEC_ONE_VIEW_PER_PASS = 512,     /* boards of up to 32 corners: one view per pass of the Gram kernel (k_eval_gram4) instead of  */
+                                           /* several views sharing a pass (k_eval_gram4p, round 6): same bits, for tests and A/B runs     */
+    TSCM_EXEC_ALL = 1023
 };
 
 /* ceres::IterationSummary subset */

@@ -481,7 +481,7 @@ def test_unknown_exec_flags_are_refused(hip_device):
     p = H.small_rig(4, 4, seed=1).normalised()
     with api.Solver(p) as s:
         with pytest.raises(TscmError) as e:
-            s.solve(exec_flags=0x200)          # (0x100 is TSCM_EXEC_MFMA_REDUCED_SOLVE since round 6)
+            s.solve(exec_flags=0x400)          # (0x100, 0x200: TSCM_EXEC_MFMA_REDUCED_SOLVE, _ONE_VIEW_PER_PASS since round 6)
         assert e.value.code == -1
         s.solve()
 
@@ -586,6 +586,38 @@ def test_gram4_serves_every_board_size_with_the_bits_of_the_16x16_tile(hip_devic
             assert x["step_is_successful"] == y["step_is_successful"]
             assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
         assert max(H.param_rel_err(a, o).values()) < 1e-6
+
+
+@pytest.mark.parametrize("cols,rows", [(6, 5), (8, 4), (7, 4), (5, 5), (5, 4), (4, 4), (4, 3), (3, 3), (3, 2), (2, 2)])
+def test_small_boards_share_a_pass_with_the_bits_of_one_view_per_pass(hip_device, cols, rows):
+    """Boards of up to 32 corners (round 6): M = 2..4 consecutive views of a chunk share a pass of k_eval_gram4p -- one geometry
+    pass for M views, the views' constants through LDS, every view its own accumulators.  Per corner and per view the same
+    operations in the same order as k_eval_gram4 (TSCM_EXEC_ONE_VIEW_PER_PASS): bit-identical -- full views, ragged ones (a prefix
+    of the corner list, an empty view, which makes the speculative first load of a block wrong), chunks of several passes and of
+    more than one metadata block (the mono problem with 300 views), and against the oracle."""
+    n = cols * rows
+    cases = [synth.make_problem(4, 10, 800 + n, cols=cols, rows=rows, pitch=360.0 / max(cols, rows, 2))]
+    rng = np.random.default_rng(n)
+    q = cases[0].copy()
+    q.view_count[::3] = rng.integers(max(1, n // 3), n + 1, size=q.view_count[::3].shape[0])
+    q.view_count[0] = max(1, n - 1)                       # the very first view of a chunk: the speculative load is wrong
+    if n >= 6:
+        q.view_count[7] = 0
+    cases.append(q)
+    if n >= 9:
+        cases.append(synth.make_problem(1, 300, 900 + n, cols=cols, rows=rows, pitch=360.0 / max(cols, rows)))
+    for prob in cases:
+        a, b, o = prob.copy().normalised(), prob.copy().normalised(), prob.copy().normalised()
+        run = (lambda z, **kw: api.refinement(z, **kw)[1]) if prob.mono else (lambda z, **kw: api.calibrate(z, **kw))
+        sa = run(a, max_num_iterations=5)
+        sb = run(b, max_num_iterations=5, exec_flags=lib.EXEC_ONE_VIEW_PER_PASS)
+        so = orc.solve(o, max_num_iterations=5)
+        assert sa["num_iterations"] == sb["num_iterations"] == so["num_iterations"]
+        assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
+        assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+        for x, y in zip(sa["iterations"], so["iterations"]):
+            assert x["step_is_successful"] == y["step_is_successful"]
+            assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
 
 
 def test_gram4_two_passes_on_the_reference_board_at_size(hip_device):

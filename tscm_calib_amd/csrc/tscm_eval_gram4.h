@@ -357,3 +357,239 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S,
     }
     TL_ONLY(if (lane == 0 && tl_iter == 5 && cand && chunk < kTimelineWaves) g_tlv[(size_t)(4 + kTlViews) * chunk + 2] = wall_clock64();)     // [2]: the wave's very end (camera tile handed on)
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_eval_gram4p<KS, M>: SMALL boards (round 6) -- M consecutive views of the chunk share a pass.
+// A board of n <= 32 corners leaves half of the 64 lanes of k_eval_gram4<KS, false> without a corner, and the geometry (263
+// VALU instructions per pass whatever the number of live lanes) is a third of the kernel: at 6 x 5 a corner cost 35.9 ps against
+// 24.9 at 9 x 6.  Here lane l works for view l / (4 KS) of the pass, corner l % (4 KS): one geometry pass serves M views.
+//   * the views' 27 constants are no longer wave-uniform: the M records are staged in LDS (one double per lane, prefetched a
+//     pass ahead) and read with the lane's own base -- broadcast reads inside a view's lanes;
+//   * the observations of a camera's consecutive views are contiguous: the lane's offset is the running sum of the counts
+//     of the views in front of its own (v_readlane of the block's metadata, M - 1 selects);
+//   * the tile holds the M views' rows one after the other (KS k-steps each, M KS <= 16); every view keeps ITS OWN accumulators
+//     (its record needs its own Gram), so the contraction issues exactly the MFMAs of M separate views: the k-steps of view
+//     s are tile rows 4 KS s ..; u-rows of all M views, then v-rows, epilogue per view.
+// Same operations per corner and per view in the same order as k_eval_gram4<KS, false> -- only WHO computes them changes: the
+// whole solve is bit-identical (tests/test_gpu_parity.py).  Views whose corner count differs from n (ragged) are handled: the
+// speculative first load of a block assumes full views and is repeated if that was wrong.
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int g4p_views(int ks) { return ks > 8 ? 1 : (16 / ks > 4 ? 4 : 16 / ks); }       // views per pass: M KS <= 16, at most 4
+__host__ __device__ inline int eval_gram4p_lds_doubles(int n_points, int ks, int m) { return g4_tile_doubles(ks * m) + 2 * n_points + 32 * m; }
+
+template <int KS, int M>
+__global__ __launch_bounds__(256, 4) void k_eval_gram4p(DevProblem P, DevState S, int cand)
+{
+    static_assert(M >= 2 && M <= 4 && KS * M <= 16, "M views of KS k-steps each in the 64 rows of a pass");
+    constexpr int RV = 4 * KS;                      // rows (= lanes) of a view
+    constexpr int kTile = g4_tile_doubles(KS * M);
+    constexpr int BL = 64 / M * M;                  // views per metadata block: whole passes
+    KTL(0);
+    const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lds_wave = eval_gram4p_lds_doubles(P.n_points, KS, M);
+    double *lds = lds_all + (size_t)wave * lds_wave;
+    double *Fl = lds;
+    double *bxy = lds + kTile;
+    double *vcl = bxy + 2 * P.n_points;             // [M][32] the views' constants of the current pass
+    const int lane = threadIdx.x & 63;
+    const int sv = lane / RV, jl = lane - sv * RV;  // my view of the pass, my corner
+    const int chunk = blockIdx.x * 4 + wave;
+    const v4i cd = *(const v4i __attribute__((address_space(4))) *)(const void *)(P.chunk_desc + chunk);
+    const int cam = cd[0], vb = cd[1], ve = cd[2];
+    const d2 my_xy = *reinterpret_cast<const d2 *>(P.board_xy + 2 * min(jl, P.n_points - 1));
+    double *const cc_buf[2] = { S.cconst[0], S.cconst[1] };
+    double *const rec_buf[2] = { S.rec[0], S.rec[1] };
+    double camU[3] = { 0.0, 0.0, 0.0 }, camV[3] = { 0.0, 0.0, 0.0 };
+    for (int i = lane; i < KS * M * kG4Stride; i += 64) Fl[i] = 0.0;
+    bool prev_valid = false;
+    double pf_u = 0.0, pf_v = 0.0;
+    if (ctrl_done) return;
+    const int tgt = cand ? (ctrl_cur ^ 1) : ctrl_cur;
+    const __amdgpu_buffer_rsrc_t r_rec = make_rsrc(tgt ? rec_buf[1] : rec_buf[0], sizeof(double) * (size_t)kRec * P.V);
+    const cptr4 ccs = (cptr4)((tgt ? cc_buf[1] : cc_buf[0]) + kCStride * cam);
+    auto CC = [&](int k) { return ccs[k]; };
+    const __amdgpu_buffer_rsrc_t r_vc = make_rsrc(S.vconst, sizeof(double) * (size_t)kVStride * P.V);
+    const __amdgpu_buffer_rsrc_t r_u = make_rsrc(P.obs_u, sizeof(double) * (size_t)P.N), r_v = make_rsrc(P.obs_v, sizeof(double) * (size_t)P.N);
+    int off_next = cd[3];
+    constexpr unsigned BAD = 0xffffe000u;
+    // the constants of the views of a pass: lane l (and l + 64 for M > 2) fetches double l % 32 of view l / 32 of the pass
+    double vc_pf0 = 0.0, vc_pf1 = 0.0;
+    auto request_vc = [&](int view0, int vend_) {
+        const int s0 = lane >> 5, k = lane & 31;
+        vc_pf0 = buf_load_f64(r_vc, (s0 < M && view0 + s0 < vend_ && k < kVConst) ? 8u * (unsigned)(kVStride * s0 + k) : BAD, 8u * (unsigned)kVStride * (unsigned)view0);
+        if constexpr (M > 2) vc_pf1 = buf_load_f64(r_vc, (s0 + 2 < M && view0 + s0 + 2 < vend_ && k < kVConst) ? 8u * (unsigned)(kVStride * (s0 + 2) + k) : BAD, 8u * (unsigned)kVStride * (unsigned)view0);
+    };
+    int m_cnt0 = 0, m_slot0 = 0;
+    if (vb + lane < min(ve, vb + BL)) { m_cnt0 = P.view_count[vb + lane]; m_slot0 = P.view_slot[vb + lane]; }
+    request_vc(vb, ve);
+    // the first pass's observations, requested before the counts are known: full views assumed (checked at the top of the block)
+    if (vb < ve) {
+        const unsigned o = (jl < P.n_points && sv < M) ? 8u * (unsigned)(sv * P.n_points + jl) : BAD;
+        pf_u = buf_load_f64(r_u, o, 8u * (unsigned)off_next); pf_v = buf_load_f64(r_v, o, 8u * (unsigned)off_next);
+    }
+    // ---- lane roles (as k_eval_gram4) ------------------------------------------------------------------------------------
+    double *fu_lo = Fl + (lane >> 2) * kG4Stride + (lane & 3), *fu_hi = Fl + (lane >> 2) * kG4Stride + ((lane & 3) ^ 2);
+    const int li = lane >> 4, c16 = lane & 15, lb = c16 >> 2, lj = c16 & 3;
+    const unsigned lds0 = lds_addr(Fl);
+    const unsigned aN = lds0 + 8u * (unsigned)g4_elem(c16, li);
+    const unsigned aR = lds0 + 8u * (unsigned)g4_elem((c16 + 4) & 15, li);
+    const unsigned aB = lds0 + 8u * (unsigned)g4_elem(4 * g4_cgroup(lb, 2) + lj, li);
+    const double rc0 = lj == 0 ? ccs[0] : lj == 1 ? ccs[1] : ccs[2];
+    const double rc1 = lj == 0 ? ccs[3] : lj == 1 ? ccs[4] : ccs[5];
+    const double rc2 = lj == 0 ? ccs[6] : lj == 1 ? ccs[7] : ccs[8];
+    unsigned o1e = BAD, o1w = BAD, o2 = BAD, o3e = BAD, o4 = BAD, o5 = BAD, o6 = BAD, o7a = BAD, o7b = BAD;
+    {
+        const int b = lb, j = lj, i = li;
+        auto W = [](int wcol, int row) { return 8u * (unsigned)(6 * wcol + row); };
+        const int f1 = g4_wcol(4 + i), f1j = g4_wcol(4 + j), f2 = g4_wcol(8 + i), f2j = g4_wcol(8 + j), f3 = g4_wcol(12 + i);
+        if (b == 0 && j < 3 && i < 3) { o1e = 8u * (unsigned)(6 * j + i); o3e = 8u * (unsigned)(6 * i + 3 + j); }
+        if (b == 0 && j == 3 && i < 3) { o1w = W(kFR, i); o7a = 8u * (unsigned)i; }
+        if (b == 1 && j < 3) o1w = W(f1, 3 + j);
+        if (b == 0 && i < 3) o2 = W(f1j, i);
+        if (b == 0 && i == 3 && j < 3) { o2 = W(kFR, 3 + j); o7b = 8u * (unsigned)(3 + j); }
+        if (b == 3 && j < 3 && i < 3) o2 = W(f3, j);
+        if (b == 0 && i < 3) o4 = W(f2j, i);
+        if (b == 2 && j < 3) o4 = W(f2, 3 + j);
+        if (b == 3 && j < 3 && i < 3) o4 = W(f3, 3 + j);
+        if (b == 3 && i == 0 && j < 3) { o5 = W(9, j); o6 = W(9, 3 + j); }
+        if (b == 0 && j == 3 && i < 3) o6 = W(7, i);
+        if (b == 2 && i == 3 && j < 3) o6 = W(7, 3 + j);
+    }
+    if (lane < P.n_points) *reinterpret_cast<d2 *>(bxy + 2 * lane) = *reinterpret_cast<const d2 *>(P.board_xy + 2 * lane);
+    (void)my_xy;
+    const double *vcm = vcl + 32 * min(sv, M - 1);          // my view's constants
+    auto VC = [&](int k) { return vcm[k]; };
+    // the record of one view from its two accumulator sets (the epilogue of k_eval_gram4, same operations, same order)
+    auto store_view = [&](const double (&aU)[3], const double (&aV)[3], unsigned slot) {
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int b = (le >> 2) & 3, i = le >> 4;
+        const unsigned offW = 8u * (unsigned)kRecW * slot, offE = 8u * ((unsigned)kRecW * (unsigned)P.V + (unsigned)kRecE * slot);
+        const double T0 = aU[0] + aV[0], T1 = aU[1] + aV[1], T2 = aU[2] + aV[2];
+        const double tb0 = quad_tb(T0, rc0, rc1, rc2), tb1 = quad_tb(T1, rc0, rc1, rc2), tb2 = quad_tb(T2, rc0, rc1, rc2);
+        const double tbU2 = quad_tb(aU[2], rc0, rc1, rc2);
+        const bool split1 = b == 3 && i == 0, split2 = (le & 3) == 3 ? b == 0 : (b == 2 ? i == 3 : (b == 3 && i == 0));
+        buf_store_f64(r_rec, o1e, offE, T0);
+        buf_store_f64(r_rec, o1w, offW, b == 1 ? tb0 : T0);
+        buf_store_f64(r_rec, o2, offW, split1 ? aU[1] : (i == 3 ? tb1 : T1));
+        buf_store_f64(r_rec, o3e, offE, tb1);
+        const double a4 = b != 0 ? tb2 : T2, u4 = b != 0 ? tbU2 : aU[2];
+        buf_store_f64(r_rec, o4, offW, split2 ? u4 : a4);
+        buf_store_f64(r_rec, o5, offW, T1 - aU[1]);
+        buf_store_f64(r_rec, o6, offW, a4 - u4);
+        const unsigned offG = 8u * ((unsigned)(kRecW + kRecE) * (unsigned)P.V + (unsigned)kRecG * slot);
+        buf_store_f64(r_rec, o7a, offG, T0);
+        buf_store_f64(r_rec, o7b, offG, tb1);
+    };
+    for (int vbase = vb; vbase < ve; vbase += BL) {
+    const int vend = min(ve, vbase + BL);
+    int m_cnt = 0, m_slot = 0;
+    if (vbase == vb) { m_cnt = m_cnt0; m_slot = m_slot0; }
+    else if (vbase + lane < vend) { m_cnt = P.view_count[vbase + lane]; m_slot = P.view_slot[vbase + lane]; }
+    asm volatile("" : "+v"(m_cnt), "+v"(m_slot));
+    {
+        // the block's first pass: its observations were requested assuming full views (the head; the previous block's last pass
+        // requests nothing across the block boundary) -- (re)request them with the real counts where that is not what is there
+        bool full = vbase == vb;
+        int o = off_next, my_o = 0, my_c = 0;
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            const int c = vbase + s < vend ? __builtin_amdgcn_readlane(m_cnt, s) : 0;          // (m_cnt: lane i = view vbase + i)
+            full = full && (c == P.n_points || vbase + s >= vend);
+            if (sv == s) { my_o = o; my_c = c; }
+            o += c;
+        }
+        if (!full) {
+            const unsigned ol = (jl < my_c && sv < M) ? 8u * (unsigned)(my_o + jl) : BAD;       // (the offset differs from lane to lane: all of it in the vector part)
+            pf_u = buf_load_f64(r_u, ol, 0u); pf_v = buf_load_f64(r_v, ol, 0u);
+        }
+    }
+    for (int view = vbase; view < vend; view += M) {
+        const int nvp = min(M, vend - view);                 // views of this pass
+        int cnt[M], my_cnt = 0;
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            cnt[s] = s < nvp ? __builtin_amdgcn_readlane(m_cnt, min(view - vbase + s, 63)) : 0;
+            if (sv == s) my_cnt = cnt[s];
+            off_next += cnt[s];
+        }
+        wave_lds_fence();                       // the previous pass has finished with the tile and the constants
+#if TSCM_PRIO
+        set_prio(3 - min(3, 8 * (view - vb) / max(1, ve - vb) % 4));      // priority by progress: see k_eval_gram
+#endif
+        // the views' constants into LDS
+        if (lane < 32 * min(M, 2)) vcl[lane] = vc_pf0;
+        if constexpr (M > 2) { if (lane < 32 * (M - 2)) vcl[64 + lane] = vc_pf1; }
+        wave_lds_fence();
+        const bool valid = sv < nvp && jl < my_cnt;
+        double fv[16];
+        auto PUT = [&](int c, double u, double v) { (c < 8 ? fu_lo : fu_hi)[4 * c] = u; fv[c] = v; };
+        if (valid) {
+            const double x = bxy[2 * jl], y = bxy[2 * jl + 1];
+            constexpr int tcol[15] = { kG4Wb, kG4Wb + 1, kG4Wb + 2, kG4Tc, kG4Tc + 1, kG4Tc + 2, kG4Wc, kG4Wc + 1, kG4Wc + 2,
+                                       kG4F, kG4One, kG4Xi, kG4Lam, kG4Al, kG4R };
+            corner_geometry(x, y, pf_u, pf_v, VC, CC, [&](int gc, double u, double v) { PUT(tcol[gc], u, v); });
+        } else if (prev_valid) {
+#pragma unroll
+            for (int c = 0; c < kTcols; ++c) (c < 8 ? fu_lo : fu_hi)[4 * c] = 0.0;
+        }
+        prev_valid = valid;
+        {
+            // the next pass of this block: its observations (the lane's own offset: the running sum of the counts in front of its
+            // view) and its views' constants
+            const int vn = view + M;
+            int o = off_next, my_o = 0, my_c = 0;
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                const int c = vn + s < vend ? __builtin_amdgcn_readlane(m_cnt, min(vn + s - vbase, 63)) : 0;
+                if (sv == s) { my_o = o; my_c = c; }
+                o += c;
+            }
+            const unsigned ol = (jl < my_c && sv < M) ? 8u * (unsigned)(my_o + jl) : BAD;
+            pf_u = buf_load_f64(r_u, ol, 0u); pf_v = buf_load_f64(r_v, ol, 0u);
+            if (vn < vend) request_vc(vn, vend);
+            else if (vend < ve) request_vc(vend, ve);          // (the next block's first pass: its constants need no counts)
+        }
+        wave_lds_fence();
+        double accU[M][3];
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            accU[s][0] = accU[s][1] = accU[s][2] = 0.0;
+            if (s < nvp) gram4_full<KS, false>(aN + 8u * (unsigned)(kG4Stride * KS * s), aR + 8u * (unsigned)(kG4Stride * KS * s), aB + 8u * (unsigned)(kG4Stride * KS * s), accU[s]);
+        }
+        wave_lds_fence();
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < kTcols; ++c) (c < 8 ? fu_lo : fu_hi)[4 * c] = fv[c];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            if (s < nvp) {
+                double accV[3] = { 0.0, 0.0, 0.0 };
+                gram4_full<KS, false>(aN + 8u * (unsigned)(kG4Stride * KS * s), aR + 8u * (unsigned)(kG4Stride * KS * s), aB + 8u * (unsigned)(kG4Stride * KS * s), accV);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { camU[q] += accU[s][q]; camV[q] += accV[q]; }
+                store_view(accU[s], accV, (unsigned)__builtin_amdgcn_readlane(m_slot, view - vbase + s));
+            }
+        }
+    }
+    }   // block of BL views
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int r = g4_old_col(4 * lb + li), c = g4_old_col(4 * g4_cgroup(lb, q) + lj);
+        lds[16 * r + c] = camU[q]; lds[16 * c + r] = camU[q];
+        lds[256 + 16 * r + c] = camV[q]; lds[256 + 16 * c + r] = camV[q];
+    }
+    __syncthreads();
+    {
+        const int t = threadIdx.x;
+        const size_t st = lds_wave;
+        double *part = S.campart + (size_t)512 * blockIdx.x;
+        part[t] = (lds_all[t] + lds_all[st + t]) + (lds_all[2 * st + t] + lds_all[3 * st + t]);
+        part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
+    }
+}

@@ -108,6 +108,13 @@ static EvalKernel g4_kernel(int ks, bool multi)
         k_eval_gram4<11, true>, k_eval_gram4<12, true>, k_eval_gram4<13, true>, k_eval_gram4<14, true> };
     return (multi ? passes : single)[ks - 1];
 }
+// boards of up to 32 corners: M = g4p_views(KS) views share a pass (k_eval_gram4p)
+static EvalKernel g4p_kernel(int ks)
+{
+    static const EvalKernel packed[8] = { k_eval_gram4p<1, 4>, k_eval_gram4p<2, 4>, k_eval_gram4p<3, 4>, k_eval_gram4p<4, 4>,
+                                          k_eval_gram4p<5, 3>, k_eval_gram4p<6, 2>, k_eval_gram4p<7, 2>, k_eval_gram4p<8, 2> };
+    return ks >= 1 && ks <= 8 ? packed[ks - 1] : nullptr;
+}
 static EvalKernel f32_kernel(int ks, bool multi)     // the fp32-Jacobian tier on the same pass plan
 {
     static const EvalKernel single[kG4MaxKS] = {
@@ -186,6 +193,9 @@ struct tscm_solver {
     bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
     bool solve_tiles = true;            // this solve: k_solve_reduced<.., MF = false> (the default; TSCM_EXEC_MFMA_REDUCED_SOLVE clears it)
     size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4
+    EvalKernel eval4p = nullptr;        // boards of up to 32 corners: several views per pass (k_eval_gram4p); nullptr otherwise
+    size_t lds_eval4p = 0;
+    bool one_view_per_pass = false;     // this solve: TSCM_EXEC_ONE_VIEW_PER_PASS
     EvalKernel eval4 = nullptr, eval32 = nullptr;   // ... and its instantiation for this problem's board (g4_kernel), the fp32-Jacobian tier's (f32_kernel)
     // dominant-kernel timing
     int timing = 0;                     // 0 = off, n = bracket every n-th launch of the dominant kernel (and every n-th exchange) with HIP events
@@ -900,6 +910,10 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, g4.ks);
     s->lds_eval4 = lds_eval4; s->eval4 = eval4; s->eval32 = f32_kernel(g4.ks, g4.passes > 1);
+    if (g4.passes == 1 && g4.ks <= 8) {
+        s->eval4p = g4p_kernel(g4.ks);
+        s->lds_eval4p = 4 * sizeof(double) * (size_t)eval_gram4p_lds_doubles(p->n_points, g4.ks, g4p_views(g4.ks));
+    }
     // reduced solve: up to 8 cameras k_solve_nd on the plan of the camera-pair graph (tscm_nd_plan.h), larger rigs in global memory
     s->solve_variant = C <= 4 ? 0 : C <= kMaxCamLds ? 1 : 3;
     if (s->solve_variant == 0) {
@@ -1117,6 +1131,7 @@ static int launch_eval(tscm_solver *s, int cand)
     const dim3 grid(P.n_chunks / 4);
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
     if (s->f32_jacobian) launch_eval_kernel(s->eval32, grid, s->lds_eval32, s, e0, e1, cand);
+    else if (!s->gram16 && s->eval4p && !s->one_view_per_pass) launch_eval_kernel(s->eval4p, grid, s->lds_eval4p, s, e0, e1, cand);     // small boards: views share a pass
     else if (!s->gram16) launch_eval_kernel(s->eval4, grid, s->lds_eval4, s, e0, e1, cand);       // every board size (round 6)
     else if (P.rp == 58) launch_eval_kernel(k_eval_gram<58>, grid, s->lds_eval, s, e0, e1, cand);
     else launch_eval_kernel(k_eval_gram<0>, grid, s->lds_eval, s, e0, e1, cand);
@@ -1525,6 +1540,7 @@ static int run_lm_inner(LmRun &run, const tscm_options *opt_in, tscm_summary *su
         s->perturb_at = s->perturb_at_next; s->perturb_at_next = 0;
         if (!rerun) { s->no_rerun = s->no_rerun_next; s->no_rerun_next = false; }
         s->gram16 = (opt.exec_flags & TSCM_EXEC_GRAM_16X16) != 0;
+        s->one_view_per_pass = (opt.exec_flags & TSCM_EXEC_ONE_VIEW_PER_PASS) != 0;
         s->solve_tiles = !(opt.exec_flags & TSCM_EXEC_MFMA_REDUCED_SOLVE) || s->P.n_act > 46;      // (MF needs row 47 for the right-hand side)
         s->nd = (opt.exec_flags & TSCM_EXEC_DENSE_REDUCED_ORDER) ? 1 : 0;
         s->graph_order = (opt.exec_flags & TSCM_EXEC_GRAPH_REDUCED_ORDER) != 0 || (s->solve_variant == 0 && s->nd);

@@ -28,6 +28,7 @@ EXEC_DENSE_REDUCED_ORDER = 32
 EXEC_GRAPH_REDUCED_ORDER = 64
 EXEC_SEPARATE_STATS = 128
 EXEC_MFMA_REDUCED_SOLVE = 256
+EXEC_ONE_VIEW_PER_PASS = 512
 
 E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
            -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM", -7: "TSCM_E_PEER"}
