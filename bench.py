@@ -524,6 +524,9 @@ def main():
                        "iterations_per_solve": ITERS_PER_SOLVE, "parallelism": f"frames sharded over {world} GPU(s)" if exchange != "ipc" or n_dev >= world
                                       else f"frames sharded over {world} rank processes on {n_dev} GPU(s) (IPC exchange: a run of the multi-process path, not a scaling measurement)"},
             "exchange": exchange if multi else None, "n_devices": None if stub else min(world, n_dev),
+            # which RCCL algorithm / protocol the operator pinned, if any (the redundant control step needs an all-reduce whose
+            # result does not depend on the rank -- ring and tree sums are; the rank-divergence guard stops the solve if one ever is not)
+            "rccl_env": ({k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO")} if multi and exchange == "rccl" else None),
             # (the IPC back-end between DEVICES -- fine-grained buffers, explicit peer access: ABI 6 -- has never met a second device)
             "exchange_note": ("IPC exchange across devices: correct by construction, never measured; RCCL is the production back-end"
                               if multi and exchange == "ipc" and not stub and min(world, n_dev) > 1 else None),
