@@ -446,6 +446,8 @@ def main():
         g4_passes = -(-full.n_points // 56)
         g4_ks = -(-(-(-full.n_points // g4_passes)) // 4)
         g4_name = f"k_eval_gram4<{g4_ks},{'true' if g4_passes > 1 else 'false'}>"
+        if g4_passes == 1 and g4_ks <= 8 and not (args.exec_flags & 512):      # boards of up to 32 corners: M views share a pass
+            g4_name = f"k_eval_gram4p<{g4_ks},{min(4, 16 // g4_ks)}>"
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS
         roof = {
