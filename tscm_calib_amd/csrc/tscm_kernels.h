@@ -1596,8 +1596,11 @@ struct RawTc {
 #define TSCM_SCHUR_OCC 2        // workgroups per CU the NV <= 2 instantiation that serves grids of several rounds is compiled for.  3 (round 6, measured): the
                                 // compiler meets 168 VGPRs with 196 bytes of scratch per lane and the kernel takes 63.7 us instead of 51.9 at config 5
 #endif
-template <int NV, bool RIDE = false>
-__global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
+// CB: boards of a chunk at most.  64, or 32 (round 6, an experiment: TSCM_SCHUR_CB=32 at create): half the W columns per thread
+// (96 -> 48 VGPRs at NV = 2), 167 registers without a spill, THREE workgroups per CU.  The same arithmetic per board and per
+// 4-board group; twice the workgroups and partial tiles.  Measured at config 5: 57.4 us against 52.3 -- not the default.
+template <int NV, bool RIDE = false, int CB = kChunkBoards>
+__global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : (CB == 32 ? 3 : TSCM_SCHUR_OCC)) : 1) void k_schur_gram(DevProblem P, DevState S, int chunk0, int ctl, int first_round, int ctl_epoch, int stats_target, int n_chunks)
 {
     TL_ONLY(KtlScope ktl_scope(3, ctl && !RIDE ? S.ctrl_snap : static_cast<const CtrlHead *>(S.ctrl));)     // (the snapshot: the writer workgroup advances S.ctrl while later rounds start)
     PHASE_STAMP(tsk);
@@ -1620,12 +1623,14 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
     // (one block, so that the control step in the head can borrow all of it: facl first, 16-byte aligned)
     // (round 6: the waves' partial tiles share the space of the E sums, which are dead behind phase 0b's barrier -- 53.2 KB instead of 74.8 at NV = 2: three workgroups per CU fit)
     struct __attribute__((aligned(16))) Lds {
-        double facl[kChunkBoards][kFac];
-        union { double sumE[kChunkBoards][NE]; double tiles[4][NT][256]; double head_rest[256 * kMaxCamLds + kScal + 8 + 512 * kMaxCamLds + 256 - kChunkBoards * kFac]; };      // (head_rest: what the control step in the head borrows beyond facl)
+        static_assert(CB == 64 || CB == 32, "four waves x (CB / 16) groups of four boards");
+        double facl[CB][kFac];
+        union { double sumE[CB][NE]; double tiles[4][NT][256]; double head_rest[256 * kMaxCamLds + kScal + 8 + 512 * kMaxCamLds + 256 - CB * kFac]; };      // (head_rest: what the control step in the head borrows beyond facl)
     };
     __shared__ Lds lds_blk;
-    double (&sumE)[kChunkBoards][NE] = lds_blk.sumE;
-    double (&facl)[kChunkBoards][kFac] = lds_blk.facl;
+    double (&sumE)[CB][NE] = lds_blk.sumE;
+    double (&facl)[CB][kFac] = lds_blk.facl;
+    constexpr int NG = CB / 16;                     // passes of 16 boards in phase 0a = groups of four boards per wave in phase 1
     double (&tiles)[4][NT][256] = lds_blk.tiles;
     const int chunk = chunk0 + cblk;
     const int tid = threadIdx.x;
@@ -1633,8 +1638,8 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
     const int a = lane & 15, kq = lane >> 4;
     const int c0 = desc.x, nbd = desc.y - desc.x, slot0 = desc.z;       // boards c0 .. c0 + nbd - 1 (<= kChunkBoards), views at slots slot0 + NV * i
     constexpr unsigned BAD = 0xffffe000u;
-    double ev[4][NJ];
-    double w[4][NV][6];
+    double ev[NG][NJ];
+    double w[NG][NV][6];
     // the boards of a chunk share their camera set: the rotation of view p's camera is chunk-uniform
     const double *Rcp[NV];
     auto request = [&](int cur_) {
@@ -1655,7 +1660,7 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
                                      : 8u * (unsigned)(kRecW * pv + 6 * (kWcolTc + r9 / 3) + 3 + r9 % 3);
                 const unsigned per_slot = idx < 18 ? 8u * kRecE : 8u * kRecW;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NG; ++i) {
                     const int bf = 16 * i + (tid >> 4);
                     const unsigned o0 = idx < NE ? first + per_slot * (unsigned)(slot0 + NV * min(bf, nbd - 1)) : BAD;
                     double acc = 0.0;
@@ -1666,8 +1671,8 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int bg = 16 * wave + 4 * g + kq;
+        for (int g = 0; g < NG; ++g) {
+            const int bg = 4 * NG * wave + 4 * g + kq;
             const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + 6u * (unsigned)a) : BAD;
 #pragma unroll
             for (int p = 0; p < NV; ++p)
@@ -1725,7 +1730,7 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
     if (ctl) {
         constexpr int kHl = 256 * kMaxCamLds + kScal + 8, kGall = 512 * kMaxCamLds;
         static_assert(sizeof(Lds) / sizeof(double) >= kHl + kGall + 256, "finish_evaluation's LDS (C <= 8) fits the kernel's block");
-        static_assert(kChunkBoards * kFac >= kHl + 256, "control_outcome's LDS fits the factor records' space");
+        static_assert(sizeof(Lds) / sizeof(double) >= kHl + 256, "control_outcome's LDS fits the kernel's block");
         __shared__ CtlOut s_ctl;
         double *scratch = reinterpret_cast<double *>(&lds_blk);
         // The LM state comes from the SNAPSHOT the reductions' launch took (k_reduce_stats): the extra workgroup of THIS
@@ -1850,7 +1855,7 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
                                      : 8u * (unsigned)(kRecW * pv + 6 * (kWcolTc + r9 / 3) + 3 + r9 % 3);
                 const unsigned per_slot = idx < 18 ? 8u * kRecE : 8u * kRecW;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NG; ++i) {
                     const int bf = 16 * i + (tid >> 4);
                     const unsigned o0 = idx < NE ? first + per_slot * (unsigned)(slot0 + NV * min(bf, nbd - 1)) : BAD;
                     double acc = 0.0;
@@ -1861,8 +1866,8 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int bg = 16 * wave + 4 * g + kq;
+        for (int g = 0; g < NG; ++g) {
+            const int bg = 4 * NG * wave + 4 * g + kq;
             const unsigned base = (a < 14 && bg < nbd) ? 8u * ((unsigned)kRecW * (unsigned)(slot0 + NV * bg) + 6u * (unsigned)a) : BAD;
 #pragma unroll
             for (int p = 0; p < NV; ++p)
@@ -1883,7 +1888,7 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
     {
         const int e = tid & 15, grp = tid >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NG; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) if (e + 16 * j < NE) sumE[16 * i + grp][e + 16 * j] = ev[i][j];
     }
@@ -1918,9 +1923,9 @@ __global__ __launch_bounds__(256, NV <= 2 ? (RIDE ? 2 : TSCM_SCHUR_OCC) : 1) voi
     for (int t = 0; t < NT; ++t) acc[t] = d4{ 0.0, 0.0, 0.0, 0.0 };
     const bool grad_col = a == kFR;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (16 * wave + 4 * g >= nbd) break;                              // wave-uniform
-        const int bg = 16 * wave + 4 * g + kq;
+    for (int g = 0; g < NG; ++g) {
+        if (4 * NG * wave + 4 * g >= nbd) break;                          // wave-uniform
+        const int bg = 4 * NG * wave + 4 * g + kq;
         const bool valid = bg < nbd;
         const int bl = min(bg, nbd - 1);
         FacFwd F;

@@ -167,6 +167,7 @@ struct tscm_solver {
     bool ctl_in_schur = false;          // this solve: the control step of a candidate's evaluation is taken in the head of the next k_schur_gram
     int schur_resident_ride[4] = { 0, 0, 0, 0 };   // ... of k_schur_gram<NV, true>
     int schur_resident[4] = { 0, 0, 0, 0 };   // workgroups of k_schur_gram<NV> that are resident at once (occupancy x CUs): the first round of its grid
+    int schur_cb = kChunkBoards;        // boards per chunk at most: 32 where the Schur grid has several rounds anyway (k_schur_gram<NV, false, 32>: three workgroups per CU)
     int ctl_epoch = 0;                  // control steps taken in k_schur_gram's head in this solve so far
     bool stats_ride = false;            // this solve: the reductions behind a candidate's evaluation are the first workgroups of the next k_schur_gram (k_schur_gram<NV, true>)
     int stats_epoch = 0;                // launches of k_schur_gram<NV, true> in this solve so far (S.ctl_pub->stats_arrived counts their reduction workgroups)
@@ -652,9 +653,21 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[1], reinterpret_cast<const void *>(k_schur_gram<1, true>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[2], reinterpret_cast<const void *>(k_schur_gram<2, true>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[3], reinterpret_cast<const void *>(k_schur_gram<3, true>), 256, 0));
+        // Round 6, an experiment switch (TSCM_SCHUR_CB=32 in the environment at create): chunks of 32 boards and k_schur_gram<NV, false, 32>
+        // at THREE workgroups per CU (167 registers, no spill) -- the occupancy the round-5 analysis asked for.  Measured at config 5:
+        // 57.4 us against 52.3 with 64-board chunks at two per CU (twice the workgroups, each with its head, its control outcome and
+        // its four barriers): not the default (HISTORY A.7).
+        {
+            const char *e = std::getenv("TSCM_SCHUR_CB");
+            s->schur_cb = e && std::atoi(e) == 32 ? 32 : kChunkBoards;
+        }
+        if (s->schur_cb == 32) {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[1], reinterpret_cast<const void *>(k_schur_gram<1, false, 32>), 256, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[2], reinterpret_cast<const void *>(k_schur_gram<2, false, 32>), 256, 0));
+        }
         for (int nv = 1; nv <= 3; ++nv) { s->schur_resident[nv] *= prop.multiProcessorCount; s->schur_resident_ride[nv] *= prop.multiProcessorCount; }
         lap(4);
-        const int per_bchunk = std::min<int>(kChunkBoards, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
+        const int per_bchunk = std::min<int>(s->schur_cb, std::max<int>(16, (int)((fast_boards + target_bchunks - 1) / target_bchunks)));
         size_t i = 0;
         while (i < order_b.size()) {
             size_t e = i + 1;
@@ -780,7 +793,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
             if (s->nv_chunks[nv]++ == 0) s->nv_chunk0[nv] = (int)c;
             max_boards = std::max(max_boards, bchunks[c].end - bchunks[c].begin);
         }
-        if (max_boards > kChunkBoards) return fail(TSCM_E_UNSUPPORTED, "internal error: board chunk larger than kChunkBoards");
+        if (max_boards > s->schur_cb) return fail(TSCM_E_UNSUPPORTED, "internal error: board chunk larger than the Schur kernels' chunk size");
         s->lds_gram = 0;
         // groups of 16 boards while they all fit the chip at once (5 workgroups per CU), groups of 32 beyond that
         s->bs_threads = (B + 15) / 16 > 5 * std::max(1, prop.multiProcessorCount) * 3 / 2 ? 256 : 128;
@@ -1342,8 +1355,10 @@ static int enqueue_iteration(LmRun &run, int iteration)
             if (s->nv_chunks[2]) hipLaunchKernelGGL((k_schur_gram<2, true>), dim3(std::max(ns, s->nv_chunks[2]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], (ctl & 7) | (s->withhold == 2 ? 16 : 0), s->schur_resident_ride[2], ce, target, s->nv_chunks[2]);
             if (s->nv_chunks[3]) hipLaunchKernelGGL((k_schur_gram<3, true>), dim3(std::max(ns, s->nv_chunks[3]) + 1), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], (ctl & 7) | (s->withhold == 2 ? 16 : 0), s->schur_resident_ride[3], ce, target, s->nv_chunks[3]);
         } else {
-            if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0, s->nv_chunks[1]);
-            if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0, s->nv_chunks[2]);
+            if (s->nv_chunks[1] && s->schur_cb == 32) hipLaunchKernelGGL((k_schur_gram<1, false, 32>), dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0, s->nv_chunks[1]);
+            else if (s->nv_chunks[1]) hipLaunchKernelGGL(k_schur_gram<1>, dim3(s->nv_chunks[1] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[1], ctl, s->schur_resident[1], ce, 0, s->nv_chunks[1]);
+            if (s->nv_chunks[2] && s->schur_cb == 32) hipLaunchKernelGGL((k_schur_gram<2, false, 32>), dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0, s->nv_chunks[2]);
+            else if (s->nv_chunks[2]) hipLaunchKernelGGL(k_schur_gram<2>, dim3(s->nv_chunks[2] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[2], ctl, s->schur_resident[2], ce, 0, s->nv_chunks[2]);
             if (s->nv_chunks[3]) hipLaunchKernelGGL(k_schur_gram<3>, dim3(s->nv_chunks[3] + (ctl ? 1 : 0)), dim3(256), s->lds_gram, s->stream, P, S, s->nv_chunk0[3], ctl, s->schur_resident[3], ce, 0, s->nv_chunks[3]);
         }
         if (P.n_pchunks) hipLaunchKernelGGL(k_pair_gram, dim3(P.n_pchunks), dim3(256), 0, s->stream, P, S);
