@@ -327,6 +327,34 @@ def test_ragged_views_and_missing_detections(hip_device):
     assert np.all(pg.board_rt[2] == p.board_rt[2])       # untouched parameter block
 
 
+def test_observation_arrays_with_gaps_and_in_any_view_order(hip_device):
+    """tscm_problem.view_offset is the caller's: views may sit anywhere in obs_u / obs_v.  Round 6 uploads the arrays as they are and
+    gathers on the device when they are reasonably dense, and gathers on the host when the table leaves them sparse (more than twice
+    the corners): both against the contiguous layout, bit for bit -- plus tscm_solver_create_timing's split."""
+    p = H.small_rig(4, 10, seed=8).normalised()
+    n, V = p.n_points, p.n_views
+    ref = p.copy().normalised()
+    sr = api.calibrate(ref)
+    rng = np.random.default_rng(3)
+    for stride in (n + 5, 3 * n + 1):                       # dense enough for the device gather | sparse: the host gather
+        q = p.copy()
+        order = rng.permutation(V)                          # view v lives at slot order[v]
+        u = np.full(V * stride + 7, 1e300)
+        w = np.full(V * stride + 7, -1e300)
+        off = (7 + order * stride).astype(np.int32)
+        for v in range(V):
+            u[off[v]:off[v] + n] = p.obs_u[p.view_offset[v]:p.view_offset[v] + n]
+            w[off[v]:off[v] + n] = p.obs_v[p.view_offset[v]:p.view_offset[v] + n]
+        q.obs_u, q.obs_v, q.view_offset = u, w, off
+        q = q.normalised()
+        with api.Solver(q) as s:
+            t = s.create_timing()
+            assert set(t) == {"runtime_init", "host_layout", "gather", "h2d", "kernel_setup"} and all(x >= 0 for x in t.values()) and sum(t.values()) > 0
+            sq = s.solve()
+        assert sq["iterations"] == sr["iterations"]
+        assert np.array_equal(q.intr, ref.intr) and np.array_equal(q.cam_rt, ref.cam_rt) and np.array_equal(q.board_rt, ref.board_rt)
+
+
 def test_big_board_more_than_64_corners(hip_device):
     """11x8 = 88 corners per view (the author's own board: main.cpp:191) -> two 64-corner passes."""
     p = synth.make_problem(4, 6, 17, cols=11, rows=8, pitch=30.0)

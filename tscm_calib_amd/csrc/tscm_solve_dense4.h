@@ -285,103 +285,194 @@ __global__ __launch_bounds__((G * G + 63) / 64 * 64, FUSED ? 3 : 1) void k_solve
             for (int c = 0; c < TS; ++c) Lm[(N48 - 1) * LD + TS * cj + c] = a[0][c];
         }
         __syncthreads();
-        if (tid < 64) {
-            const int lane = tid, col = lane & 15, kq = lane >> 4;
-            const int n_act = P.n_act;
-            auto ld_tile = [&](int I, int Jc) { d4 v; for (int r = 0; r < 4; ++r) v[r] = Lm[(16 * I + kq + 4 * r) * LD + 16 * Jc + col]; return v; };
-            d4 acc00 = ld_tile(0, 0), acc10 = ld_tile(1, 0), acc20 = ld_tile(2, 0), acc11 = ld_tile(1, 1), acc21 = ld_tile(2, 1), acc22 = ld_tile(2, 2);
-            double *Pn = Xb;                                   // [48][4]: the panel's columns, row-major
-            const int row = min(lane, N48 - 1);
-            int fail = 0;
-            auto dump = [&](const d4 &v, int I, int pc) {
+        // Two waves share the factorisation (the first version had ONE wave do everything: 2,270 clocks per panel against the tile
+        // kernel's 2,100 -- the 4 x 4 diagonal factor's four rsq chains sat on the critical path of a wave with nothing else to issue):
+        //   wave 0  holds the six tiles.  Per panel: dump the panel's columns (and the NEXT panel's diagonal block as it stands) to LDS,
+        //           barrier, take its row and the READY factor L_kk, solve the row, write it back row-major (the factor the
+        //           back-substitution reads, and -- fetched as lane (row, k) -- the MFMA operand), one MFMA per live tile;
+        //   wave 3  is the look-ahead: behind the same barrier it takes the four rows below the diagonal block from the dump, brings the
+        //           next diagonal block up to date (x = a L_kk^-T, t = d - x x^T) and factors it -- the operations of the tile kernel's
+        //           look-ahead thread, on every lane -- while wave 0 solves and updates.  ONE workgroup barrier per panel.
+        const int lane = tid & 63, wv = tid >> 6, col = lane & 15, kq = lane >> 4;
+        const int n_act = P.n_act;
+        double *PnB = Xb;                                      // [2][48][4]  the panel's columns, row-major, by parity of the panel
+        double *DnB = Xb + 2 * 4 * N48;                        // [2][16]     the next panel's diagonal block, updated through the panel before
+        double *LkB = DnB + 32;                                // [2][20]     L_kk (row-major, lower) and 1 / diag of the panel
+        static_assert(2 * 4 * N48 + 32 + 40 <= 2 * G * XT, "the panel buffers fit the space of the tile kernel's panel column");
+        int fail = 0;
+        // Cholesky of a 4 x 4 block (lower part of t) as factor_diag does it; columns past the last free one are identity
+        auto factor4 = [&](double (&t)[4][4], int tk, double *Lk) {
+            double il[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Pn[(16 * I + kq + 4 * r) * 4 + pc] = v[r];
-            };
-            auto step = [&](auto Jtag, int q) {
-                constexpr int J = decltype(Jtag)::value;
-                const int tk = 4 * J + q;                      // panel: columns 4 tk .. 4 tk + 3 = columns 4 q .. of tile column J
-                wave_lds_fence();                              // (the previous panel's reads of Pn are done)
-                if ((col >> 2) == q) {
-                    const int pc = col & 3;
-                    if constexpr (J == 0) { dump(acc00, 0, pc); dump(acc10, 1, pc); dump(acc20, 2, pc); }
-                    if constexpr (J == 1) { dump(acc11, 1, pc); dump(acc21, 2, pc); }
-                    if constexpr (J == 2) { dump(acc22, 2, pc); }
+            for (int c = 0; c < 4; ++c) {
+                const bool real = 4 * tk + c < n_act;
+                double d = t[c][c];
+#pragma unroll
+                for (int u = 0; u < c; ++u) d -= t[c][u] * t[c][u];
+                if (real && !(d > 0.0)) { fail = 1; d = 1.0; }
+                if (!real) d = 1.0;
+                const double isd = fast_rsqrt(d);
+                t[c][c] = d * isd; il[c] = isd;
+#pragma unroll
+                for (int r = c + 1; r < 4; ++r) {
+                    double v = t[r][c];
+#pragma unroll
+                    for (int u = 0; u < c; ++u) v -= t[r][u] * t[c][u];
+                    t[r][c] = real ? v * isd : 0.0;
                 }
-                wave_lds_fence();
-                // my row of the panel and the diagonal block
-                const d2 a01 = *reinterpret_cast<const d2 *>(Pn + 4 * row), a23 = *reinterpret_cast<const d2 *>(Pn + 4 * row + 2);
-                double D[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const d2 u = *reinterpret_cast<const d2 *>(Pn + 4 * (4 * tk + i)), v = *reinterpret_cast<const d2 *>(Pn + 4 * (4 * tk + i) + 2);
-                    D[i][0] = u[0]; D[i][1] = u[1]; D[i][2] = v[0]; D[i][3] = v[1];
-                }
-                double l[4][4], il[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool real = 4 * tk + c < n_act;
-                    double d = D[c][c];
-#pragma unroll
-                    for (int u = 0; u < c; ++u) d -= l[c][u] * l[c][u];
-                    if (real && !(d > 0.0)) { fail = 1; d = 1.0; }
-                    if (!real) d = 1.0;
-                    const double isd = fast_rsqrt(d);
-                    l[c][c] = d * isd; il[c] = isd;
-#pragma unroll
-                    for (int r = c + 1; r < 4; ++r) {
-                        double v = D[r][c];
-#pragma unroll
-                        for (int u = 0; u < c; ++u) v -= l[r][u] * l[c][u];
-                        l[r][c] = real ? v * isd : 0.0;
-                    }
-                }
-                const double a4[4] = { a01[0], a01[1], a23[0], a23[1] };
-                double x[4];
-                const int rel = row - 4 * tk;                  // < 0: a row that is finished; 0..3: a row of the diagonal block
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    double v = a4[c];
-#pragma unroll
-                    for (int u = 0; u < c; ++u) v -= x[u] * l[c][u];
-                    x[c] = (rel < 0 || (rel < 4 && c > rel)) ? 0.0 : v * il[c];
-                }
-                if (lane < N48) {
-                    *reinterpret_cast<d2 *>(Lm + row * LD + 4 * tk) = d2{ x[0], x[1] };
-                    *reinterpret_cast<d2 *>(Lm + row * LD + 4 * tk + 2) = d2{ x[2], x[3] };
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) idg[4 * tk + c] = il[c];
-                }
-                if (lane == N48 - 1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) wp[4 * tk + c] = 4 * tk + c < n_act ? x[c] : 0.0;
-                }
-                wave_lds_fence();
-                // the rows as MFMA operands: lane (r, k) <- X[16 I + r][k]; the update A_IJ -= X_I X_J^T of every tile still alive
-                double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-                if constexpr (J == 0) x0 = Lm[(col) * LD + 4 * tk + kq];
-                if constexpr (J <= 1) x1 = Lm[(16 + col) * LD + 4 * tk + kq];
-                x2 = Lm[(32 + col) * LD + 4 * tk + kq];
-                if constexpr (J == 0) {
-                    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0, x0, acc00, 0, 0, 0);
-                    acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, x0, acc10, 0, 0, 0);
-                    acc20 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x0, acc20, 0, 0, 0);
-                }
-                if constexpr (J <= 1) {
-                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, x1, acc11, 0, 0, 0);
-                    acc21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x1, acc21, 0, 0, 0);
-                }
-                acc22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x2, acc22, 0, 0, 0);
-            };
-            for (int tk = 0; tk < NP; ++tk) {
-                const int q = tk & 3;
-                if (tk < 4) step(std::integral_constant<int, 0>{}, q);
-                else if (tk < 8) step(std::integral_constant<int, 1>{}, q);
-                else step(std::integral_constant<int, 2>{}, q);
             }
-            if (fail) s_fail = 1;
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    idg[4 * tk + r] = il[r]; Lk[16 + r] = il[r];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Lk[4 * r + c] = c <= r ? t[r][c] : 0.0;
+                }
+            }
+        };
+        d4 acc00 = { 0, 0, 0, 0 }, acc10 = acc00, acc20 = acc00, acc11 = acc00, acc21 = acc00, acc22 = acc00;
+        if (wv == 0) {
+            auto ld_tile = [&](int I, int Jc) { d4 v; for (int r = 0; r < 4; ++r) v[r] = Lm[(16 * I + kq + 4 * r) * LD + 16 * Jc + col]; return v; };
+            acc00 = ld_tile(0, 0); acc10 = ld_tile(1, 0); acc20 = ld_tile(2, 0); acc11 = ld_tile(1, 1); acc21 = ld_tile(2, 1); acc22 = ld_tile(2, 2);
+        } else if (wv == 3) {
+            double t[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[r][c] = Lm[r * LD + c];
+            factor4(t, 0, LkB);
         }
+        const int row = min(lane, N48 - 1);
+        auto dump = [&](double *Pn, const d4 &v, int I, int pc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pn[(16 * I + kq + 4 * r) * 4 + pc] = v[r];
+        };
+        // wave 0, in front of the barrier: the panel's columns and the next panel's diagonal block
+        auto dump_step = [&](auto Jtag, int q) {
+            constexpr int J = decltype(Jtag)::value;
+            const int tk = 4 * J + q;
+            double *Pn = PnB + (tk & 1) * 4 * N48, *Dn = DnB + (tk & 1) * 16;
+            if ((col >> 2) == q) {
+                const int pc = col & 3;
+                if constexpr (J == 0) { dump(Pn, acc00, 0, pc); dump(Pn, acc10, 1, pc); dump(Pn, acc20, 2, pc); }
+                if constexpr (J == 1) { dump(Pn, acc11, 1, pc); dump(Pn, acc21, 2, pc); }
+                if constexpr (J == 2) { dump(Pn, acc22, 2, pc); }
+            }
+            // block rows / columns 4 (tk + 1) ..: register q + 1 of tile (J, J), lanes of columns 4 (q + 1) ..; across a tile
+            // boundary (q = 3) register 0 of tile (J + 1, J + 1), columns 0 .. 3
+            const int qn = (q + 1) & 3;
+            if ((col >> 2) == qn) {
+                double v = 0.0;
+                if constexpr (J == 0) v = q == 0 ? acc00[1] : q == 1 ? acc00[2] : q == 2 ? acc00[3] : acc11[0];
+                if constexpr (J == 1) v = q == 0 ? acc11[1] : q == 1 ? acc11[2] : q == 2 ? acc11[3] : acc22[0];
+                if constexpr (J == 2) v = q == 0 ? acc22[1] : q == 1 ? acc22[2] : acc22[3];
+                Dn[4 * kq + (col & 3)] = v;
+            }
+        };
+        // wave 0, behind the barrier: my row of the panel with the ready factor, then the update
+        auto solve_step = [&](auto Jtag, int q) {
+            constexpr int J = decltype(Jtag)::value;
+            const int tk = 4 * J + q;
+            const double *Pn = PnB + (tk & 1) * 4 * N48, *Lk = LkB + (tk & 1) * 20;
+            const d2 a01 = *reinterpret_cast<const d2 *>(Pn + 4 * row), a23 = *reinterpret_cast<const d2 *>(Pn + 4 * row + 2);
+            double l[4][4], il[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const d2 u = *reinterpret_cast<const d2 *>(Lk + 4 * r), v = *reinterpret_cast<const d2 *>(Lk + 4 * r + 2);
+                l[r][0] = u[0]; l[r][1] = u[1]; l[r][2] = v[0]; l[r][3] = v[1];
+            }
+            { const d2 u = *reinterpret_cast<const d2 *>(Lk + 16), v = *reinterpret_cast<const d2 *>(Lk + 18); il[0] = u[0]; il[1] = u[1]; il[2] = v[0]; il[3] = v[1]; }
+            const double a4[4] = { a01[0], a01[1], a23[0], a23[1] };
+            double x[4];
+            const int rel = row - 4 * tk;                  // < 0: a row that is finished; 0..3: a row of the diagonal block
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double v = a4[c];
+#pragma unroll
+                for (int u = 0; u < c; ++u) v -= x[u] * l[c][u];
+                x[c] = (rel < 0 || (rel < 4 && c > rel)) ? 0.0 : v * il[c];
+            }
+            if (lane < N48) {
+                *reinterpret_cast<d2 *>(Lm + row * LD + 4 * tk) = d2{ x[0], x[1] };
+                *reinterpret_cast<d2 *>(Lm + row * LD + 4 * tk + 2) = d2{ x[2], x[3] };
+            }
+            if (lane == N48 - 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wp[4 * tk + c] = 4 * tk + c < n_act ? x[c] : 0.0;
+            }
+            wave_lds_fence();
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            if constexpr (J == 0) x0 = Lm[(col) * LD + 4 * tk + kq];
+            if constexpr (J <= 1) x1 = Lm[(16 + col) * LD + 4 * tk + kq];
+            x2 = Lm[(32 + col) * LD + 4 * tk + kq];
+            if constexpr (J == 0) {
+                acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0, x0, acc00, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, x0, acc10, 0, 0, 0);
+                acc20 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x0, acc20, 0, 0, 0);
+            }
+            if constexpr (J <= 1) {
+                acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1, x1, acc11, 0, 0, 0);
+                acc21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x1, acc21, 0, 0, 0);
+            }
+            acc22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2, x2, acc22, 0, 0, 0);
+        };
+        // wave 3, behind the barrier of panel tk: the diagonal block of panel tk + 1 (the tile kernel's look-ahead thread)
+        auto lookahead = [&](int tk) {
+            const double *Pn = PnB + (tk & 1) * 4 * N48, *Dn = DnB + (tk & 1) * 16, *Lk = LkB + (tk & 1) * 20;
+            double araw[4][4], dt[4][4], f[4][4], fil[4], x[4][4], t[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const d2 a = *reinterpret_cast<const d2 *>(Pn + 4 * (4 * tk + 4 + r)), b = *reinterpret_cast<const d2 *>(Pn + 4 * (4 * tk + 4 + r) + 2);
+                araw[r][0] = a[0]; araw[r][1] = a[1]; araw[r][2] = b[0]; araw[r][3] = b[1];
+                const d2 c = *reinterpret_cast<const d2 *>(Dn + 4 * r), d = *reinterpret_cast<const d2 *>(Dn + 4 * r + 2);
+                dt[r][0] = c[0]; dt[r][1] = c[1]; dt[r][2] = d[0]; dt[r][3] = d[1];
+                const d2 u = *reinterpret_cast<const d2 *>(Lk + 4 * r), v = *reinterpret_cast<const d2 *>(Lk + 4 * r + 2);
+                f[r][0] = u[0]; f[r][1] = u[1]; f[r][2] = v[0]; f[r][3] = v[1];
+            }
+            { const d2 u = *reinterpret_cast<const d2 *>(Lk + 16), v = *reinterpret_cast<const d2 *>(Lk + 18); fil[0] = u[0]; fil[1] = u[1]; fil[2] = v[0]; fil[3] = v[1]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double v = araw[r][c];
+#pragma unroll
+                    for (int u = 0; u < c; ++u) v -= x[r][u] * f[c][u];
+                    x[r][c] = v * fil[c];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    double v = dt[r][c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v -= x[r][u] * x[c][u];
+                    t[r][c] = v;
+                }
+            factor4(t, tk + 1, LkB + ((tk + 1) & 1) * 20);
+        };
+        PH_ONLY(long long mf_t[6] = { 0, 0, 0, 0, 0, 0 };)
+        for (int tk = 0; tk < NP; ++tk) {
+            const int q = tk & 3;
+            PH_ONLY(if (tk == 1 || tk == 9) mf_t[0] = clock64();)
+            if (wv == 0) {
+                if (tk < 4) dump_step(std::integral_constant<int, 0>{}, q);
+                else if (tk < 8) dump_step(std::integral_constant<int, 1>{}, q);
+                else dump_step(std::integral_constant<int, 2>{}, q);
+            }
+            PH_ONLY(if (tk == 1 || tk == 9) mf_t[1] = clock64();)
+            __syncthreads();
+            PH_ONLY(if (tk == 1 || tk == 9) mf_t[2] = clock64();)
+            if (wv == 0) {
+                if (tk < 4) solve_step(std::integral_constant<int, 0>{}, q);
+                else if (tk < 8) solve_step(std::integral_constant<int, 1>{}, q);
+                else solve_step(std::integral_constant<int, 2>{}, q);
+                PH_ONLY(if (tk == 1 || tk == 9) { mf_t[3] = clock64(); asm volatile("" : "+v"(acc22[0])); mf_t[4] = clock64(); if (lane == 0) printf("  MF panel %d wave0: dump %lld  barrier %lld  solve+operands+mfma issue %lld  mfma done %lld\n", tk, mf_t[1] - mf_t[0], mf_t[2] - mf_t[1], mf_t[3] - mf_t[2], mf_t[4] - mf_t[3]); })
+            } else if (wv == 3 && tk + 1 < NP) {
+                lookahead(tk);
+                PH_ONLY(if (tk == 1 || tk == 9) { mf_t[3] = clock64(); if (lane == 0) printf("  MF panel %d wave3: look-ahead %lld\n", tk, mf_t[3] - mf_t[2]); })
+            }
+        }
+        if (fail) s_fail = 1;
         __syncthreads();
     } else {
     // ---- factorisation: one barrier per panel, diagonal tiles factored one panel ahead ---------------------
