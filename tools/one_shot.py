@@ -1,3 +1,7 @@
+"""What ONE call of the drop-in costs its caller (multi_calib.cpp:157-218: problem build + ceres::Solve): three creates of a solver on
+BASELINE config <n> (the first is the process's cold one: HIP's own start-up sits in runtime_init), each with the split of
+tscm_solver_create_timing, then one warm api.calibrate = tscm_solve_multi (create + H2D + natural solve + write-back + destroy).
+GPU box: python tools/one_shot.py [config]   ->  profiles/r06_one_shot.json was assembled from its output."""
 import sys, time, json
 sys.path.insert(0, ".")
 from tscm_calib_amd import api, synth
