@@ -432,11 +432,14 @@ def main():
     one_shot = create_split = None
     if rank == 0 and world == 1 and not stub:
         create_split = solver.create_timing()
-        q1 = full.copy().normalised()
-        t1 = time.perf_counter()
-        r1 = api.refinement(q1, device, **extra)[1] if full.mono else api.calibrate(q1, device, **extra)
-        one_shot = {"seconds": time.perf_counter() - t1, "solve_seconds": r1["seconds_total"], "iterations": r1["num_iterations"] - 1,
-                    "note": "warm call of tscm_solve_multi / _mono: create + H2D + natural solve + write-back + destroy"}
+        shots = []
+        for _ in range(2):                                   # (the first call also faults in the pages of its freshly copied input arrays)
+            q1 = full.copy().normalised()
+            t1 = time.perf_counter()
+            r1 = api.refinement(q1, device, **extra)[1] if full.mono else api.calibrate(q1, device, **extra)
+            shots.append(time.perf_counter() - t1)
+        one_shot = {"seconds": shots[1], "first_call_seconds": shots[0], "solve_seconds": r1["seconds_total"], "iterations": r1["num_iterations"] - 1,
+                    "note": "warm call of tscm_solve_multi / _mono: create + H2D + natural solve + write-back + destroy (next to the bench's own resident solver)"}
 
     if rank == 0:
         avg_ms = kms / max(launches, 1)
