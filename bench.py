@@ -446,8 +446,11 @@ def main():
         flops = n_local * FLOP_PER_CORNER
         bytes_per_corner = 16.0 + 168.0 / full.n_points
         # k_eval_gram4<KS, MULTI>: ceil(n / 56) passes per view of KS k-steps each (tscm_eval_gram4.h: g4_plan)
-        g4_passes = -(-full.n_points // 56)
-        g4_ks = -(-(-(-full.n_points // g4_passes)) // 4)
+        for cap in (16, 14):                                   # (g4_plan, tscm_kernels.h: 64-row passes where the LDS admits four workgroups per CU)
+            g4_passes = max(1, -(-full.n_points // (4 * cap)))
+            g4_ks = max(1, -(-(-(-full.n_points // g4_passes)) // 4))
+            if g4_ks <= 14 or 32 * (max(68 * g4_ks, 512) + 2 * full.n_points) <= 40 * 1024:
+                break
         g4_name = f"k_eval_gram4<{g4_ks},{'true' if g4_passes > 1 else 'false'}>"
         if g4_passes == 1 and g4_ks <= 8 and not (args.exec_flags & 512):      # boards of up to 32 corners: M views share a pass
             g4_name = f"k_eval_gram4p<{g4_ks},{min(4, 16 // g4_ks)}>"

@@ -586,7 +586,7 @@ def test_gram_on_4x4_blocks_and_on_the_16x16_tile_agree_bit_for_bit(hip_device, 
     assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
 
 
-@pytest.mark.parametrize("cols,rows", [(11, 8), (8, 6), (6, 5), (7, 6), (9, 7), (12, 9), (14, 10), (17, 12), (5, 4), (3, 3), (2, 2), (19, 3), (8, 7)])
+@pytest.mark.parametrize("cols,rows", [(11, 8), (8, 6), (6, 5), (7, 6), (9, 7), (12, 9), (14, 10), (17, 12), (5, 4), (3, 3), (2, 2), (19, 3), (8, 7), (8, 8), (13, 9), (10, 6)])
 def test_gram4_serves_every_board_size_with_the_bits_of_the_16x16_tile(hip_device, cols, rows):
     """Round 6: k_eval_gram4<KS, MULTI> is the default for EVERY board (rounds 3-5: 49..56 corners only) -- ceil(n / 4)
     k-steps for boards of up to 56 corners, ceil(n / 56) balanced passes of a multiple of four corners above that (the

@@ -61,7 +61,7 @@ __host__ __device__ inline int eval_f32_lds_doubles(int n_points, int ks)
 template <int KS, bool MULTI>
 __global__ __launch_bounds__(256, TSCM_F32_WGS) void k_eval_gram_f32(DevProblem P, DevState S, int cand)
 {
-    static_assert(KS >= 1 && KS <= kG4MaxKS, "a pass holds at most 56 rows");
+    static_assert(KS >= 1 && KS <= kG4MaxKS, "a pass holds at most 64 rows");
     // the control block is read together with the static chunk tables (one memory round trip, not two);
     // the early exit is taken right before the first view
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;

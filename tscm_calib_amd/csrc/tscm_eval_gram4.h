@@ -115,7 +115,7 @@ __device__ __forceinline__ double quad_tb(double x, double c0, double c1, double
 template <int KS, bool MULTI>
 __global__ __launch_bounds__(256, 4) void k_eval_gram4(DevProblem P, DevState S, int cand)
 {
-    static_assert(KS >= 1 && KS <= kG4MaxKS, "a pass holds at most 56 rows");
+    static_assert(KS >= 1 && KS <= kG4MaxKS, "a pass holds at most 64 rows");
     constexpr int kTile = g4_tile_doubles(KS);
     KTL(0);
     const int ctrl_done = S.ctrl->done, ctrl_cur = S.ctrl->cur;

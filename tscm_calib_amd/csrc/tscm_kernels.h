@@ -868,17 +868,24 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram(DevProblem P, DevState S, 
 }
 
 // Pass plan of the Gram kernels k_eval_gram4 / k_eval_gram_f32 (round 6: every board size): a pass holds 4 KS <= 56 rows
-constexpr int kG4MaxKS = 14;                    // k-steps of a pass: at most 56 rows
-// pass plan of a board of n corners: ceil(n / 56) passes of `per` corners each (a multiple of four; the last pass takes what is left)
+constexpr int kG4MaxKS = 16;                    // k-steps of a pass: at most 64 rows (one per lane)
+// pass plan of a board of n corners: `passes` passes of `per` corners each (a multiple of four; the last pass takes what is left).
+// A pass may hold 64 rows (16 k-steps) where the kernel's LDS -- tile + board points, four waves -- still admits four workgroups per
+// CU, i.e. boards of up to 64 corners in ONE pass (8 x 8, 9 x 7: rounds 3-6a ran them as two half-empty passes of 32) and e.g. 117
+// corners in two; otherwise 56 rows (14 k-steps: the tile of the 9 x 6 kernel).
 struct G4Plan { int passes, per, ks; };
 __host__ __device__ inline G4Plan g4_plan(int n_points)
 {
     G4Plan g;
-    g.passes = (n_points + 4 * kG4MaxKS - 1) / (4 * kG4MaxKS);
-    if (g.passes < 1) g.passes = 1;
-    g.ks = ((n_points + g.passes - 1) / g.passes + 3) / 4;
-    if (g.ks < 1) g.ks = 1;
-    g.per = 4 * g.ks;
+    for (int cap = 16; cap >= 14; cap -= 2) {
+        g.passes = (n_points + 4 * cap - 1) / (4 * cap);
+        if (g.passes < 1) g.passes = 1;
+        g.ks = ((n_points + g.passes - 1) / g.passes + 3) / 4;
+        if (g.ks < 1) g.ks = 1;
+        g.per = 4 * g.ks;
+        const long tile = g.ks * 68 > 512 ? g.ks * 68 : 512;           // (g4_tile_doubles: tscm_eval_gram4.h)
+        if (g.ks <= 14 || 4 * 8 * (tile + 2L * n_points) <= 40 * 1024) break;      // four workgroups of four waves in 160 KB
+    }
     return g;
 }
 

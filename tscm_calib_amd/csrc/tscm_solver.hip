@@ -101,11 +101,11 @@ static EvalKernel g4_kernel(int ks, bool multi)
     static const EvalKernel single[kG4MaxKS] = {
         k_eval_gram4<1, false>, k_eval_gram4<2, false>, k_eval_gram4<3, false>, k_eval_gram4<4, false>, k_eval_gram4<5, false>,
         k_eval_gram4<6, false>, k_eval_gram4<7, false>, k_eval_gram4<8, false>, k_eval_gram4<9, false>, k_eval_gram4<10, false>,
-        k_eval_gram4<11, false>, k_eval_gram4<12, false>, k_eval_gram4<13, false>, k_eval_gram4<14, false> };
+        k_eval_gram4<11, false>, k_eval_gram4<12, false>, k_eval_gram4<13, false>, k_eval_gram4<14, false>, k_eval_gram4<15, false>, k_eval_gram4<16, false> };
     // several passes: ceil(n / passes) >= 29 corners per pass, i.e. at least 8 k-steps
     static const EvalKernel passes[kG4MaxKS] = {
         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k_eval_gram4<8, true>, k_eval_gram4<9, true>, k_eval_gram4<10, true>,
-        k_eval_gram4<11, true>, k_eval_gram4<12, true>, k_eval_gram4<13, true>, k_eval_gram4<14, true> };
+        k_eval_gram4<11, true>, k_eval_gram4<12, true>, k_eval_gram4<13, true>, k_eval_gram4<14, true>, k_eval_gram4<15, true>, k_eval_gram4<16, true> };
     return (multi ? passes : single)[ks - 1];
 }
 // boards of up to 32 corners: M = g4p_views(KS) views share a pass (k_eval_gram4p)
@@ -120,10 +120,10 @@ static EvalKernel f32_kernel(int ks, bool multi)     // the fp32-Jacobian tier o
     static const EvalKernel single[kG4MaxKS] = {
         k_eval_gram_f32<1, false>, k_eval_gram_f32<2, false>, k_eval_gram_f32<3, false>, k_eval_gram_f32<4, false>, k_eval_gram_f32<5, false>,
         k_eval_gram_f32<6, false>, k_eval_gram_f32<7, false>, k_eval_gram_f32<8, false>, k_eval_gram_f32<9, false>, k_eval_gram_f32<10, false>,
-        k_eval_gram_f32<11, false>, k_eval_gram_f32<12, false>, k_eval_gram_f32<13, false>, k_eval_gram_f32<14, false> };
+        k_eval_gram_f32<11, false>, k_eval_gram_f32<12, false>, k_eval_gram_f32<13, false>, k_eval_gram_f32<14, false>, k_eval_gram_f32<15, false>, k_eval_gram_f32<16, false> };
     static const EvalKernel passes[kG4MaxKS] = {
         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, k_eval_gram_f32<8, true>, k_eval_gram_f32<9, true>, k_eval_gram_f32<10, true>,
-        k_eval_gram_f32<11, true>, k_eval_gram_f32<12, true>, k_eval_gram_f32<13, true>, k_eval_gram_f32<14, true> };
+        k_eval_gram_f32<11, true>, k_eval_gram_f32<12, true>, k_eval_gram_f32<13, true>, k_eval_gram_f32<14, true>, k_eval_gram_f32<15, true>, k_eval_gram_f32<16, true> };
     return (multi ? passes : single)[ks - 1];
 }
 
