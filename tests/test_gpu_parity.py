@@ -648,6 +648,44 @@ def test_small_boards_share_a_pass_with_the_bits_of_one_view_per_pass(hip_device
             assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
 
 
+@pytest.mark.parametrize("cols,rows", [(7, 6), (8, 6), (7, 5), (9, 5), (10, 7), (11, 8), (9, 8), (13, 5), (12, 7)])
+def test_views_as_one_stream_of_k_steps_give_the_bits_of_one_view_per_pass(hip_device, cols, rows):
+    """k_eval_gram4s (round 6, an experiment: TSCM_G4_STREAM=1): a pass takes the next k-steps of the chunk's stream whichever views
+    they belong to (two at most), a view's accumulators are carried across passes.  Every view still contracts its own k-steps in order: bit-identical to one view
+    per pass (TSCM_EXEC_ONE_VIEW_PER_PASS) -- full and ragged views, an empty view, chunks longer than a metadata block (mono, 300
+    views), and against the oracle."""
+    import os
+    n = cols * rows
+    os.environ["TSCM_G4_STREAM"] = "1"          # (read at tscm_solver_create: the kernel is an opt-in experiment -- measured slower)
+    try:
+        _stream_cases(cols, rows, n)
+    finally:
+        del os.environ["TSCM_G4_STREAM"]
+
+
+def _stream_cases(cols, rows, n):
+    cases = [synth.make_problem(4, 10, 950 + n, cols=cols, rows=rows, pitch=360.0 / max(cols, rows))]
+    rng = np.random.default_rng(n)
+    q = cases[0].copy()
+    q.view_count[::3] = rng.integers(max(1, n // 3), n + 1, size=q.view_count[::3].shape[0])
+    q.view_count[0] = n - 1
+    q.view_count[7] = 0
+    cases.append(q)
+    cases.append(synth.make_problem(1, 300, 960 + n, cols=cols, rows=rows, pitch=360.0 / max(cols, rows)))
+    for prob in cases:
+        a, b, o = prob.copy().normalised(), prob.copy().normalised(), prob.copy().normalised()
+        run = (lambda z, **kw: api.refinement(z, **kw)[1]) if prob.mono else (lambda z, **kw: api.calibrate(z, **kw))
+        sa = run(a, max_num_iterations=5)
+        sb = run(b, max_num_iterations=5, exec_flags=lib.EXEC_ONE_VIEW_PER_PASS)
+        so = orc.solve(o, max_num_iterations=5)
+        assert sa["num_iterations"] == sb["num_iterations"] == so["num_iterations"]
+        assert [it["cost"] for it in sa["iterations"]] == [it["cost"] for it in sb["iterations"]]
+        assert np.array_equal(a.intr, b.intr) and np.array_equal(a.cam_rt, b.cam_rt) and np.array_equal(a.board_rt, b.board_rt)
+        for x, y in zip(sa["iterations"], so["iterations"]):
+            assert x["step_is_successful"] == y["step_is_successful"]
+            assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
+
+
 def test_gram4_two_passes_on_the_reference_board_at_size(hip_device):
     """The reference's own board (11 x 8 = 88 corners, main.cpp:190-191) at config-3 size (4 cameras x 500 views,
     176,000 corners): natural solve against the oracle, trace and every parameter block."""

@@ -593,3 +593,5 @@ __global__ __launch_bounds__(256, 4) void k_eval_gram4p(DevProblem P, DevState S
         part[256 + t] = (lds_all[256 + t] + lds_all[st + 256 + t]) + (lds_all[2 * st + 256 + t] + lds_all[3 * st + 256 + t]);
     }
 }
+
+#include "tscm_eval_gram4s.h"      // (an experiment of round 6: the views of a chunk as one stream of k-steps -- measured slower, opt-in)

@@ -222,6 +222,7 @@ struct DevProblem {
     const short *bid_lut;              // [C*C] tile of block (mi, mj), mi <= mj; -1 = no board is seen by both
     int bid_part_small[kSmallBids + 1]; // bid_part_ptr by value (rigs of <= kMaxCamLds cameras: no memory round trip in front of the partial tiles)
     int g4_per;                        // k_eval_gram4<KS, true>: corners of a pass (boards of more than 56 corners: g4_plan)
+    int g4s_ksv;                       // k_eval_gram4s: k-steps of a view, ceil(n_points / 4)
 };
 
 struct DevState {

@@ -194,6 +194,8 @@ struct tscm_solver {
     bool gram16 = false;                // this solve: TSCM_EXEC_GRAM_16X16
     bool solve_tiles = true;            // this solve: k_solve_reduced<.., MF = false> (the default; TSCM_EXEC_MFMA_REDUCED_SOLVE clears it)
     size_t lds_eval4 = 0;               // dynamic LDS of k_eval_gram4
+    bool eval4s = false;                // the views of a chunk as one stream of k-steps (k_eval_gram4s): boards whose passes leave lanes idle
+    size_t lds_eval4s = 0;
     EvalKernel eval4p = nullptr;        // boards of up to 32 corners: several views per pass (k_eval_gram4p); nullptr otherwise
     size_t lds_eval4p = 0;
     bool one_view_per_pass = false;     // this solve: TSCM_EXEC_ONE_VIEW_PER_PASS
@@ -731,7 +733,7 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     DevState &S = s->S;
     P.C = C; P.B = B; P.n_points = p->n_points; P.V = V; P.N = (int)N; P.n_pad = s->n_pad;
     P.rank = rank; P.world = world;
-    P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double)); P.g4_per = g4.per;
+    P.rp = rp; P.half = half_rows; P.lds_wave = (int)(lds_eval_bytes / sizeof(double)); P.g4_per = g4.per; P.g4s_ksv = (p->n_points + 3) / 4;
     P.n_chunks = (int)chunk_vb.size(); P.n_pairs = (int)n_pairs; P.n_pchunks = (int)pc_begin.size(); P.n_bids = n_bids;
     P.n_bchunks = (int)bc_begin.size(); P.n_tiles = n_tiles;
     std::vector<double> bxy(p->board_xy, p->board_xy + 2 * (size_t)p->n_points);
@@ -923,6 +925,17 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     s->lds_eval = 4 * lds_eval_bytes;
     s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, g4.ks);
     s->lds_eval4 = lds_eval4; s->eval4 = eval4; s->eval32 = f32_kernel(g4.ks, g4.passes > 1);
+    {
+        // the stream kernel (k_eval_gram4s, tscm_eval_gram4s.h): an experiment of round 6, TSCM_G4_STREAM=1 at create only
+        const int ksv = (p->n_points + 3) / 4;
+        const double fill = (double)p->n_points / (64.0 * g4.passes);
+        const char *e = std::getenv("TSCM_G4_STREAM");
+        (void)fill;
+        s->eval4s = ksv >= 9 && e && std::atoi(e) != 0;          // (measured slower on every board: opt-in only)
+        s->lds_eval4s = sizeof(double) * (size_t)eval_gram4s_lds_doubles(p->n_points);
+        if (s->lds_eval4s > 160 * 1024) s->eval4s = false;
+        if (s->eval4s && s->lds_eval4s > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram4s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval4s));
+    }
     if (g4.passes == 1 && g4.ks <= 8) {
         s->eval4p = g4p_kernel(g4.ks);
         s->lds_eval4p = 4 * sizeof(double) * (size_t)eval_gram4p_lds_doubles(p->n_points, g4.ks, g4p_views(g4.ks));
@@ -1145,6 +1158,7 @@ static int launch_eval(tscm_solver *s, int cand)
     // 9x6 .. 7x8 boards (53..56 corners per pass) get the variant with a compile-time LDS pitch
     if (s->f32_jacobian) launch_eval_kernel(s->eval32, grid, s->lds_eval32, s, e0, e1, cand);
     else if (!s->gram16 && s->eval4p && !s->one_view_per_pass) launch_eval_kernel(s->eval4p, grid, s->lds_eval4p, s, e0, e1, cand);     // small boards: views share a pass
+    else if (!s->gram16 && s->eval4s && !s->one_view_per_pass) launch_eval_kernel(k_eval_gram4s, grid, s->lds_eval4s, s, e0, e1, cand);      // the chunk's views as one stream of k-steps
     else if (!s->gram16) launch_eval_kernel(s->eval4, grid, s->lds_eval4, s, e0, e1, cand);       // every board size (round 6)
     else if (P.rp == 58) launch_eval_kernel(k_eval_gram<58>, grid, s->lds_eval, s, e0, e1, cand);
     else launch_eval_kernel(k_eval_gram<0>, grid, s->lds_eval, s, e0, e1, cand);
