@@ -446,14 +446,16 @@ def main():
         flops = n_local * FLOP_PER_CORNER
         bytes_per_corner = 16.0 + 168.0 / full.n_points
         # k_eval_gram4<KS, MULTI>: ceil(n / 56) passes per view of KS k-steps each (tscm_eval_gram4.h: g4_plan)
-        for cap in (16, 14):                                   # (g4_plan, tscm_kernels.h: 64-row passes where the LDS admits four workgroups per CU)
-            g4_passes = max(1, -(-full.n_points // (4 * cap)))
-            g4_ks = max(1, -(-(-(-full.n_points // g4_passes)) // 4))
-            if g4_ks <= 14 or 32 * (max(68 * g4_ks, 512) + 2 * full.n_points) <= 40 * 1024:
-                break
+        if stub:
+            g4_passes, g4_ks, g4_views = 1, 14, 1
+        else:                                                   # the library's own pass plan (g4_plan, tscm_kernels.h)
+            import ctypes as _C
+            _pl = [_C.c_int(0) for _ in range(4)]
+            lib.check(lib.lib().tscm_debug_gram_plan(full.n_points, *[_C.byref(x) for x in _pl]))
+            g4_passes, g4_ks, g4_views = _pl[0].value, _pl[2].value, _pl[3].value
         g4_name = f"k_eval_gram4<{g4_ks},{'true' if g4_passes > 1 else 'false'}>"
-        if g4_passes == 1 and g4_ks <= 8 and not (args.exec_flags & 512):      # boards of up to 32 corners: M views share a pass
-            g4_name = f"k_eval_gram4p<{g4_ks},{min(4, 16 // g4_ks)}>"
+        if g4_views > 1 and not (args.exec_flags & 512):       # boards of up to 32 corners: M views share a pass
+            g4_name = f"k_eval_gram4p<{g4_ks},{g4_views}>"
         achieved_tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = FP32_PEAK_TFLOPS if args.jacobian_fp32 else FP64_PEAK_TFLOPS
         roof = {

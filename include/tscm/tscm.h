@@ -237,6 +237,10 @@ int tscm_solver_create_timing(const tscm_solver *s, double out[5]);
  * views by device board), board_perm[its boards] = the caller's board (relative to *b0) that becomes device board k (boards
  * grouped by camera-set signature, unseen boards last).  Outputs other than n_views may be NULL. */
 int tscm_debug_layout_order(const tscm_problem *p, int rank, int world, int *n_views, int *dev2orig, int *board_perm, int *b0);
+/* TESTS / bench.py (host code): the pass plan of the Gram kernels for a board of n_points corners -- passes per view, corners per
+ * pass (a multiple of four), k-steps per pass (the kernels' template parameter KS <= 16) and, for boards of up to 32 corners, the
+ * views that share a pass.  The reference's 11 x 8 board: 2 passes of 44 corners, KS = 11. */
+int tscm_debug_gram_plan(int n_points, int *passes, int *corners_per_pass, int *k_steps, int *views_per_pass);
 /* A hand-off between workgroups of one launch (evaluation's reductions -> control step; Schur-complement tiles -> reduced
  * solve -> back-substitution) that does not
  * come within its time bound (0.5 s: a debugger, a co-tenant, a context switch -- or a fault) stops the solve on the

@@ -85,3 +85,30 @@ def test_device_orders_of_every_shard(world):
         assert dev2orig[:n].tolist() == order and perm[:len(boards)].tolist() == want_perm
         seen += n
     assert seen == int(np.count_nonzero(p.view_count > 0))
+
+
+def _plan(n):
+    out = [C.c_int(0) for _ in range(4)]
+    lib.check(lib.lib().tscm_debug_gram_plan(n, *[C.byref(x) for x in out]))
+    return tuple(x.value for x in out)          # passes, corners per pass, k-steps, views per pass
+
+
+def test_pass_plan_of_the_gram_kernels():
+    """g4_plan (round 6: the tuned Gram kernel serves every board size): known boards, and the invariants over 1..600 corners --
+    a pass is a multiple of four corners and at most 64 rows, the passes cover the board and are balanced (no pass could be
+    dropped), 64-row passes only where tile + board points leave four workgroups per CU their LDS."""
+    assert _plan(54) == (1, 56, 14, 1)           # BASELINE's 9 x 6: the round-3 kernel's tile
+    assert _plan(88) == (2, 44, 11, 1)           # the reference's 11 x 8 (main.cpp:190-191)
+    assert _plan(64) == (1, 64, 16, 1) and _plan(63) == (1, 64, 16, 1) and _plan(57) == (1, 60, 15, 1)      # one pass of up to 64 rows
+    assert _plan(48) == (1, 48, 12, 1) and _plan(42) == (1, 44, 11, 1)
+    assert _plan(30) == (1, 32, 8, 2) and _plan(20) == (1, 20, 5, 3) and _plan(12) == (1, 12, 3, 4) and _plan(4) == (1, 4, 1, 4)
+    assert _plan(70) == (2, 36, 9, 1) and _plan(108) == (2, 56, 14, 1) and _plan(117) == (2, 60, 15, 1)
+    assert _plan(128) == (3, 44, 11, 1)          # two passes of 64 rows would not leave four workgroups per CU their LDS
+    for n in range(1, 601):
+        passes, per, ks, m = _plan(n)
+        assert per == 4 * ks and 1 <= ks <= 16 and passes * per >= n and (passes - 1) * per < n
+        assert m == (min(4, 16 // ks) if passes == 1 and ks <= 8 else 1) and m * ks <= 16
+        if ks > 14:
+            assert 32 * (max(68 * ks, 512) + 2 * n) <= 40 * 1024
+        else:
+            assert passes == -(-n // 56) or passes == -(-n // 64)

@@ -416,6 +416,18 @@ static int layout_orders(const tscm_problem *p, int b0, int b1, std::vector<int>
     return 0;
 }
 
+// the pass plan of the Gram kernels for a board of n_points corners (g4_plan, tscm_kernels.h): host code
+extern "C" int tscm_debug_gram_plan(int n_points, int *passes, int *corners_per_pass, int *k_steps, int *views_per_pass)
+{
+    if (n_points < 1) return fail(TSCM_E_INVALID, "n_points must be positive");
+    const G4Plan g = g4_plan(n_points);
+    if (passes) *passes = g.passes;
+    if (corners_per_pass) *corners_per_pass = g.per;
+    if (k_steps) *k_steps = g.ks;
+    if (views_per_pass) *views_per_pass = g.passes == 1 && g.ks <= 8 ? g4p_views(g.ks) : 1;       // (k_eval_gram4p: boards of up to 32 corners)
+    return 0;
+}
+
 extern "C" int tscm_debug_layout_order(const tscm_problem *p, int rank, int world, int *n_views_out, int *dev2orig, int *board_perm_out, int *b0_out)
 {
     if (int rc = validate(p)) return rc;

@@ -116,7 +116,7 @@ class CCornerSet(C.Structure):
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_device_peak_fp64_ex", "tscm_device_peak_fp32_mfma", "tscm_default_options",
-    "tscm_solver_create", "tscm_solver_create_timing", "tscm_debug_layout_order", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_debug_perturb_exchange", "tscm_solver_reruns", "tscm_solver_solve", "tscm_solver_upload_params",
+    "tscm_solver_create", "tscm_solver_create_timing", "tscm_debug_layout_order", "tscm_debug_gram_plan", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_debug_perturb_exchange", "tscm_solver_reruns", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
     "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
@@ -172,6 +172,7 @@ def lib():
     L.tscm_solver_set_comm.argtypes = [vp, vp]
     L.tscm_solver_create_timing.argtypes = [vp, dp]
     L.tscm_debug_layout_order.argtypes = [C.POINTER(CProblem), C.c_int, C.c_int, ip, ip, ip, ip]
+    L.tscm_debug_gram_plan.argtypes = [C.c_int, ip, ip, ip, ip]
     L.tscm_solver_debug_withhold_handoff.argtypes = [vp, C.c_int]
     L.tscm_solver_debug_perturb_exchange.argtypes = [vp, C.c_int, C.c_int]
     L.tscm_solver_reruns.argtypes = [vp]
