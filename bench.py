@@ -340,6 +340,10 @@ def main():
                              f"TSCM_BENCH_EXCHANGE=ipc runs the {world} rank processes on the visible device(s) with the library's IPC exchange")
         device = local_rank % max(1, n_dev)
 
+    if not stub and os.environ.get("TSCM_BENCH_EXPERIMENT"):              # A/B runs of the layout experiments: "which=value[,which=value]"
+        for kv in os.environ["TSCM_BENCH_EXPERIMENT"].split(","):
+            k, v = kv.split("=")
+            lib.check(lib.lib().tscm_debug_experiment(int(k), int(v)))
     t_create = time.perf_counter()
     solver = Solver(full, device=device, rank=rank, world=world)          # H2D of this rank's observations + layout build
     t_create = time.perf_counter() - t_create

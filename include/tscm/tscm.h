@@ -237,6 +237,14 @@ int tscm_solver_create_timing(const tscm_solver *s, double out[5]);
  * views by device board), board_perm[its boards] = the caller's board (relative to *b0) that becomes device board k (boards
  * grouped by camera-set signature, unseen boards last).  Outputs other than n_views may be NULL. */
 int tscm_debug_layout_order(const tscm_problem *p, int rank, int world, int *n_views, int *dev2orig, int *board_perm, int *b0);
+/* TESTS / A-B tools only: experiment switches of the layout the NEXT tscm_solver_create builds (process-wide; both were built, are
+ * bit-identical to the default and measured slower in round 6 -- HISTORY A.7): value 0 = off (the default). */
+enum {
+    TSCM_EXPERIMENT_SCHUR_CHUNK_32 = 0,   /* Schur-complement chunks of 32 boards, k_schur_gram<NV, false, 32> at three workgroups per CU */
+    TSCM_EXPERIMENT_GRAM_STREAM = 1,      /* k_eval_gram4s: the views of a chunk as one stream of k-steps (boards of >= 33 corners)      */
+    TSCM_EXPERIMENT_COUNT = 2
+};
+int tscm_debug_experiment(int which, int value);
 /* TESTS / bench.py (host code): the pass plan of the Gram kernels for a board of n_points corners -- passes per view, corners per
  * pass (a multiple of four), k-steps per pass (the kernels' template parameter KS <= 16) and, for boards of up to 32 corners, the
  * views that share a pass.  The reference's 11 x 8 board: 2 passes of 44 corners, KS = 11. */

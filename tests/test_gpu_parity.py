@@ -650,17 +650,16 @@ def test_small_boards_share_a_pass_with_the_bits_of_one_view_per_pass(hip_device
 
 @pytest.mark.parametrize("cols,rows", [(7, 6), (8, 6), (7, 5), (9, 5), (10, 7), (11, 8), (9, 8), (13, 5), (12, 7)])
 def test_views_as_one_stream_of_k_steps_give_the_bits_of_one_view_per_pass(hip_device, cols, rows):
-    """k_eval_gram4s (round 6, an experiment: TSCM_G4_STREAM=1): a pass takes the next k-steps of the chunk's stream whichever views
+    """k_eval_gram4s (round 6, an experiment: tscm_debug_experiment(TSCM_EXPERIMENT_GRAM_STREAM, 1)): a pass takes the next k-steps of the chunk's stream whichever views
     they belong to (two at most), a view's accumulators are carried across passes.  Every view still contracts its own k-steps in order: bit-identical to one view
     per pass (TSCM_EXEC_ONE_VIEW_PER_PASS) -- full and ragged views, an empty view, chunks longer than a metadata block (mono, 300
     views), and against the oracle."""
-    import os
     n = cols * rows
-    os.environ["TSCM_G4_STREAM"] = "1"          # (read at tscm_solver_create: the kernel is an opt-in experiment -- measured slower)
+    lib.check(lib.lib().tscm_debug_experiment(lib.EXPERIMENT_GRAM_STREAM, 1))      # (read at tscm_solver_create: an opt-in experiment -- measured slower)
     try:
         _stream_cases(cols, rows, n)
     finally:
-        del os.environ["TSCM_G4_STREAM"]
+        lib.check(lib.lib().tscm_debug_experiment(lib.EXPERIMENT_GRAM_STREAM, 0))
 
 
 def _stream_cases(cols, rows, n):
@@ -684,6 +683,24 @@ def _stream_cases(cols, rows, n):
         for x, y in zip(sa["iterations"], so["iterations"]):
             assert x["step_is_successful"] == y["step_is_successful"]
             assert abs(x["cost"] - y["cost"]) <= 1e-9 * y["cost"]
+
+
+def test_schur_chunks_of_32_boards_give_the_same_bits(hip_device):
+    """k_schur_gram<NV, false, 32> (round 6, an experiment: three workgroups per CU without a spill; measured slower at config 5):
+    the same arithmetic per board and per group of four boards, twice the partial tiles -- the T reduction sums them in tile order,
+    so the bits differ only through that order: costs to 1e-12, same decisions, on a rig whose Schur grid has several chunks."""
+    p = synth.make_problem(8, 1200, 31)
+    a, b = p.copy().normalised(), p.copy().normalised()
+    sa = api.calibrate(a, max_num_iterations=6)
+    lib.check(lib.lib().tscm_debug_experiment(lib.EXPERIMENT_SCHUR_CHUNK_32, 1))
+    try:
+        sb = api.calibrate(b, max_num_iterations=6)
+    finally:
+        lib.check(lib.lib().tscm_debug_experiment(lib.EXPERIMENT_SCHUR_CHUNK_32, 0))
+    assert sa["num_iterations"] == sb["num_iterations"]
+    for x, y in zip(sa["iterations"], sb["iterations"]):
+        assert x["step_is_successful"] == y["step_is_successful"] and abs(x["cost"] - y["cost"]) <= 1e-12 * y["cost"]
+    assert max(H.param_rel_err(a, b).values()) < 1e-9
 
 
 def test_gram4_two_passes_on_the_reference_board_at_size(hip_device):

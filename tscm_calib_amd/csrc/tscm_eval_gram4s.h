@@ -1,4 +1,4 @@
-// tscm_eval_gram4s.h -- k_eval_gram4s, an EXPERIMENT of round 6 (included by tscm_eval_gram4.h; TSCM_G4_STREAM=1 in the environment at
+// tscm_eval_gram4s.h -- k_eval_gram4s, an EXPERIMENT of round 6 (included by tscm_eval_gram4.h; tscm_debug_experiment(TSCM_EXPERIMENT_GRAM_STREAM, 1) in front of
 // tscm_solver_create selects it, the default never does): built, bit-identical to the other Gram kernels, and SLOWER than one view
 // per pass on every board measured (7 x 6: 61.8 us against 48.3; 8 x 6: 58.8 / 50.0; 10 x 7: 84.5 / 81.6; 11 x 8: 91.1 / 85.4; 9 x 6:
 // 67.4 / 53.7 at config-4 size) -- the passes it saves cost less than what every pass pays for the per-lane view bookkeeping, the

@@ -1604,7 +1604,7 @@ struct RawTc {
 #define TSCM_SCHUR_OCC 2        // workgroups per CU the NV <= 2 instantiation that serves grids of several rounds is compiled for.  3 (round 6, measured): the
                                 // compiler meets 168 VGPRs with 196 bytes of scratch per lane and the kernel takes 63.7 us instead of 51.9 at config 5
 #endif
-// CB: boards of a chunk at most.  64, or 32 (round 6, an experiment: TSCM_SCHUR_CB=32 at create): half the W columns per thread
+// CB: boards of a chunk at most.  64, or 32 (round 6, an experiment: tscm_debug_experiment(TSCM_EXPERIMENT_SCHUR_CHUNK_32, 1)): half the W columns per thread
 // (96 -> 48 VGPRs at NV = 2), 167 registers without a spill, THREE workgroups per CU.  The same arithmetic per board and per
 // 4-board group; twice the workgroups and partial tiles.  Measured at config 5: 57.4 us against 52.3 -- not the default.
 template <int NV, bool RIDE = false, int CB = kChunkBoards>

@@ -46,6 +46,7 @@ int tscm_set_error(int code, const std::string &msg) { return fail(code, msg); }
             return fail(TSCM_E_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));             \
     } while (0)
 
+static int g_experiment[TSCM_EXPERIMENT_COUNT] = { 0 };      // tscm_debug_experiment
 static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Exchange backends of the frame-sharded solve.  RCCL: one process per GPU (the production path).  LOCAL: all ranks
@@ -416,6 +417,16 @@ static int layout_orders(const tscm_problem *p, int b0, int b1, std::vector<int>
     return 0;
 }
 
+// Experiment switches of the LAYOUT a solver is created with (round 6: built, measured, not the default -- HISTORY A.7).  Process-wide,
+// read by tscm_solver_create; an entry point and not an environment variable read inside the library (the tests and the A/B tools set
+// them explicitly), not tscm_options either: nothing a production caller can set makes a solve slower.
+extern "C" int tscm_debug_experiment(int which, int value)
+{
+    if (which < 0 || which >= TSCM_EXPERIMENT_COUNT) return fail(TSCM_E_INVALID, "unknown experiment");
+    g_experiment[which] = value;
+    return 0;
+}
+
 // the pass plan of the Gram kernels for a board of n_points corners (g4_plan, tscm_kernels.h): host code
 extern "C" int tscm_debug_gram_plan(int n_points, int *passes, int *corners_per_pass, int *k_steps, int *views_per_pass)
 {
@@ -667,14 +678,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[1], reinterpret_cast<const void *>(k_schur_gram<1, true>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[2], reinterpret_cast<const void *>(k_schur_gram<2, true>), 256, 0));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident_ride[3], reinterpret_cast<const void *>(k_schur_gram<3, true>), 256, 0));
-        // Round 6, an experiment switch (TSCM_SCHUR_CB=32 in the environment at create): chunks of 32 boards and k_schur_gram<NV, false, 32>
+        // Round 6, an experiment switch (tscm_debug_experiment(TSCM_EXPERIMENT_SCHUR_CHUNK_32, 1) before create): chunks of 32 boards and k_schur_gram<NV, false, 32>
         // at THREE workgroups per CU (167 registers, no spill) -- the occupancy the round-5 analysis asked for.  Measured at config 5:
         // 57.4 us against 52.3 with 64-board chunks at two per CU (twice the workgroups, each with its head, its control outcome and
         // its four barriers): not the default (HISTORY A.7).
-        {
-            const char *e = std::getenv("TSCM_SCHUR_CB");
-            s->schur_cb = e && std::atoi(e) == 32 ? 32 : kChunkBoards;
-        }
+        s->schur_cb = g_experiment[TSCM_EXPERIMENT_SCHUR_CHUNK_32] ? 32 : kChunkBoards;
         if (s->schur_cb == 32) {
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[1], reinterpret_cast<const void *>(k_schur_gram<1, false, 32>), 256, 0));
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->schur_resident[2], reinterpret_cast<const void *>(k_schur_gram<2, false, 32>), 256, 0));
@@ -938,12 +946,11 @@ extern "C" int tscm_solver_create_sharded(const tscm_problem *p, int device, int
     s->lds_eval32 = sizeof(double) * (size_t)eval_f32_lds_doubles(p->n_points, g4.ks);
     s->lds_eval4 = lds_eval4; s->eval4 = eval4; s->eval32 = f32_kernel(g4.ks, g4.passes > 1);
     {
-        // the stream kernel (k_eval_gram4s, tscm_eval_gram4s.h): an experiment of round 6, TSCM_G4_STREAM=1 at create only
+        // the stream kernel (k_eval_gram4s, tscm_eval_gram4s.h): an experiment of round 6, tscm_debug_experiment(TSCM_EXPERIMENT_GRAM_STREAM, 1) only
         const int ksv = (p->n_points + 3) / 4;
         const double fill = (double)p->n_points / (64.0 * g4.passes);
-        const char *e = std::getenv("TSCM_G4_STREAM");
         (void)fill;
-        s->eval4s = ksv >= 9 && e && std::atoi(e) != 0;          // (measured slower on every board: opt-in only)
+        s->eval4s = ksv >= 9 && g_experiment[TSCM_EXPERIMENT_GRAM_STREAM] != 0;          // (measured slower on every board: opt-in only)
         s->lds_eval4s = sizeof(double) * (size_t)eval_gram4s_lds_doubles(p->n_points);
         if (s->lds_eval4s > 160 * 1024) s->eval4s = false;
         if (s->eval4s && s->lds_eval4s > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_gram4s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_eval4s));

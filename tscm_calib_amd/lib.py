@@ -29,6 +29,8 @@ EXEC_GRAPH_REDUCED_ORDER = 64
 EXEC_SEPARATE_STATS = 128
 EXEC_MFMA_REDUCED_SOLVE = 256
 EXEC_ONE_VIEW_PER_PASS = 512
+EXPERIMENT_SCHUR_CHUNK_32 = 0
+EXPERIMENT_GRAM_STREAM = 1
 
 E_NAMES = {0: "TSCM_OK", -1: "TSCM_E_INVALID", -2: "TSCM_E_NO_DEVICE", -3: "TSCM_E_HIP",
            -4: "TSCM_E_RCCL", -5: "TSCM_E_UNSUPPORTED", -6: "TSCM_E_NOMEM", -7: "TSCM_E_PEER"}
@@ -116,7 +118,7 @@ class CCornerSet(C.Structure):
 # every symbol include/tscm/tscm.h declares
 EXPORTS = [
     "tscm_abi_version", "tscm_last_error", "tscm_device_count", "tscm_device_synchronize", "tscm_device_peak_fp64", "tscm_device_peak_fp64_ex", "tscm_device_peak_fp32_mfma", "tscm_default_options",
-    "tscm_solver_create", "tscm_solver_create_timing", "tscm_debug_layout_order", "tscm_debug_gram_plan", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_debug_perturb_exchange", "tscm_solver_reruns", "tscm_solver_solve", "tscm_solver_upload_params",
+    "tscm_solver_create", "tscm_solver_create_timing", "tscm_debug_layout_order", "tscm_debug_gram_plan", "tscm_debug_experiment", "tscm_solver_set_comm", "tscm_solver_debug_withhold_handoff", "tscm_solver_debug_perturb_exchange", "tscm_solver_reruns", "tscm_solver_solve", "tscm_solver_upload_params",
     "tscm_solver_solve_resident", "tscm_solver_download_params", "tscm_solver_destroy",
     "tscm_solver_kernel_time", "tscm_solver_exchange_time", "tscm_solve_multi", "tscm_solve_mono", "tscm_eval_functor",
     "tscm_eval_normal_equations", "tscm_project_points", "tscm_unproject_pixels",
@@ -173,6 +175,7 @@ def lib():
     L.tscm_solver_create_timing.argtypes = [vp, dp]
     L.tscm_debug_layout_order.argtypes = [C.POINTER(CProblem), C.c_int, C.c_int, ip, ip, ip, ip]
     L.tscm_debug_gram_plan.argtypes = [C.c_int, ip, ip, ip, ip]
+    L.tscm_debug_experiment.argtypes = [C.c_int, C.c_int]
     L.tscm_solver_debug_withhold_handoff.argtypes = [vp, C.c_int]
     L.tscm_solver_debug_perturb_exchange.argtypes = [vp, C.c_int, C.c_int]
     L.tscm_solver_reruns.argtypes = [vp]
